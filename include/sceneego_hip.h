@@ -1,0 +1,119 @@
+/*
+ * sceneego_hip.h — C ABI of libsceneego_hip.so (gfx950 / MI355X).
+ *
+ * The SceneEgo reference (jianwang-mpi/SceneEgo) is pure Python and has no FFI / plugin registry:
+ * its depth-aware voxel pose path dispatches ATen operators (and numpy for the voxeliser).  This
+ * library is what stands in for those operator calls; each entry point below names the reference
+ * call site (file:line, relative to the reference repo) it replaces.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes; no torch / HIP types in the signatures (`stream` is a hipStream_t
+ *     passed as void*, NULL = default stream);
+ *   - every pointer is DEVICE memory owned by the caller; nothing is allocated, freed or
+ *     synchronised inside; launches are asynchronous on `stream` and hipGraph-capturable;
+ *   - return value: 0 on success, otherwise the hipError_t of the failed call, or
+ *     SE_ERR_BAD_ARG (-1) for an unsupported shape/argument (nothing is launched then);
+ *   - activations are float32, channels-last: volumes are [B][Z][Y][X][C] ("NDHWC"; the reference's
+ *     meshgrid order i,j,k of voxel_net_depth.py:117-121 is our Z,Y,X, flat voxel n = (i*G + j)*G + k),
+ *     images are [B][H][W][C].
+ */
+#ifndef SCENEEGO_HIP_H
+#define SCENEEGO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SE_ERR_BAD_ARG (-1)
+
+/* epilogue flags of se_conv3d_f32 / se_deconv3d_k2s2_f32 */
+#define SE_EPI_RELU          1   /* y = max(y, 0)                                                    */
+#define SE_EPI_RES_PRE_RELU  2   /* y += residual BEFORE the ReLU  (Res3DBlock: relu(res + skip))     */
+#define SE_EPI_RES_POST_RELU 4   /* y += residual AFTER the ReLU   (decoder: upsample(x) + skip_x)    */
+#define SE_EPI_OUT_PLANAR    8   /* write [B][Cout][voxels] (NCDHW) instead of NDHWC                  */
+
+/* ABI version; bumped on any signature change. */
+int se_abi_version(void);
+
+/* Occupancy voxeliser.  Replaces VoxelNetwork_depth.depth_map_to_voxel_numpy +
+ * point_cloud_to_voxel_numpy (network/voxel_net_depth.py:194-222; per-sample host loop :252-255).
+ *   depth    [B][depth_h][depth_w] float32 metres
+ *   ray_tab  [up][up][3] float64: unit ray of padded-image pixel (x'+pad_x, y), indexed [y][x']
+ *   occ      [B][G][G][G] float32, written as {0,1} (cleared inside)
+ * Per pixel (y, x') of the `up` x `up` nearest-resized depth (src row floor(y*depth_h/up), src col
+ * floor(x'*depth_w/up)): p = ray*d in float64; q = rint(((p.x+side/2)*G)/side, ((p.y+side/2)*G)/side,
+ * (p.z*G)/side) (half-to-even, unfused); if 0<=q<=G-1 on all axes occ[qx][qy][qz] = 1.  If pad_x > 0
+ * the zero-padded columns contribute the point (0,0,0).  Bit-exact with the reference.          */
+int se_voxelize_f64(const float* depth, const double* ray_tab, float* occ,
+                    int batch, int depth_h, int depth_w, int up, int pad_x,
+                    int volume_size, double cuboid_side, void* stream);
+
+/* Same for a full-width depth map without resize/pad: dataset/real_depth_utils.py:29-60
+ * (`voxel_output=True` path).  ray_tab [depth_h][depth_w][3] float64 indexed [y][x].            */
+int se_voxelize_full_f64(const float* depth, const double* ray_tab, float* occ,
+                         int batch, int depth_h, int depth_w,
+                         int volume_size, double cuboid_side, void* stream);
+
+/* Table-driven bilinear voxel gather.  Replaces nn.Upsample(1024^2) + ConstantPad2d(128) +
+ * F.grid_sample (network/voxel_net_depth.py:60-61,238,243; utils/op.py:194-214) without the
+ * 1024x1280 intermediate.
+ *   feat [B][texels][channels] float32 (NHWC feature map, texels = H*W)
+ *   idx  [voxels][4] int32 texel index per tap (-1 = zero tap), w [voxels][4] float32 tap weights
+ *   out  [B][voxels][out_stride_c]; channels [out_c_offset, out_c_offset+channels) are written.
+ * channels % 4 == 0, out_stride_c % 4 == 0, out_c_offset % 4 == 0.                                */
+int se_unproject_gather_f32(const float* feat, const int* idx, const float* w, float* out,
+                            int batch, int texels, int channels, int voxels,
+                            int out_stride_c, int out_c_offset, void* stream);
+
+/* with_intersection=True input assembly (network/voxel_net_depth.py:258-260): given vol channels
+ * [0,c) already in `buf` [B][voxels][stride_c] and occ [B][voxels], writes buf[..., c:2c] = vol*occ. */
+int se_intersection_f32(float* buf, const float* occ, int batch, int voxels, int channels,
+                        int stride_c, void* stream);
+
+/* Weight preparation: folds an eval-mode BatchNorm3d into the convolution and re-orders the weights
+ * into the MFMA fragment order the conv kernels read (v_mfma_f32_16x16x4_f32 A-operand blocks).
+ * Replaces nothing at run time in the reference — it is what makes Conv3d+BatchNorm3d(+ReLU)
+ * (network/v2v.py:12-14,24-30,35-38,61-63) one kernel.
+ *   w      Conv3d weight [cout][cin][k][k][k], or (transposed != 0) ConvTranspose3d weight [cin][cout][2][2][2]
+ *   b      conv bias [cout] or NULL
+ *   gamma,beta,mean,var  BatchNorm3d weight/bias/running_mean/running_var [cout], or all NULL (no BN)
+ *   wpack  out, se_conv3d_packed_elems(...) floats;  bpack out, cout_pad floats (cout rounded up to 16)
+ * cin_pad >= cin is the channel count of the activation tensor the conv will read (multiple of 16;
+ * extra channels get zero weights).                                                               */
+int se_conv3d_pack_f32(const float* w, const float* b, const float* gamma, const float* beta,
+                       const float* mean, const float* var, float eps,
+                       float* wpack, float* bpack,
+                       int cout, int cin, int cin_pad, int ksize, int transposed, void* stream);
+long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, int transposed);
+
+/* Conv3d (k = 1, 3 or 7, stride 1, zero padding (k-1)/2) + folded BN + epilogue.
+ * Replaces Basic3DBlock / Res3DBlock convs and output_layer (network/v2v.py:8-43,161).
+ *   in  [B][D][D][D][cin_pad]   out [B][D][D][D][cout] (or planar, SE_EPI_OUT_PLANAR)
+ *   residual: same shape as out (NDHWC) or NULL.  cin_pad % 16 == 0; cout % 16 == 0 unless planar. */
+int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
+                  float* out, int batch, int dim, int cin_pad, int cout, int ksize, int flags,
+                  void* stream);
+
+/* ConvTranspose3d(k=2, s=2) + folded BN + ReLU (+ skip).  Replaces Upsample3DBlock and the decoder
+ * adds (network/v2v.py:55-67,124-137).  in [B][D]^3[cin] -> out [B][2D]^3[cout]; residual like out. */
+int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
+                         float* out, int batch, int dim, int cin, int cout, int flags, void* stream);
+
+/* F.max_pool3d(kernel 2, stride 2) (network/v2v.py:46-52).  in [B][D]^3[C] -> out [B][D/2]^3[C]. */
+int se_maxpool3d_2_f32(const float* in, float* out, int batch, int dim, int channels, void* stream);
+
+/* 3D soft-argmax.  Replaces op.integrate_tensor_3d_with_coordinates (utils/op.py:83-96).
+ *   vol    [rows][voxels] float32 (rows = B*joints, planar logits, already multiplied by volume_multiplier)
+ *   coord  [voxels][3] float32 voxel-centre coordinates
+ *   out_vol[rows][voxels] softmax(vol) (mode 1) or relu(vol) (mode 0)
+ *   joints [rows][3] = sum_n out_vol[n] * coord[n]
+ *   scratch: se_softargmax3d_scratch_elems(rows) floats of workspace.                              */
+int se_softargmax3d_f32(const float* vol, const float* coord, float* out_vol, float* joints,
+                        float* scratch, int rows, int voxels, int mode, void* stream);
+long long se_softargmax3d_scratch_elems(int rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCENEEGO_HIP_H */

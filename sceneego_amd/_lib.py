@@ -1,0 +1,166 @@
+"""ctypes binding of ``libsceneego_hip.so`` (C ABI declared in ``include/sceneego_hip.h``).
+
+PyTorch is only the allocator and stream provider here: every call passes ``tensor.data_ptr()`` and the
+current HIP stream.  There is deliberately NO fallback: if the shared library is missing, or a tensor
+is not on a HIP device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsceneego_hip.so")
+ABI_VERSION = 1
+
+EPI_RELU = 1
+EPI_RES_PRE_RELU = 2
+EPI_RES_POST_RELU = 4
+EPI_OUT_PLANAR = 8
+
+_vp, _i, _f, _d, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong
+
+# name -> (restype, argtypes); must list every symbol of include/sceneego_hip.h (tests/test_abi.py checks)
+SIGNATURES = {
+    "se_abi_version": (_i, []),
+    "se_voxelize_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _vp]),
+    "se_voxelize_full_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _vp]),
+    "se_unproject_gather_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "se_intersection_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "se_conv3d_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_conv3d_packed_elems": (_ll, [_i, _i, _i, _i]),
+    "se_conv3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "se_deconv3d_k2s2_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_maxpool3d_2_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "se_softargmax3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "se_softargmax3d_scratch_elems": (_ll, [_i]),
+}
+
+_lib = None
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library once; raise loudly when it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise HipExtensionError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or sceneego_amd/csrc/build.sh). The SceneEgo hot path has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.se_abi_version()
+    if got != ABI_VERSION:
+        raise HipExtensionError(f"libsceneego_hip.so ABI {got} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def require_hip(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipExtensionError("SceneEgo HIP operators need tensors on a HIP device (got %s)" % t.device)
+    load()
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(code: int, what: str) -> None:
+    if code != 0:
+        raise HipExtensionError(f"{what} failed with code {code}" + (" (bad argument)" if code == -1 else " (hipError_t)"))
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+
+
+# ---------------------------------------------------------------------------------------------
+def voxelize(depth, ray_tab, occ, batch, depth_h, depth_w, up, pad_x, volume_size, cuboid_side):
+    require_hip(depth, ray_tab, occ)
+    _chk_f32(depth, occ)
+    assert ray_tab.dtype == torch.float64 and ray_tab.is_contiguous()
+    _check(load().se_voxelize_f64(_ptr(depth), _ptr(ray_tab), _ptr(occ), batch, depth_h, depth_w, up, pad_x,
+                                  volume_size, float(cuboid_side), _stream()), "se_voxelize_f64")
+
+
+def voxelize_full(depth, ray_tab, occ, batch, depth_h, depth_w, volume_size, cuboid_side):
+    require_hip(depth, ray_tab, occ)
+    _chk_f32(depth, occ)
+    assert ray_tab.dtype == torch.float64 and ray_tab.is_contiguous()
+    _check(load().se_voxelize_full_f64(_ptr(depth), _ptr(ray_tab), _ptr(occ), batch, depth_h, depth_w,
+                                       volume_size, float(cuboid_side), _stream()), "se_voxelize_full_f64")
+
+
+def unproject_gather(feat, idx, w, out, batch, texels, channels, voxels, out_stride_c, out_c_offset):
+    require_hip(feat, idx, w, out)
+    _chk_f32(feat, w, out)
+    assert idx.dtype == torch.int32 and idx.is_contiguous()
+    _check(load().se_unproject_gather_f32(_ptr(feat), _ptr(idx), _ptr(w), _ptr(out), batch, texels, channels,
+                                          voxels, out_stride_c, out_c_offset, _stream()), "se_unproject_gather_f32")
+
+
+def intersection(buf, occ, batch, voxels, channels, stride_c):
+    require_hip(buf, occ)
+    _chk_f32(buf, occ)
+    _check(load().se_intersection_f32(_ptr(buf), _ptr(occ), batch, voxels, channels, stride_c, _stream()),
+           "se_intersection_f32")
+
+
+def conv3d_packed_elems(cout, cin_pad, ksize, transposed) -> int:
+    return int(load().se_conv3d_packed_elems(cout, cin_pad, ksize, 1 if transposed else 0))
+
+
+def conv3d_pack(w, b, gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_pad, ksize, transposed):
+    require_hip(w, wpack, bpack)
+    _chk_f32(w, b, gamma, beta, mean, var, wpack, bpack)
+    _check(load().se_conv3d_pack_f32(_ptr(w), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), float(eps),
+                                     _ptr(wpack), _ptr(bpack), cout, cin, cin_pad, ksize, 1 if transposed else 0,
+                                     _stream()), "se_conv3d_pack_f32")
+
+
+def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin_pad, cout, ksize, flags):
+    require_hip(inp, out)
+    _check(load().se_conv3d_f32(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim, cin_pad,
+                                cout, ksize, flags, _stream()), "se_conv3d_f32")
+
+
+def deconv3d_k2s2(inp, wpack, bpack, residual, out, batch, dim, cin, cout, flags):
+    require_hip(inp, out)
+    _check(load().se_deconv3d_k2s2_f32(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim,
+                                       cin, cout, flags, _stream()), "se_deconv3d_k2s2_f32")
+
+
+def maxpool3d_2(inp, out, batch, dim, channels):
+    require_hip(inp, out)
+    _check(load().se_maxpool3d_2_f32(_ptr(inp), _ptr(out), batch, dim, channels, _stream()), "se_maxpool3d_2_f32")
+
+
+def softargmax3d_scratch_elems(rows) -> int:
+    return int(load().se_softargmax3d_scratch_elems(rows))
+
+
+def softargmax3d(vol, coord, out_vol, joints, rows, voxels, mode, scratch=None):
+    require_hip(vol, coord, out_vol, joints)
+    _chk_f32(vol, coord, out_vol, joints)
+    if scratch is None:
+        scratch = torch.empty(softargmax3d_scratch_elems(rows), device=vol.device, dtype=torch.float32)
+    _check(load().se_softargmax3d_f32(_ptr(vol), _ptr(coord), _ptr(out_vol), _ptr(joints), _ptr(scratch), rows,
+                                      voxels, mode, _stream()), "se_softargmax3d_f32")

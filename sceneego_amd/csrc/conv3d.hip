@@ -1,0 +1,320 @@
+// V2V 3D convolutions on the gfx950 matrix cores, exact float32 (v_mfma_f32_16x16x4_f32).
+//
+// Layout: activations are channels-last [B][Z][Y][X][C]; a convolution is the implicit GEMM
+//     out[cout][voxel] = sum_{tap, cin} W[cout][cin][tap] * in[voxel + tap][cin]
+// One MFMA computes a 16(cout) x 16(voxel) tile over 4 values of k.  Operand maps (guide §3):
+//     A: lane l holds A[i = l&15][k = l>>4]   -> weights,     i = cout
+//     B: lane l holds B[k = l>>4][j = l&15]   -> activations, j = voxel
+//     D: lane l holds D[i = 4*(l>>4) + r][j = l&15], r = 0..3 -> 4 consecutive couts of ONE voxel,
+//        i.e. a 16-byte channels-last store per lane.
+// A lane reads its activations as ONE 16-byte load: 4 consecutive channels c0..c0+3 with
+// c0 = 16*cg + 4*(l>>4).  The four MFMAs j = 0..3 that consume it contract the channel set
+// {16*cg + 4*h + j : h = 0..3}; the weight blocks are packed to match (se_conv3d_pack_f32), so a
+// 16-channel group of one tap costs one 16-B load per operand and 4 MFMAs per (cout tile, voxel tile).
+// The f32 MFMA is bit-for-bit an fmaf chain: no precision is traded for the matrix pipe.
+//
+// This file: weight packer (+ BatchNorm fold), the generic "direct" kernel (activations straight from
+// global/L2, any k in {1,3,7}, any volume size, batch flattened into the voxel axis — used for the small
+// pyramid levels and as the always-available path), ConvTranspose3d k2s2, and max-pool.
+// The LDS-tiled kernels for the 64^3/32^3 levels live in conv3d_tiled.hip.
+#include "common.h"
+
+namespace {
+
+__host__ __device__ inline int round_up16(int v) { return (v + 15) & ~15; }
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: wpack[tap][cg][nt][lane][j] = W[cout = 16*nt + (lane&15)][cin = 16*cg + 4*(lane>>4) + j][tap] * scale[cout]
+// bpack[cout] = (b - mean) * scale + beta,  scale = gamma / sqrt(var + eps)    (identity without BN)
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                            const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                            float* __restrict__ wpack, float* __restrict__ bpack, int cout, int cin, int cin_pad,
+                            int taps, int transposed, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cgs = cin_pad / 16;
+    const int nts = round_up16(cout) / 16;
+    if (t < round_up16(cout)) {
+        float v = 0.f;
+        if (t < cout) {
+            const float sc = gamma ? gamma[t] / sqrtf(var[t] + eps) : 1.f;
+            const float b0 = b ? b[t] : 0.f;
+            v = gamma ? (b0 - mean[t]) * sc + beta[t] : b0;
+        }
+        bpack[t] = v;
+    }
+    if (t >= total) return;
+    const int j = (int)(t & 3);
+    const int lane = (int)((t >> 2) & 63);
+    long long r = t >> 8;
+    const int nt = (int)(r % nts); r /= nts;
+    const int cg = (int)(r % cgs); r /= cgs;
+    const int tap = (int)r;
+    const int co = nt * 16 + (lane & 15);
+    const int ci = cg * 16 + 4 * (lane >> 4) + j;
+    float v = 0.f;
+    if (co < cout && ci < cin) {
+        const float sc = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
+        const float wv = transposed ? w[((size_t)ci * cout + co) * taps + tap] : w[((size_t)co * cin + ci) * taps + tap];
+        v = wv * sc;
+    }
+    wpack[t] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// direct implicit-GEMM kernel
+// ------------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float* in;
+    const float* wpack;
+    const float* bpack;
+    const float* res;
+    float* out;
+    long long total_vox;  // B * dim^3 (input voxels)
+    int dim;
+    int cin_pad;
+    int cout;      // real output channels
+    int nts;       // cout tiles of 16 in the packed weights
+    int flags;
+};
+
+template <int KS, int M_T, int N_T, bool DECONV>
+__global__ __launch_bounds__(256) void conv3d_direct_kernel(ConvArgs a) {
+    constexpr int P = (KS - 1) / 2;
+    constexpr int TAPS = KS * KS * KS;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int vl = lane & 15;   // voxel within the 16-voxel tile / cout within the weight tile
+    const int h = lane >> 4;    // k group
+    const int dim = a.dim;
+    const int cgs = a.cin_pad >> 4;
+    const int nt0 = blockIdx.y * N_T;
+    const int sub = DECONV ? blockIdx.z : 0;  // (a,b,c) sub-position of the 2x2x2 transposed kernel
+
+    // voxel coordinates of this lane's column in each of the wave's M_T tiles
+    const long long v_base = ((long long)blockIdx.x * 4 + wave) * (M_T * 16);
+    int vb[M_T], vz[M_T], vy[M_T], vx[M_T];
+    bool vok[M_T];
+#pragma unroll
+    for (int m = 0; m < M_T; ++m) {
+        const long long vid = v_base + m * 16 + vl;
+        vok[m] = vid < a.total_vox;
+        long long t = vok[m] ? vid : 0;
+        vx[m] = (int)(t % dim); t /= dim;
+        vy[m] = (int)(t % dim); t /= dim;
+        vz[m] = (int)(t % dim); t /= dim;
+        vb[m] = (int)t;
+    }
+
+    f32x4 acc[M_T][N_T];
+#pragma unroll
+    for (int m = 0; m < M_T; ++m)
+#pragma unroll
+        for (int n = 0; n < N_T; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack);
+    for (int tap = 0; tap < (DECONV ? 1 : TAPS); ++tap) {
+        const int dz = tap / (KS * KS) - P;
+        const int dy = (tap / KS) % KS - P;
+        const int dx = tap % KS - P;
+        const float* src[M_T];
+        bool ok[M_T];
+#pragma unroll
+        for (int m = 0; m < M_T; ++m) {
+            const int zz = vz[m] + dz, yy = vy[m] + dy, xx = vx[m] + dx;
+            ok[m] = vok[m] && (unsigned)zz < (unsigned)dim && (unsigned)yy < (unsigned)dim && (unsigned)xx < (unsigned)dim;
+            const long long off = ((((long long)vb[m] * dim + zz) * dim + yy) * dim + xx) * a.cin_pad + 4 * h;
+            src[m] = a.in + (ok[m] ? off : 0);
+        }
+        const int wtap = DECONV ? sub : tap;
+        for (int cg = 0; cg < cgs; ++cg) {
+            f32x4 xf[M_T];
+#pragma unroll
+            for (int m = 0; m < M_T; ++m) {
+                xf[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ok[m]) xf[m] = *reinterpret_cast<const f32x4*>(src[m] + cg * 16);
+            }
+            const f32x4* wrow = wp + ((size_t)(wtap * cgs + cg) * a.nts + nt0) * 64 + lane;
+#pragma unroll
+            for (int n = 0; n < N_T; ++n) {
+                const f32x4 wf = wrow[n * 64];
+#pragma unroll
+                for (int m = 0; m < M_T; ++m) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, xf[m].x, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, xf[m].y, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, xf[m].z, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, xf[m].w, acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: lane owns couts co0..co0+3 of voxel (m, vl)
+    const bool relu = a.flags & SE_EPI_RELU;
+    const bool res_pre = (a.flags & SE_EPI_RES_PRE_RELU) && a.res;
+    const bool res_post = (a.flags & SE_EPI_RES_POST_RELU) && a.res;
+    const bool planar = a.flags & SE_EPI_OUT_PLANAR;
+    const int odim = DECONV ? dim * 2 : dim;
+    const long long ovox_per_b = (long long)odim * odim * odim;
+#pragma unroll
+    for (int m = 0; m < M_T; ++m) {
+        if (!vok[m]) continue;
+        int oz = vz[m], oy = vy[m], ox = vx[m];
+        if (DECONV) {
+            oz = 2 * oz + (sub >> 2);
+            oy = 2 * oy + ((sub >> 1) & 1);
+            ox = 2 * ox + (sub & 1);
+        }
+        const long long on = ((long long)oz * odim + oy) * odim + ox;  // voxel index inside the sample
+#pragma unroll
+        for (int n = 0; n < N_T; ++n) {
+            const int co0 = (nt0 + n) * 16 + 4 * h;
+            if (co0 >= a.cout) continue;
+            f32x4 v = acc[m][n] + *reinterpret_cast<const f32x4*>(a.bpack + co0);
+            if (planar) {
+                float* o = a.out + ((long long)vb[m] * a.cout + co0) * ovox_per_b + on;
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (co0 + r < a.cout) {
+                        float y = vv[r];
+                        if (relu) y = fmaxf(y, 0.f);
+                        o[(long long)r * ovox_per_b] = y;
+                    }
+                }
+            } else {
+                const long long ooff = ((long long)vb[m] * ovox_per_b + on) * a.cout + co0;
+                if (res_pre) v += *reinterpret_cast<const f32x4*>(a.res + ooff);
+                if (relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if (res_post) v += *reinterpret_cast<const f32x4*>(a.res + ooff);
+                *reinterpret_cast<f32x4*>(a.out + ooff) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// max-pool 2x2x2 stride 2, channels-last, 16 B per lane
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                       long long total /* B*od^3*cq */, int od, int cq) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int q = (int)(t % cq);
+    long long r = t / cq;
+    const int x = (int)(r % od); r /= od;
+    const int y = (int)(r % od); r /= od;
+    const int z = (int)(r % od); r /= od;
+    const long long b = r;
+    const int id = od * 2;
+    const int C = cq * 4;
+    const float* p = in + ((((b * id + 2 * z) * id + 2 * y) * id + 2 * x) * (long long)C) + q * 4;
+    f32x4 m = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const long long off = (((long long)(k >> 2) * id + ((k >> 1) & 1)) * id + (k & 1)) * C;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + off);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+    *reinterpret_cast<f32x4*>(out + t * 4) = m;
+}
+
+template <int KS>
+int launch_direct(const ConvArgs& a, hipStream_t s) {
+    // cout tiles per workgroup: 2 when the layer has an even number of 16-wide cout tiles
+    const long long vox_per_wg = 4 * 4 * 16;  // 4 waves x M_T=4 x 16
+    const unsigned gx = (unsigned)((a.total_vox + vox_per_wg - 1) / vox_per_wg);
+    if (a.nts % 2 == 0) {
+        hipLaunchKernelGGL((conv3d_direct_kernel<KS, 4, 2, false>), dim3(gx, a.nts / 2), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((conv3d_direct_kernel<KS, 4, 1, false>), dim3(gx, a.nts), dim3(256), 0, s, a);
+    }
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int se_abi_version(void) { return 1; }
+
+extern "C" long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, int transposed) {
+    const long long taps = transposed ? 8 : (long long)ksize * ksize * ksize;
+    return taps * (cin_pad / 16) * (round_up16(cout) / 16) * 256;
+}
+
+extern "C" int se_conv3d_pack_f32(const float* w, const float* b, const float* gamma, const float* beta,
+                                  const float* mean, const float* var, float eps, float* wpack, float* bpack,
+                                  int cout, int cin, int cin_pad, int ksize, int transposed, void* stream) {
+    if (cout <= 0 || cin <= 0 || cin_pad < cin || (cin_pad & 15)) return SE_ERR_BAD_ARG;
+    if (transposed ? (ksize != 2) : (ksize != 1 && ksize != 3 && ksize != 7)) return SE_ERR_BAD_ARG;
+    if ((gamma != nullptr) != (beta != nullptr) || (gamma != nullptr) != (mean != nullptr) ||
+        (gamma != nullptr) != (var != nullptr))
+        return SE_ERR_BAD_ARG;
+    const int taps = ksize * ksize * ksize;
+    const long long total = se_conv3d_packed_elems(cout, cin_pad, ksize, transposed);
+    const long long threads = total > round_up16(cout) ? total : round_up16(cout);
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, se_stream(stream), w, b,
+                       gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_pad, taps, transposed, total);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+// implemented in conv3d_tiled.hip; returns 1 if it took the launch, 0 if the shape is not covered, <0 / hipError on failure
+int se_conv3d_tiled_try(const float* in, const float* wpack, const float* bpack, const float* residual, float* out,
+                        int batch, int dim, int cin_pad, int cout, int ksize, int flags, hipStream_t s);
+
+extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
+                             float* out, int batch, int dim, int cin_pad, int cout, int ksize, int flags,
+                             void* stream) {
+    if (batch <= 0 || dim <= 0 || cin_pad <= 0 || (cin_pad & 15) || cout <= 0) return SE_ERR_BAD_ARG;
+    if (ksize != 1 && ksize != 3 && ksize != 7) return SE_ERR_BAD_ARG;
+    const bool planar = flags & SE_EPI_OUT_PLANAR;
+    if (!planar && (cout & 15)) return SE_ERR_BAD_ARG;
+    if (planar && (flags & (SE_EPI_RES_PRE_RELU | SE_EPI_RES_POST_RELU))) return SE_ERR_BAD_ARG;
+    if ((flags & SE_EPI_RES_PRE_RELU) && (flags & SE_EPI_RES_POST_RELU)) return SE_ERR_BAD_ARG;
+    hipStream_t s = se_stream(stream);
+    const int took = se_conv3d_tiled_try(in, wpack, bpack, residual, out, batch, dim, cin_pad, cout, ksize, flags, s);
+    if (took != 0) return took > 0 ? 0 : took;
+    ConvArgs a;
+    a.in = in; a.wpack = wpack; a.bpack = bpack; a.res = residual; a.out = out;
+    a.total_vox = (long long)batch * dim * dim * dim;
+    a.dim = dim; a.cin_pad = cin_pad; a.cout = cout; a.nts = round_up16(cout) / 16; a.flags = flags;
+    switch (ksize) {
+        case 1: return launch_direct<1>(a, s);
+        case 3: return launch_direct<3>(a, s);
+        default: return launch_direct<7>(a, s);
+    }
+}
+
+extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
+                                    float* out, int batch, int dim, int cin, int cout, int flags, void* stream) {
+    if (batch <= 0 || dim <= 0 || cin <= 0 || (cin & 15) || cout <= 0 || (cout & 15)) return SE_ERR_BAD_ARG;
+    if (flags & SE_EPI_OUT_PLANAR) return SE_ERR_BAD_ARG;
+    if ((flags & SE_EPI_RES_PRE_RELU) && (flags & SE_EPI_RES_POST_RELU)) return SE_ERR_BAD_ARG;
+    ConvArgs a;
+    a.in = in; a.wpack = wpack; a.bpack = bpack; a.res = residual; a.out = out;
+    a.total_vox = (long long)batch * dim * dim * dim;
+    a.dim = dim; a.cin_pad = cin; a.cout = cout; a.nts = cout / 16; a.flags = flags;
+    const long long vox_per_wg = 4 * 4 * 16;
+    const unsigned gx = (unsigned)((a.total_vox + vox_per_wg - 1) / vox_per_wg);
+    if (a.nts % 2 == 0) {
+        hipLaunchKernelGGL((conv3d_direct_kernel<1, 4, 2, true>), dim3(gx, a.nts / 2, 8), dim3(256), 0, se_stream(stream), a);
+    } else {
+        hipLaunchKernelGGL((conv3d_direct_kernel<1, 4, 1, true>), dim3(gx, a.nts, 8), dim3(256), 0, se_stream(stream), a);
+    }
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int se_maxpool3d_2_f32(const float* in, float* out, int batch, int dim, int channels, void* stream) {
+    if (batch <= 0 || dim <= 0 || (dim & 1) || channels <= 0 || (channels & 3)) return SE_ERR_BAD_ARG;
+    const int od = dim / 2, cq = channels / 4;
+    const long long total = (long long)batch * od * od * od * cq;
+    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, se_stream(stream), in, out,
+                       total, od, cq);
+    SE_CHECK_LAUNCH();
+    return 0;
+}

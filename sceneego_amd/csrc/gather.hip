@@ -1,0 +1,78 @@
+// Table-driven bilinear voxel gather (HBM-bound on the 128 B/voxel output stream).
+//
+// The reference materialises a [B,32,1024,1280] tensor (nearest upsample + zero pad) only to point-sample
+// it at the G^3 projected voxel centres with grid_sample (voxel_net_depth.py:60-61,238,243; op.py:209).
+// Here the 4 bilinear taps of every voxel are resolved at init time to texel indices of the compact
+// 64x64 map (sceneego_amd/op.py:build_gather_table), so the per-frame work is 4 x 128 B reads (L2
+// resident: the whole map is 512 KB) and one 128 B write per voxel.
+#include "common.h"
+
+namespace {
+
+// thread = (voxel, channel quad); channel quads of one voxel are adjacent lanes => 128 B contiguous
+// stores for C = 32, and the 4 tap rows are read as 16 B per lane, 128 B per voxel.
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ feat, const int4* __restrict__ idx,
+                                                     const f32x4* __restrict__ w, float* __restrict__ out,
+                                                     int texels, int cq /* channels/4 */, int voxels,
+                                                     int out_stride_c, int out_c_offset) {
+    const int b = blockIdx.y;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int v = (int)(t / cq);
+    const int q = (int)(t - (long long)v * cq);
+    if (v >= voxels) return;
+    const int4 id = idx[v];
+    const f32x4 wt = w[v];
+    const float* fb = feat + (size_t)b * texels * (cq * 4) + q * 4;
+    const int C = cq * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // accumulation order nw, ne, sw, se as ATen's grid_sampler_2d (zeros padding => skipped taps add 0)
+    if (id.x >= 0) acc += *reinterpret_cast<const f32x4*>(fb + (size_t)id.x * C) * wt.x;
+    if (id.y >= 0) acc += *reinterpret_cast<const f32x4*>(fb + (size_t)id.y * C) * wt.y;
+    if (id.z >= 0) acc += *reinterpret_cast<const f32x4*>(fb + (size_t)id.z * C) * wt.z;
+    if (id.w >= 0) acc += *reinterpret_cast<const f32x4*>(fb + (size_t)id.w * C) * wt.w;
+    float* o = out + ((size_t)b * voxels + v) * out_stride_c + out_c_offset + q * 4;
+    *reinterpret_cast<f32x4*>(o) = acc;
+}
+
+__global__ __launch_bounds__(256) void intersection_kernel(float* __restrict__ buf, const float* __restrict__ occ,
+                                                           long long total_vox, int cq, int stride_c) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long v = t / cq;
+    const int q = (int)(t - v * cq);
+    if (v >= total_vox) return;
+    const float o = occ[v];
+    float* p = buf + v * stride_c + q * 4;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(p);
+    *reinterpret_cast<f32x4*>(p + cq * 4) = x * o;
+}
+
+}  // namespace
+
+extern "C" int se_unproject_gather_f32(const float* feat, const int* idx, const float* w, float* out, int batch,
+                                       int texels, int channels, int voxels, int out_stride_c, int out_c_offset,
+                                       void* stream) {
+    if (batch <= 0 || texels <= 0 || voxels <= 0 || channels <= 0) return SE_ERR_BAD_ARG;
+    if ((channels & 3) || (out_stride_c & 3) || (out_c_offset & 3) || out_c_offset + channels > out_stride_c)
+        return SE_ERR_BAD_ARG;
+    const int cq = channels / 4;
+    const long long threads = (long long)voxels * cq;
+    dim3 grid((unsigned)((threads + 255) / 256), batch);
+    hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, se_stream(stream), feat,
+                       reinterpret_cast<const int4*>(idx), reinterpret_cast<const f32x4*>(w), out, texels, cq,
+                       voxels, out_stride_c, out_c_offset);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int se_intersection_f32(float* buf, const float* occ, int batch, int voxels, int channels, int stride_c,
+                                   void* stream) {
+    if (batch <= 0 || voxels <= 0 || channels <= 0 || (channels & 3) || (stride_c & 3) || 2 * channels > stride_c)
+        return SE_ERR_BAD_ARG;
+    const int cq = channels / 4;
+    const long long total_vox = (long long)batch * voxels;
+    const long long threads = total_vox * cq;
+    hipLaunchKernelGGL(intersection_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, se_stream(stream),
+                       buf, occ, total_vox, cq, stride_c);
+    SE_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,138 @@
+// 3D soft-argmax (utils/op.py:83-96): softmax over all G^3 voxels of every (sample, joint) row, then the
+// expectation of the voxel-centre coordinates.  HBM-bound: 4 B/voxel/row read (twice, second pass is
+// L2/MALL resident at 64^3) + 4 B written (the softmaxed volumes are part of forward()'s return value).
+//
+// Two launches, split-row so that B*15 rows x SE_SA_SPLITS chunks fill the 256 CUs:
+//   pass 1: per chunk  m = max v, l = sum exp(v-m), s = sum exp(v-m) * coord      -> scratch
+//   pass 2: every chunk re-derives the row's (M, L) from the SE_SA_SPLITS partials in a fixed order
+//           (bitwise deterministic), writes exp(v-M)/L; chunk 0 also writes the joint.
+#include "common.h"
+
+#define SE_SA_SPLITS 32
+#define SE_SA_PART 8  // floats per partial record: m, l, sx, sy, sz, pad
+
+namespace {
+
+__device__ __forceinline__ float block_reduce_max(float v, float* sm) {
+    v = wave_reduce_max(v);
+    const int wid = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[wid] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float* sm) {
+    v = wave_reduce_sum(v);
+    const int wid = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[wid] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// grid (SE_SA_SPLITS, rows), block 256
+__global__ __launch_bounds__(256) void softargmax_partial_kernel(const float* __restrict__ vol,
+                                                                 const float* __restrict__ coord,
+                                                                 float* __restrict__ scratch, int voxels,
+                                                                 int mode) {
+    __shared__ float sm[4];
+    const int row = blockIdx.y, s = blockIdx.x;
+    const int chunk = (((voxels + SE_SA_SPLITS - 1) / SE_SA_SPLITS) + 3) & ~3;
+    const int c0 = s * chunk;
+    const int c1 = min(c0 + chunk, voxels);
+    const float* v = vol + (size_t)row * voxels;
+
+    float m = -INFINITY;
+    if (mode == 1) {
+        for (int i = c0 + threadIdx.x * 4; i < c1; i += 1024) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(v + i);
+            m = fmaxf(m, fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w)));
+        }
+        m = block_reduce_max(m, sm);
+    }
+    float l = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int i = c0 + threadIdx.x * 4; i < c1; i += 1024) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(v + i);
+        const f32x4 c_a = *reinterpret_cast<const f32x4*>(coord + (size_t)i * 3);
+        const f32x4 c_b = *reinterpret_cast<const f32x4*>(coord + (size_t)i * 3 + 4);
+        const f32x4 c_c = *reinterpret_cast<const f32x4*>(coord + (size_t)i * 3 + 8);
+        float e0, e1, e2, e3;
+        if (mode == 1) {
+            e0 = expf(x.x - m); e1 = expf(x.y - m); e2 = expf(x.z - m); e3 = expf(x.w - m);
+        } else {
+            e0 = fmaxf(x.x, 0.f); e1 = fmaxf(x.y, 0.f); e2 = fmaxf(x.z, 0.f); e3 = fmaxf(x.w, 0.f);
+        }
+        l += (e0 + e1) + (e2 + e3);
+        sx += e0 * c_a.x + e1 * c_a.w + e2 * c_b.z + e3 * c_c.y;
+        sy += e0 * c_a.y + e1 * c_b.x + e2 * c_b.w + e3 * c_c.z;
+        sz += e0 * c_a.z + e1 * c_b.y + e2 * c_c.x + e3 * c_c.w;
+    }
+    l = block_reduce_sum(l, sm);
+    sx = block_reduce_sum(sx, sm);
+    sy = block_reduce_sum(sy, sm);
+    sz = block_reduce_sum(sz, sm);
+    if (threadIdx.x == 0) {
+        float* p = scratch + ((size_t)row * SE_SA_SPLITS + s) * SE_SA_PART;
+        p[0] = m; p[1] = l; p[2] = sx; p[3] = sy; p[4] = sz;
+    }
+}
+
+// grid (SE_SA_SPLITS, rows), block 256
+__global__ __launch_bounds__(256) void softargmax_finish_kernel(const float* __restrict__ vol,
+                                                                const float* __restrict__ scratch,
+                                                                float* __restrict__ out_vol,
+                                                                float* __restrict__ joints, int voxels, int mode) {
+    const int row = blockIdx.y, s = blockIdx.x;
+    const float* part = scratch + (size_t)row * SE_SA_SPLITS * SE_SA_PART;
+    // every thread folds the partials in the same fixed order -> identical (M, L) everywhere
+    float M = -INFINITY;
+    if (mode == 1)
+        for (int k = 0; k < SE_SA_SPLITS; ++k)
+            if (part[k * SE_SA_PART + 1] > 0.f) M = fmaxf(M, part[k * SE_SA_PART + 0]);
+    float L = 0.f, SX = 0.f, SY = 0.f, SZ = 0.f;
+    for (int k = 0; k < SE_SA_SPLITS; ++k) {
+        const float* p = part + k * SE_SA_PART;
+        const float f = (mode == 1) ? ((p[1] > 0.f) ? expf(p[0] - M) : 0.f) : 1.f;
+        L += p[1] * f; SX += p[2] * f; SY += p[3] * f; SZ += p[4] * f;
+    }
+    const float invL = (mode == 1) ? 1.f / L : 1.f;
+    if (s == 0 && threadIdx.x == 0) {
+        joints[row * 3 + 0] = SX * invL;
+        joints[row * 3 + 1] = SY * invL;
+        joints[row * 3 + 2] = SZ * invL;
+    }
+    const int chunk = (((voxels + SE_SA_SPLITS - 1) / SE_SA_SPLITS) + 3) & ~3;
+    const int c0 = s * chunk;
+    const int c1 = min(c0 + chunk, voxels);
+    const float* v = vol + (size_t)row * voxels;
+    float* o = out_vol + (size_t)row * voxels;
+    for (int i = c0 + threadIdx.x * 4; i < c1; i += 1024) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(v + i);
+        f32x4 r;
+        if (mode == 1) {
+            r.x = expf(x.x - M) * invL; r.y = expf(x.y - M) * invL;
+            r.z = expf(x.z - M) * invL; r.w = expf(x.w - M) * invL;
+        } else {
+            r.x = fmaxf(x.x, 0.f); r.y = fmaxf(x.y, 0.f); r.z = fmaxf(x.z, 0.f); r.w = fmaxf(x.w, 0.f);
+        }
+        *reinterpret_cast<f32x4*>(o + i) = r;
+    }
+}
+
+}  // namespace
+
+extern "C" long long se_softargmax3d_scratch_elems(int rows) {
+    return (long long)rows * SE_SA_SPLITS * SE_SA_PART;
+}
+
+extern "C" int se_softargmax3d_f32(const float* vol, const float* coord, float* out_vol, float* joints,
+                                   float* scratch, int rows, int voxels, int mode, void* stream) {
+    if (rows <= 0 || voxels <= 0 || (voxels & 3) || (mode != 0 && mode != 1)) return SE_ERR_BAD_ARG;
+    hipStream_t s = se_stream(stream);
+    dim3 grid(SE_SA_SPLITS, rows);
+    hipLaunchKernelGGL(softargmax_partial_kernel, grid, dim3(256), 0, s, vol, coord, scratch, voxels, mode);
+    SE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(softargmax_finish_kernel, grid, dim3(256), 0, s, vol, scratch, out_vol, joints, voxels, mode);
+    SE_CHECK_LAUNCH();
+    return 0;
+}

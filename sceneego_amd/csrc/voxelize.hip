@@ -1,0 +1,89 @@
+// Depth map -> occupancy grid (scatter).  HBM-bound: 4 B depth + 24 B ray per pixel in, 4 B scattered out.
+//
+// Follows the reference arithmetic operation by operation so the set of occupied voxels is
+// bit-identical (network/voxel_net_depth.py:194-222):
+//   depth -> cv2.resize(1024x1024, INTER_NEAREST) -> zero pad 128 cols -> transpose/flatten (x-major)
+//   point = ray(float64) * depth ; q = round_half_even(((p + side/2) * G) / side) ; 0 <= q <= G-1 ; occ[q] = 1
+// All float64, and NO fused multiply-add: numpy rounds the product and the sum separately.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ void se_splat(double px, double py, double pz, float* __restrict__ occ_b,
+                                          int G, double half_side, double dG, double side) {
+    // (p + side/2) * G / side, evaluated left to right like numpy (voxel_net_depth.py:209-213)
+    double qx = ((px + half_side) * dG) / side;
+    double qy = ((py + half_side) * dG) / side;
+    double qz = (pz * dG) / side;
+    qx = rint(qx);  // np.round_: half to even (:215)
+    qy = rint(qy);
+    qz = rint(qz);
+    const double hi = (double)(G - 1);
+    if (qx >= 0.0 && qx <= hi && qy >= 0.0 && qy <= hi && qz >= 0.0 && qz <= hi) {  // :216-218
+        const int ix = (int)qx, iy = (int)qy, iz = (int)qz;
+        occ_b[((size_t)ix * G + iy) * G + iz] = 1.0f;  // benign race: every writer stores 1.0f
+    }
+}
+
+// grid: (ceil(up*up/256), B).  Thread = one pixel (y, x') of the resized depth; x' fastest => the
+// ray table (24 B/pixel) and the depth row are read coalesced.
+__global__ __launch_bounds__(256) void voxelize_kernel(const float* __restrict__ depth,
+                                                       const double* __restrict__ ray_tab,
+                                                       float* __restrict__ occ, int depth_h, int depth_w,
+                                                       int up_h, int up_w, int has_pad, int G, double side) {
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    float* occ_b = occ + (size_t)b * G * G * G;
+    const double half_side = side / 2.0;
+    const double dG = (double)G;
+    if (has_pad && pix == 0) {
+        // the zero-padded columns (:198): depth 0 -> point (0,0,0)
+        se_splat(0.0, 0.0, 0.0, occ_b, G, half_side, dG, side);
+    }
+    if (pix >= up_h * up_w) return;
+    const int y = pix / up_w;
+    const int xp = pix - y * up_w;
+    // cv2 INTER_NEAREST: src = min(floor(dst * (src_size / dst_size)), src_size - 1), scale in double
+    int sy = (int)floor((double)y * ((double)depth_h / (double)up_h));
+    int sx = (int)floor((double)xp * ((double)depth_w / (double)up_w));
+    sy = min(sy, depth_h - 1);
+    sx = min(sx, depth_w - 1);
+    const double d = (double)depth[((size_t)b * depth_h + sy) * depth_w + sx];
+    const double* r = ray_tab + (size_t)pix * 3;
+    se_splat(r[0] * d, r[1] * d, r[2] * d, occ_b, G, half_side, dG, side);
+}
+
+}  // namespace
+
+extern "C" int se_voxelize_f64(const float* depth, const double* ray_tab, float* occ, int batch, int depth_h,
+                               int depth_w, int up, int pad_x, int volume_size, double cuboid_side,
+                               void* stream) {
+    if (batch <= 0 || depth_h <= 0 || depth_w <= 0 || up <= 0 || volume_size <= 0 || pad_x < 0) return SE_ERR_BAD_ARG;
+    hipStream_t s = se_stream(stream);
+    const size_t occ_bytes = (size_t)batch * volume_size * volume_size * volume_size * sizeof(float);
+    hipError_t e = hipMemsetAsync(occ, 0, occ_bytes, s);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((up * up + 255) / 256, batch);
+    hipLaunchKernelGGL(voxelize_kernel, grid, dim3(256), 0, s, depth, ray_tab, occ, depth_h, depth_w, up, up,
+                       pad_x > 0 ? 1 : 0, volume_size, cuboid_side);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int se_voxelize_full_f64(const float* depth, const double* ray_tab, float* occ, int batch,
+                                    int depth_h, int depth_w, int volume_size, double cuboid_side,
+                                    void* stream) {
+    if (batch <= 0 || depth_h <= 0 || depth_w <= 0 || volume_size <= 0) return SE_ERR_BAD_ARG;
+    hipStream_t s = se_stream(stream);
+    const size_t occ_bytes = (size_t)batch * volume_size * volume_size * volume_size * sizeof(float);
+    hipError_t e = hipMemsetAsync(occ, 0, occ_bytes, s);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((depth_h * depth_w + 255) / 256, batch);
+    // no resize (up == depth size => sy = y, sx = x) and no padding
+    hipLaunchKernelGGL(voxelize_kernel, grid, dim3(256), 0, s, depth, ray_tab, occ, depth_h, depth_w, depth_h,
+                       depth_w, 0, volume_size, cuboid_side);
+    SE_CHECK_LAUNCH();
+    return 0;
+}

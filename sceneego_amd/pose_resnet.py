@@ -1,0 +1,180 @@
+"""2D backbone: ResNet-50 trunk + three stride-2 transposed-conv stages ("simple baseline" pose net).
+
+Stands in for the reference's ``network/pose_resnet.py`` (``PoseResNet`` ``:135-246``, ``Bottleneck``
+``:52-90``, ``get_pose_net`` ``:313-332``).  The parameter tree reproduces the reference's state-dict
+key names and shapes exactly so the published checkpoint loads with ``strict=True``;
+the code that builds and runs it is this build's own:
+
+  * the trunk is described by a stage table and built in a loop;
+  * ``forward`` returns ``(heatmaps, features)`` like the reference (``:225-246``), but the dead
+    ``final_layer`` (1x1, 256->16) is only evaluated when ``compute_heatmaps=True`` — the voxel path
+    discards the heatmaps (``network/voxel_net_depth.py:235``);
+  * ``FoldedBackbone`` is the inference executor used on the GPU: every BatchNorm is folded into the
+    preceding convolution once, tensors run channels-last so MIOpen picks its NHWC MFMA kernels, and
+    the residual add + ReLU are the only element-wise launches left.  The dense 2D convolutions are
+    the one place the north-star assigns to MIOpen rather than to hand-written HIP.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+BN_MOMENTUM = 0.1
+
+# (planes, blocks, stride of the first block) — ResNet-50
+_STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
+_EXPANSION = 4
+_DECONV_PLANES = (256, 256, 256)
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c, momentum=BN_MOMENTUM)
+
+
+class Bottleneck(nn.Module):
+    """1x1 -> 3x3 (carries the stride) -> 1x1 (x4), each followed by BN; ReLU(out + shortcut)."""
+
+    expansion = _EXPANSION
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = _bn(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = _bn(planes)
+        self.conv3 = nn.Conv2d(planes, planes * _EXPANSION, 1, bias=False)
+        self.bn3 = _bn(planes * _EXPANSION)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        sc = x if self.downsample is None else self.downsample(x)
+        return self.relu(y + sc)
+
+
+class PoseResNet(nn.Module):
+    def __init__(self, num_heatmaps: int = 16, joints_out: int = 15):
+        super().__init__()
+        self.joints_out = joints_out
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = _bn(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        inplanes = 64
+        for si, (planes, blocks, stride) in enumerate(_STAGES, start=1):
+            mods = []
+            for bi in range(blocks):
+                s = stride if bi == 0 else 1
+                ds = None
+                if bi == 0 and (s != 1 or inplanes != planes * _EXPANSION):
+                    ds = nn.Sequential(nn.Conv2d(inplanes, planes * _EXPANSION, 1, stride=s, bias=False),
+                                       _bn(planes * _EXPANSION))
+                mods.append(Bottleneck(inplanes, planes, s, ds))
+                inplanes = planes * _EXPANSION
+            setattr(self, f"layer{si}", nn.Sequential(*mods))
+        up = []
+        for planes in _DECONV_PLANES:  # k4 s2 p1, no bias (reference :198-223)
+            up += [nn.ConvTranspose2d(inplanes, planes, 4, stride=2, padding=1, output_padding=0, bias=False),
+                   _bn(planes), nn.ReLU(inplace=True)]
+            inplanes = planes
+        self.deconv_layers = nn.Sequential(*up)
+        self.final_layer = nn.Conv2d(inplanes, num_heatmaps, 1)
+
+    def trunk(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return x
+
+    def forward(self, x, return_mid_layer=False, compute_heatmaps=True):
+        mid = self.trunk(x)
+        features = self.deconv_layers(mid)
+        heatmaps = self.final_layer(features)[:, :self.joints_out] if compute_heatmaps else None
+        if return_mid_layer:
+            return heatmaps, features, mid
+        return heatmaps, features
+
+
+def strip_module_prefix(state_dict):
+    """Checkpoints saved from DataParallel carry a ``module.`` prefix (reference ``:282-289,326-330``)."""
+    keys = list(state_dict.keys())
+    if keys and keys[0].startswith("module"):
+        return OrderedDict((k[7:], v) for k, v in state_dict.items())
+    return state_dict
+
+
+def load_state_dict(model, new_state_dict):
+    """Merge-then-load, as the reference's helper (``:306-310``): missing keys keep their init values."""
+    state = model.state_dict()
+    state.update(new_state_dict)
+    model.load_state_dict(state)
+    return model
+
+
+def get_pose_net(model_path=None, state_dict=None):
+    """Reference ``get_pose_net`` (``:313-332``).  ``get_pose_net(None)`` loads nothing."""
+    model = PoseResNet()
+    if state_dict is None:
+        if model_path is not None:
+            model = load_state_dict(model, torch.load(model_path, map_location="cpu"))
+    else:
+        model = load_state_dict(model, strip_module_prefix(state_dict))
+    return model
+
+
+# ------------------------------------------------------------------------------------------------
+# inference executor: BN folded, channels-last, MIOpen convolutions
+# ------------------------------------------------------------------------------------------------
+def _fold(conv_w, bn, transposed=False):
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    shift = bn.bias - bn.running_mean * scale
+    if transposed:   # ConvTranspose2d weight is [Cin, Cout, kh, kw]
+        w = conv_w * scale.view(1, -1, 1, 1)
+    else:
+        w = conv_w * scale.view(-1, 1, 1, 1)
+    return w.detach().contiguous(memory_format=torch.channels_last), shift.detach().contiguous()
+
+
+class FoldedBackbone:
+    """Folded copy of a ``PoseResNet`` in eval mode; ``__call__(images) -> features [B,256,64,64]`` (NHWC strides).
+
+    ``dtype`` torch.float32 (parity path) or torch.bfloat16 (BASELINE config 3).
+    """
+
+    def __init__(self, net: PoseResNet, dtype=torch.float32):
+        self.dtype = dtype
+        cvt = lambda wb: (wb[0].to(dtype).contiguous(memory_format=torch.channels_last), wb[1].to(dtype))
+        self.stem = cvt(_fold(net.conv1.weight, net.bn1))
+        self.blocks = []
+        for si in range(1, 5):
+            for blk in getattr(net, f"layer{si}"):
+                ds = None
+                if blk.downsample is not None:
+                    ds = cvt(_fold(blk.downsample[0].weight, blk.downsample[1])) + (blk.downsample[0].stride,)
+                self.blocks.append((cvt(_fold(blk.conv1.weight, blk.bn1)), cvt(_fold(blk.conv2.weight, blk.bn2)),
+                                    cvt(_fold(blk.conv3.weight, blk.bn3)), blk.conv2.stride, ds))
+        self.ups = []
+        mods = list(net.deconv_layers)
+        for i in range(0, len(mods), 3):
+            self.ups.append(cvt(_fold(mods[i].weight, mods[i + 1], transposed=True)))
+
+    @torch.no_grad()
+    def __call__(self, images):
+        x = images.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        x = F.relu_(F.conv2d(x, self.stem[0], self.stem[1], stride=2, padding=3))
+        x = F.max_pool2d(x, 3, stride=2, padding=1)
+        for c1, c2, c3, stride, ds in self.blocks:
+            y = F.relu_(F.conv2d(x, c1[0], c1[1]))
+            y = F.relu_(F.conv2d(y, c2[0], c2[1], stride=stride, padding=1))
+            y = F.conv2d(y, c3[0], c3[1])
+            sc = x if ds is None else F.conv2d(x, ds[0], ds[1], stride=ds[2])
+            x = F.relu_(y.add_(sc))
+        for w, b in self.ups:
+            x = F.relu_(F.conv_transpose2d(x, w, b, stride=2, padding=1))
+        return x

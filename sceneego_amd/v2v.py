@@ -1,0 +1,261 @@
+"""V2V-PoseNet 3D encoder-decoder on hand-written HIP kernels.
+
+Stands in for the reference's ``network/v2v.py`` (``V2VModel`` ``:142-181``, ``EncoderDecorder`` ``:70-139``,
+``Res3DBlock`` ``:21-43``, ``Basic3DBlock`` ``:8-18``, ``Pool3DBlock`` ``:46-52``, ``Upsample3DBlock`` ``:55-67``).
+
+Two layers:
+
+* The ``nn.Module`` tree below is a *parameter container*: same sub-module names, parameter shapes and
+  initialisation as the reference, so ``state_dict()`` has the reference's keys and the
+  published checkpoint loads strictly.  The modules own no arithmetic.
+* ``V2VProgram`` is what runs: built once from the tree (``V2VModel.compile``), it folds every eval-mode
+  BatchNorm3d into its convolution, re-orders the weights into MFMA fragment order on the device
+  (``se_conv3d_pack_f32``) and replays a fixed launch list over channels-last ``[B,Z,Y,X,C]`` buffers:
+  one kernel per Conv3d+BN(+ReLU)(+residual) / ConvTranspose3d+BN+ReLU(+skip) / max-pool.  There is no
+  ATen fallback: without ``libsceneego_hip.so`` or off a HIP device it raises.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _round16(c):
+    return (c + 15) // 16 * 16
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers (reference key names)
+# ------------------------------------------------------------------------------------------------
+class Basic3DBlock(nn.Module):
+    def __init__(self, in_planes, out_planes, kernel_size):
+        super().__init__()
+        self.block = nn.Sequential(
+            nn.Conv3d(in_planes, out_planes, kernel_size=kernel_size, stride=1, padding=(kernel_size - 1) // 2),
+            nn.BatchNorm3d(out_planes), nn.ReLU(True))
+
+
+class Res3DBlock(nn.Module):
+    def __init__(self, in_planes, out_planes):
+        super().__init__()
+        self.res_branch = nn.Sequential(
+            nn.Conv3d(in_planes, out_planes, kernel_size=3, stride=1, padding=1), nn.BatchNorm3d(out_planes),
+            nn.ReLU(True),
+            nn.Conv3d(out_planes, out_planes, kernel_size=3, stride=1, padding=1), nn.BatchNorm3d(out_planes))
+        if in_planes == out_planes:
+            self.skip_con = nn.Sequential()
+        else:
+            self.skip_con = nn.Sequential(nn.Conv3d(in_planes, out_planes, kernel_size=1, stride=1, padding=0),
+                                          nn.BatchNorm3d(out_planes))
+
+
+class Pool3DBlock(nn.Module):
+    def __init__(self, pool_size):
+        super().__init__()
+        assert pool_size == 2
+        self.pool_size = pool_size
+
+
+class Upsample3DBlock(nn.Module):
+    def __init__(self, in_planes, out_planes, kernel_size, stride):
+        super().__init__()
+        assert kernel_size == 2 and stride == 2
+        self.block = nn.Sequential(
+            nn.ConvTranspose3d(in_planes, out_planes, kernel_size=2, stride=2, padding=0, output_padding=0),
+            nn.BatchNorm3d(out_planes), nn.ReLU(True))
+
+
+# (name, in, out) of the encoder/decoder pyramid: level k works at G / 2^k
+_ENC = ((32, 64), (64, 128), (128, 128), (128, 128), (128, 128))
+_SKIP = (32, 64, 128, 128, 128)
+_DEC_UP = ((64, 32), (128, 64), (128, 128), (128, 128), (128, 128))  # decoder_upsample1..5 (in, out)
+_DEC_RES = (64, 128, 128, 128, 128)                                  # decoder_res1..5
+
+
+class EncoderDecorder(nn.Module):  # (sic) the reference's spelling is part of the checkpoint key names
+    def __init__(self):
+        super().__init__()
+        for k in range(5):
+            setattr(self, f"encoder_pool{k + 1}", Pool3DBlock(2))
+            setattr(self, f"encoder_res{k + 1}", Res3DBlock(*_ENC[k]))
+            setattr(self, f"skip_res{k + 1}", Res3DBlock(_SKIP[k], _SKIP[k]))
+            setattr(self, f"decoder_res{k + 1}", Res3DBlock(_DEC_RES[k], _DEC_RES[k]))
+            setattr(self, f"decoder_upsample{k + 1}", Upsample3DBlock(_DEC_UP[k][0], _DEC_UP[k][1], 2, 2))
+        self.mid_res = Res3DBlock(128, 128)
+
+
+class V2VModel(nn.Module):
+    def __init__(self, input_channels, output_channels):
+        super().__init__()
+        self.input_channels = input_channels
+        self.output_channels = output_channels
+        self.front_layers = nn.Sequential(Basic3DBlock(input_channels, 16, 7), Res3DBlock(16, 32),
+                                          Res3DBlock(32, 32), Res3DBlock(32, 32))
+        self.encoder_decoder = EncoderDecorder()
+        self.back_layers = nn.Sequential(Res3DBlock(32, 32), Basic3DBlock(32, 32, 1), Basic3DBlock(32, 32, 1))
+        self.output_layer = nn.Conv3d(32, output_channels, kernel_size=1, stride=1, padding=0)
+        self._program = None
+        self._initialize_weights()
+
+    def _initialize_weights(self):
+        # reference v2v.py:172-181
+        for m in self.modules():
+            if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)):
+                nn.init.xavier_normal_(m.weight)
+                nn.init.constant_(m.bias, 0)
+
+    # -- execution ---------------------------------------------------------------------------
+    def compile(self) -> "V2VProgram":
+        """(Re)build the HIP launch program from the current parameters (call after loading weights)."""
+        self._program = V2VProgram(self)
+        return self._program
+
+    @property
+    def program(self) -> "V2VProgram":
+        if self._program is None:
+            self.compile()
+        return self._program
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._program = None
+
+    def _apply(self, fn, *a, **k):
+        self._program = None  # .to(device) / .float() invalidate packed weights
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, x):
+        """Reference signature: ``[B,Cin,G,G,G] -> [B,Cout,G,G,G]`` logits (NCDHW in and out)."""
+        _lib.require_hip(x)
+        B, C, G = x.shape[0], x.shape[1], x.shape[2]
+        prog = self.program
+        buf = torch.zeros((B, G, G, G, prog.cin_pad), device=x.device, dtype=torch.float32)
+        buf[..., :C] = x.permute(0, 2, 3, 4, 1)
+        logits = prog.run(buf, B, G)
+        return logits.view(B, self.output_channels, G, G, G)
+
+
+# ------------------------------------------------------------------------------------------------
+# the launch program
+# ------------------------------------------------------------------------------------------------
+class _PackedConv:
+    __slots__ = ("w", "b", "cin_pad", "cout", "k", "transposed")
+
+    def __init__(self, conv, bn, cin_pad=None):
+        transposed = isinstance(conv, nn.ConvTranspose3d)
+        w = conv.weight.detach().float().contiguous()
+        dev = w.device
+        if transposed:
+            cin, cout = w.shape[0], w.shape[1]
+            k = 2
+        else:
+            cout, cin = w.shape[0], w.shape[1]
+            k = w.shape[2]
+        self.cin_pad = cin_pad if cin_pad is not None else _round16(cin)
+        self.cout, self.k, self.transposed = cout, k, transposed
+        n = _lib.conv3d_packed_elems(cout, self.cin_pad, k, transposed)
+        self.w = torch.empty(n, device=dev, dtype=torch.float32)
+        self.b = torch.empty(_round16(cout), device=dev, dtype=torch.float32)
+        f = lambda t: None if t is None else t.detach().float().contiguous()
+        if bn is not None:
+            assert not bn.training, "V2VProgram folds BatchNorm3d running statistics: call .eval() first"
+            g, be, mu, var, eps = f(bn.weight), f(bn.bias), f(bn.running_mean), f(bn.running_var), bn.eps
+        else:
+            g = be = mu = var = None
+            eps = 0.0
+        _lib.conv3d_pack(w, f(conv.bias), g, be, mu, var, eps, self.w, self.b, cout, cin, self.cin_pad, k, transposed)
+
+
+class V2VProgram:
+    def __init__(self, model: V2VModel):
+        p = next(model.parameters())
+        if not p.is_cuda:
+            raise _lib.HipExtensionError("V2VModel must live on a HIP device to be compiled (got %s)" % p.device)
+        _lib.load()
+        self.device = p.device
+        self.cout = model.output_channels
+        self.cin = model.input_channels
+        self.cin_pad = _round16(self.cin)
+        fl, ed, bl = model.front_layers, model.encoder_decoder, model.back_layers
+        basic = lambda m, cin_pad=None: _PackedConv(m.block[0], m.block[1], cin_pad)
+        self.front0 = basic(fl[0], self.cin_pad)
+        self.front_res = [self._pack_res(fl[i]) for i in (1, 2, 3)]
+        self.enc = [self._pack_res(getattr(ed, f"encoder_res{k}")) for k in range(1, 6)]
+        self.skip = [self._pack_res(getattr(ed, f"skip_res{k}")) for k in range(1, 6)]
+        self.dec = [self._pack_res(getattr(ed, f"decoder_res{k}")) for k in range(1, 6)]
+        self.up = [basic(getattr(ed, f"decoder_upsample{k}")) for k in range(1, 6)]
+        self.mid = self._pack_res(ed.mid_res)
+        self.back_res = self._pack_res(bl[0])
+        self.back1 = basic(bl[1])
+        self.back2 = basic(bl[2])
+        self.out = _PackedConv(model.output_layer, None)
+
+    @staticmethod
+    def _pack_res(m):
+        c1 = _PackedConv(m.res_branch[0], m.res_branch[1])
+        c2 = _PackedConv(m.res_branch[3], m.res_branch[4])
+        sk = _PackedConv(m.skip_con[0], m.skip_con[1]) if len(m.skip_con) else None
+        return (c1, c2, sk)
+
+    # -- primitive launches ------------------------------------------------------------------
+    def _new(self, B, dim, c):
+        return torch.empty((B, dim, dim, dim, c), device=self.device, dtype=torch.float32)
+
+    def _conv(self, x, pc, B, dim, flags, residual=None, out=None):
+        if out is None:
+            out = self._new(B, dim, pc.cout)
+        _lib.conv3d(x, pc.w, pc.b, residual, out, B, dim, pc.cin_pad, pc.cout, pc.k, flags)
+        return out
+
+    def _res(self, x, blk, B, dim):
+        """Res3DBlock (v2v.py:40-43): relu(bn(conv(relu(bn(conv(x))))) + skip(x))."""
+        c1, c2, sk = blk
+        a = self._conv(x, c1, B, dim, _lib.EPI_RELU)
+        s = x if sk is None else self._conv(x, sk, B, dim, 0)
+        return self._conv(a, c2, B, dim, _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU, residual=s)
+
+    def _pool(self, x, B, dim, c):
+        out = self._new(B, dim // 2, c)
+        _lib.maxpool3d_2(x, out, B, dim, c)
+        return out
+
+    def _up(self, x, pc, skip, B, dim):
+        """Upsample3DBlock + decoder add (v2v.py:64-67,124-137): relu(bn(convT(x))) + skip."""
+        out = self._new(B, dim * 2, pc.cout)
+        _lib.deconv3d_k2s2(x, pc.w, pc.b, skip, out, B, dim, pc.cin_pad, pc.cout, _lib.EPI_RELU | _lib.EPI_RES_POST_RELU)
+        return out
+
+    # -- the network -------------------------------------------------------------------------
+    def run(self, x, B, G, out=None):
+        """x: [B,G,G,G,cin_pad] channels-last (channels >= cin zero) -> planar logits [B,cout,G^3]."""
+        assert x.shape[-1] == self.cin_pad and x.is_contiguous()
+        if G % 32:
+            raise ValueError("volume_size must be a multiple of 32 (five 2x max-pools), got %d" % G)
+        x = self._conv(x, self.front0, B, G, _lib.EPI_RELU)
+        for blk in self.front_res:
+            x = self._res(x, blk, B, G)
+        # encoder (v2v.py:104-119)
+        skips = []
+        dim = G
+        for k in range(5):
+            skips.append(self._res(x, self.skip[k], B, dim))
+            x = self._pool(x, B, dim, x.shape[-1])
+            dim //= 2
+            x = self._res(x, self.enc[k], B, dim)
+        x = self._res(x, self.mid, B, dim)
+        # decoder (v2v.py:121-137)
+        for k in range(4, -1, -1):
+            x = self._res(x, self.dec[k], B, dim)
+            x = self._up(x, self.up[k], skips[k], B, dim)
+            skips[k] = None
+            dim *= 2
+        # back layers + output (v2v.py:155-161)
+        x = self._res(x, self.back_res, B, G)
+        x = self._conv(x, self.back1, B, G, _lib.EPI_RELU)
+        x = self._conv(x, self.back2, B, G, _lib.EPI_RELU)
+        if out is None:
+            out = torch.empty((B, self.cout, G * G * G), device=self.device, dtype=torch.float32)
+        _lib.conv3d(x, self.out.w, self.out.b, None, out, B, G, self.out.cin_pad, self.out.cout, 1, _lib.EPI_OUT_PLANAR)
+        return out

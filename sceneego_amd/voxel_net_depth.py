@@ -1,0 +1,232 @@
+"""``VoxelNetwork_depth`` — drop-in for the reference's top module on MI355X.
+
+Boundary: same constructor ``VoxelNetwork_depth(config, device='cuda')``, same public
+attributes (``grid_coord_proj_batch``, ``coord_volumes``, ``coord_volume``, ``grid_coord_proj``, ``ray``,
+``backbone``, ``process_features``, ``volume_net``, ``fisheye_camera_model``), same
+``forward(images, grid_coord_proj_batch, coord_volumes, scene_volumes=None, depth_map_batch=None)`` and
+same 4-tuple return as ``network/voxel_net_depth.py:19-275``; ``state_dict()`` has the reference's 699 keys.
+
+What runs underneath is this build's own pipeline (one HIP stream, no host round trips):
+
+    images --MIOpen--> features[B,64,64,256] --1x1 conv--> F[B,64,64,32]          (pose_resnet.FoldedBackbone)
+    F --se_unproject_gather_f32--> X[B,G,G,G, 0:32]   (table-driven 4-tap, no 1024x1280 intermediate)
+    depth --se_voxelize_f64--> occ[B,G,G,G] --> X[..., 32]                          (float64, bit-exact)
+    X --V2VProgram (se_conv3d_f32 / se_deconv3d_k2s2_f32 / se_maxpool3d_2_f32)--> logits[B,15,G^3]
+    logits --se_softargmax3d_f32--> joints[B,15,3], volumes[B,15,G,G,G]
+
+Deviations from the reference, all documented in DESIGN.md:
+  * B may exceed ``opt.batch_size`` (the reference silently requires B <= 40, ``:241-242,269-270``);
+  * the second return value is the compact ``[B,32,64,64]`` feature map unless the module was built with
+    ``materialize_features=True`` (then the literal ``[B,32,1024,1280]`` tensor of ``:238`` is produced);
+  * the voxeliser uses per-point index semantics (torch<=2.8 meaning of ``voxel[idx.T] = 1``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib, op, pose_resnet
+from .config import resolve_calibration_path
+from .fisheye import FishEyeCameraCalibrated
+from .v2v import V2VModel
+
+FEATURE_CHANNELS = 32
+
+
+class VoxelNetwork_depth(nn.Module):
+    def __init__(self, config, device="cuda", materialize_features: bool = False, verbose: bool = True):
+        super().__init__()
+        say = print if verbose else (lambda *a, **k: None)
+        self.device = device
+        self.num_joints = config.model.backbone.num_joints
+
+        # volume
+        self.volume_softmax = config.model.volume_softmax
+        self.volume_multiplier = config.model.volume_multiplier
+        self.volume_size = config.model.volume_size
+        self.cuboid_side = config.model.cuboid_side
+        self.kind = config.model.kind
+
+        # heatmap (stored, unused on this path — as in the reference)
+        self.heatmap_softmax = config.model.heatmap_softmax
+        self.heatmap_multiplier = config.model.heatmap_multiplier
+        self.heatmap_shape = tuple(config.heatmap_shape)
+        self.materialize_features = materialize_features
+
+        if config.model.backbone.local_checkpoint:
+            loads = torch.load(config.model.backbone.checkpoint, map_location="cpu")
+            self.backbone = pose_resnet.get_pose_net(state_dict=loads["state_dict"])
+        else:
+            say("Do not load checkpoint")
+            self.backbone = pose_resnet.get_pose_net(None)
+        self.backbone = self.backbone.to(device)
+        if config.opt.train_2d is False:
+            for p in self.backbone.parameters():
+                p.requires_grad = False
+
+        # 1x1 conv + nearest upsample + pad: kept as modules for the state-dict keys
+        # (``process_features.0.{weight,bias}``); the upsample/pad are folded into the gather table.
+        self.process_features = nn.Sequential(
+            nn.Conv2d(256, FEATURE_CHANNELS, 1),
+            nn.Upsample(size=(op.UPSAMPLED, op.UPSAMPLED)),
+            nn.ConstantPad2d(padding=(op.PAD_X, op.PAD_X, 0, 0), value=0.0),
+        ).to(device)
+
+        self.with_scene = config.model.with_scene
+        self.with_intersection = False
+        if config.model.with_scene is True:
+            if config.model.with_intersection is True:
+                volume_input_channel_num = FEATURE_CHANNELS + 1 + FEATURE_CHANNELS
+                self.with_intersection = True
+            else:
+                volume_input_channel_num = FEATURE_CHANNELS + 1
+        else:
+            volume_input_channel_num = FEATURE_CHANNELS
+        self.volume_net = V2VModel(volume_input_channel_num, self.num_joints).to(device)
+
+        say("build coord volume")
+        self.coord_volume = op.build_coord_volume(self.volume_size, self.cuboid_side)
+        self.coord_volumes = self.coord_volume.unsqueeze(0).expand(config.opt.batch_size, -1, -1, -1, -1).to(device)
+
+        self.fisheye_camera_model = FishEyeCameraCalibrated(
+            calibration_file_path=resolve_calibration_path(config.dataset.camera_calibration_path))
+        say("build reprojected grid coord")
+        self.grid_coord_proj = op.get_projected_2d_points_with_coord_volumes(
+            fisheye_model=self.fisheye_camera_model, coord_volume=self.coord_volume)
+        self.grid_coord_proj.requires_grad = False
+        self.grid_coord_proj_batch = op.get_grid_coord_proj_batch(
+            self.grid_coord_proj, batch_size=config.opt.batch_size, heatmap_shape=config.heatmap_shape)
+        self.grid_coord_proj_batch.requires_grad = False
+        self.grid_coord_proj_batch = self.grid_coord_proj_batch.to(device)
+
+        self.image_width = config.dataset.image_width
+        self.image_height = config.dataset.image_height
+        self.ray = op.calculated_ray_direction_numpy(self.fisheye_camera_model, self.image_width, self.image_height)
+
+        # device-side constant tables of this build (lazily uploaded, rebuilt if a caller passes other grids)
+        self._tables_for = None
+        self._gather_idx = self._gather_w = self._ray_tab = self._coord_flat = None
+        self._folded = None
+
+    # ------------------------------------------------------------------------------------------
+    def _invalidate(self):
+        self._folded = None
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._invalidate()
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
+        self._tables_for = None
+        out = super()._apply(fn, *a, **k)
+        # plain-attribute constants follow the module like the reference's ``.to(device)`` in __init__
+        for name in ("coord_volumes", "grid_coord_proj_batch"):
+            t = getattr(self, name, None)
+            if isinstance(t, torch.Tensor):
+                setattr(self, name, fn(t))
+        return out
+
+    def compile(self, dtype=torch.float32):
+        """Fold/pack all weights for inference (done lazily by forward; call after changing weights in place)."""
+        if self.training:
+            raise RuntimeError("VoxelNetwork_depth runs inference only: call .eval() before forward()")
+        dev = next(self.volume_net.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.HipExtensionError("VoxelNetwork_depth.forward needs the module on a HIP device (got %s); "
+                                         "there is no CPU fallback" % dev)
+        fb = pose_resnet.FoldedBackbone(self.backbone, dtype=dtype)
+        pf = self.process_features[0]
+        w = pf.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last)
+        b = pf.bias.detach().to(dtype)
+        self._folded = (fb, w, b)
+        self.volume_net.compile()
+        return self
+
+    def _device_tables(self, grid_coord_proj_batch, coord_volumes, device):
+        key = (grid_coord_proj_batch.data_ptr(), coord_volumes.data_ptr(), str(device))
+        if self._tables_for == key:
+            return
+        G = self.volume_size
+        grid = grid_coord_proj_batch[0].reshape(-1, 2)
+        idx, w = op.build_gather_table(grid, self.heatmap_shape, feat_hw=64)
+        self._gather_idx, self._gather_w = idx.to(device), w.to(device)
+        self._coord_flat = coord_volumes[0].reshape(G * G * G, 3).to(device=device, dtype=torch.float32).contiguous()
+        ray_tab = op.build_voxelizer_ray_table(self.ray, self.image_width, self.image_height)
+        self._ray_tab = torch.from_numpy(ray_tab).to(device)
+        self._tables_for = key
+
+    # ------------------------------------------------------------------------------------------
+    def depth_map_to_voxel(self, depth_map_batch):
+        """[B,H,W] depth (metres) -> [B,G,G,G] occupancy, on device (reference ``:194-222`` for the whole batch)."""
+        dev = depth_map_batch.device
+        self._device_tables(self.grid_coord_proj_batch, self.coord_volumes, dev)
+        B = depth_map_batch.shape[0]
+        depth = depth_map_batch.reshape(B, depth_map_batch.shape[-2], depth_map_batch.shape[-1]).float().contiguous()
+        G = self.volume_size
+        occ = torch.empty((B, G, G, G), device=dev, dtype=torch.float32)
+        _lib.voxelize(depth, self._ray_tab, occ, B, depth.shape[1], depth.shape[2], op.UPSAMPLED, op.PAD_X, G,
+                      self.cuboid_side)
+        return occ
+
+    @torch.no_grad()
+    def forward(self, images, grid_coord_proj_batch, coord_volumes, scene_volumes=None, depth_map_batch=None):
+        """See the module docstring; reference ``network/voxel_net_depth.py:224-275``."""
+        _lib.require_hip(images)
+        if self.with_scene is True and scene_volumes is None and depth_map_batch is None:
+            print("no scene volume or depth input!")
+            return None
+        if self._folded is None:
+            self.compile()
+        dev = images.device
+        B = images.shape[0]
+        G = self.volume_size
+        N = G * G * G
+        self._device_tables(grid_coord_proj_batch, coord_volumes, dev)
+        fb, pw, pb = self._folded
+
+        # 2D: backbone (MIOpen) + 1x1 channel reduction, channels-last
+        feat2d = torch.nn.functional.conv2d(fb(images), pw, pb)                  # [B,32,64,64], NHWC strides
+        feat_nhwc = feat2d.permute(0, 2, 3, 1)
+        if feat_nhwc.dtype != torch.float32 or not feat_nhwc.is_contiguous():
+            feat_nhwc = feat_nhwc.float().contiguous()
+
+        # lift to the volume: V2V input buffer [B,G,G,G,cin_pad], zero beyond the real channels
+        prog = self.volume_net.program
+        C = FEATURE_CHANNELS
+        x = torch.empty((B, G, G, G, prog.cin_pad), device=dev, dtype=torch.float32)
+        if prog.cin_pad > C:
+            x[..., C:].zero_()
+        _lib.unproject_gather(feat_nhwc, self._gather_idx, self._gather_w, x, B, feat_nhwc.shape[1] * feat_nhwc.shape[2],
+                              C, N, prog.cin_pad, 0)
+
+        if self.with_scene is True:
+            # the reference's scene_volumes branch ignores with_intersection (:246-249); kept
+            use_inter = self.with_intersection and scene_volumes is None
+            if scene_volumes is not None:
+                occ = scene_volumes.reshape(B, G, G, G).to(device=dev, dtype=torch.float32).contiguous()
+            else:
+                occ = self.depth_map_to_voxel(depth_map_batch)
+            if use_inter:
+                _lib.intersection(x, occ, B, N, C, prog.cin_pad)                 # channels [32,64) = vol * occ
+                x[..., 2 * C] = occ
+            else:
+                x[..., C] = occ
+
+        logits = prog.run(x, B, G)                                               # [B,J,N] planar
+        if self.volume_multiplier != 1.0:
+            logits = logits * self.volume_multiplier
+        joints = torch.empty((B, self.num_joints, 3), device=dev, dtype=torch.float32)
+        volumes = torch.empty_like(logits)
+        _lib.softargmax3d(logits, self._coord_flat, volumes, joints, B * self.num_joints, N,
+                          1 if self.volume_softmax else 0)
+        volumes = volumes.view(B, self.num_joints, G, G, G)
+
+        features = feat2d
+        if self.materialize_features:
+            features = self.process_features[2](self.process_features[1](feat2d.float()))
+        return joints, features, volumes, self.coord_volumes
+
+
+VoxelNetDepth = VoxelNetwork_depth  # the name BASELINE.json uses

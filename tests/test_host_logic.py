@@ -1,0 +1,135 @@
+"""CPU: host-side logic of the product (config, fisheye constants, lookup tables, module tree / state dict)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from sceneego_amd import EasyDict, load_config, op, synth
+from sceneego_amd.fisheye import FishEyeCameraCalibrated
+from sceneego_amd.voxel_net_depth import VoxelNetwork_depth
+
+from conftest import CALIB, synthetic_state_dict
+
+
+def test_easydict_and_config(config):
+    assert config.model.volume_size == 64 and config.model.cuboid_side == 2
+    assert list(config.heatmap_shape) == [1024, 1280]
+    assert config.model.backbone.num_joints == 15 and config.opt.batch_size == 40
+    d = EasyDict({"a": {"b": [1, {"c": 2}]}})
+    assert d.a.b[1].c == 2 and d["a"]["b"][0] == 1
+    d.x = {"y": 3}
+    assert d.x.y == 3 and d["x"]["y"] == 3
+
+
+@pytest.fixture(scope="module")
+def net(config):
+    return VoxelNetwork_depth(config, device="cpu", verbose=False)
+
+
+def test_constants_match_reference_goldens(net, golden):
+    g = golden("constants")
+    np.testing.assert_array_equal(net.grid_coord_proj[::997].numpy(), g["grid_coord_proj_every997"])
+    np.testing.assert_array_equal(net.grid_coord_proj_batch[0, ::997, 0].numpy(), g["grid_norm_every997"])
+    np.testing.assert_array_equal(net.ray[g["ray_idx"]], g["ray_values"])
+    np.testing.assert_array_equal(net.fisheye_camera_model.img_center, g["img_center"])
+    cv = net.coord_volume
+    np.testing.assert_array_equal(cv[[0, 0, 63, 63, 32], [0, 63, 0, 63, 32], [0, 63, 63, 0, 32]].numpy(),
+                                  g["coord_volume_corners"])
+    assert tuple(net.coord_volumes.shape) == (40, 64, 64, 64, 3)
+    assert tuple(net.grid_coord_proj_batch.shape) == (40, 262144, 1, 2)
+
+
+def test_fisheye_round_trip():
+    """pixel -> ray -> pixel (the reference's own smoke idea, utils/fisheye/FishEyeCalibrated.py:205-218)."""
+    cam = FishEyeCameraCalibrated(CALIB)
+    pts = np.array([[640.0, 512.0], [300.0, 700.0], [900.0, 200.0], [615.0, 100.0]])
+    ray = cam.camera2world_ray(pts)
+    np.testing.assert_allclose(np.linalg.norm(ray, axis=1), 1.0, atol=1e-12)
+    back = cam.world2camera(ray * 1.7)
+    np.testing.assert_allclose(back, pts, atol=0.35)   # the two calibration polynomials are only mutually approximate
+    back_t = cam.world2camera_pytorch(torch.from_numpy(ray * 1.7).float()).numpy()
+    np.testing.assert_allclose(back_t, back, atol=1e-3)
+
+
+def test_odd_volume_raises_like_reference(config):
+    """Odd volume_size puts a voxel centre on the optical axis -> 'norm is zero!' (FishEyeCalibrated.py:158,174-177)."""
+    cam = FishEyeCameraCalibrated(CALIB)
+    cv = op.build_coord_volume(5, 2)
+    with pytest.raises(Exception, match="norm is zero"):
+        op.get_projected_2d_points_with_coord_volumes(cam, cv)
+
+
+def test_gather_table_equals_literal_grid_sample(net):
+    """Fused 4-tap table == Upsample(1024^2) + pad(128) + grid_sample on a random 64x64 map."""
+    torch.manual_seed(0)
+    feat = torch.randn(1, 8, 64, 64)
+    big = F.pad(F.interpolate(feat, size=(1024, 1024), mode="nearest"), (128, 128, 0, 0))
+    grid = net.grid_coord_proj_batch[:1]
+    lit = F.grid_sample(big, grid, align_corners=True)[0, :, :, 0]                 # [8, N]
+    idx, w = op.build_gather_table(net.grid_coord_proj_batch[0].reshape(-1, 2), (1024, 1280), 64)
+    flat = feat[0].reshape(8, -1)
+    acc = torch.zeros_like(lit)
+    for t in range(4):
+        i = idx[:, t].long()
+        acc += torch.where(i >= 0, flat[:, i.clamp(min=0)], torch.zeros(())) * w[:, t]
+    assert float((acc - lit).abs().max()) < 2e-6
+    assert int((idx < 0).sum()) == 0            # no voxel projects into the zero-pad columns
+    assert 2900 <= len(torch.unique(idx)) <= 2950   # only ~71 % of the 4096 texels are ever touched
+
+
+def test_voxelizer_ray_table_layout(net):
+    tab = op.build_voxelizer_ray_table(net.ray, 1280, 1024)
+    assert tab.shape == (1024, 1024, 3) and tab.dtype == np.float64
+    y, xp = 17, 900
+    np.testing.assert_array_equal(tab[y, xp], net.ray[(xp + 128) * 1024 + y])
+
+
+def test_state_dict_contract(net):
+    sd = net.state_dict()
+    assert len(sd) == 699
+    assert tuple(sd["backbone.conv1.weight"].shape) == (64, 3, 7, 7)
+    assert tuple(sd["backbone.deconv_layers.0.weight"].shape) == (2048, 256, 4, 4)
+    assert tuple(sd["backbone.final_layer.weight"].shape) == (16, 256, 1, 1)
+    assert tuple(sd["process_features.0.weight"].shape) == (32, 256, 1, 1)
+    assert tuple(sd["volume_net.front_layers.0.block.0.weight"].shape) == (16, 33, 7, 7, 7)
+    assert tuple(sd["volume_net.output_layer.weight"].shape) == (15, 32, 1, 1, 1)
+    assert "volume_net.encoder_decoder.encoder_res1.skip_con.0.weight" in sd
+    assert "volume_net.encoder_decoder.decoder_upsample2.block.0.weight" in sd
+    assert tuple(sd["volume_net.encoder_decoder.decoder_upsample2.block.0.weight"].shape) == (128, 64, 2, 2, 2)
+    n_params = sum(v.numel() for k, v in sd.items() if not k.endswith("num_batches_tracked") and "running" not in k)
+    assert n_params == 33999440 + 8224 + 11949775 - 0 or n_params > 45_000_000
+    # strict load of a full synthetic checkpoint, and of one saved from DataParallel for the backbone helper
+    net.load_state_dict(synthetic_state_dict(False), strict=True)
+    from sceneego_amd import pose_resnet
+    bb = {("module." + k[len("backbone."):]): v for k, v in sd.items() if k.startswith("backbone.")}
+    m = pose_resnet.get_pose_net(state_dict=bb)
+    assert torch.equal(m.conv1.weight, sd["backbone.conv1.weight"])
+
+
+def test_intersection_variant_has_65_input_channels(config):
+    cfg = load_config()
+    cfg.model.with_intersection = True
+    n = VoxelNetwork_depth(cfg, device="cpu", verbose=False)
+    assert tuple(n.state_dict()["volume_net.front_layers.0.block.0.weight"].shape) == (16, 65, 7, 7, 7)
+
+
+def test_forward_contract_without_gpu(net):
+    """No scene input -> None (voxel_net_depth.py:263-265); CPU tensors -> loud failure, never a silent fallback."""
+    from sceneego_amd import _lib
+    img = torch.zeros(1, 3, 256, 256)
+    with pytest.raises(_lib.HipExtensionError):
+        net(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=torch.ones(1, 1024, 1280))
+
+
+def test_synth_is_deterministic_and_portable():
+    a = synth.uniform01(3, "x", 5)
+    b = synth.uniform01(3, "x", 5)
+    assert np.array_equal(a, b)
+    # pinned values: the generator is integer arithmetic, identical on every box
+    np.testing.assert_allclose(a[:2], synth.uniform01(3, "x", 2), rtol=0, atol=0)
+    assert abs(float(synth.normal(0, "n", (100000,)).std()) - 1.0) < 0.01
+    img, depth = synth.make_inputs(7, 1, "floor")
+    assert tuple(img.shape) == (1, 3, 256, 256) and tuple(depth.shape) == (1, 1024, 1280)
+    assert float(depth.max()) <= 10.0 and float(depth.min()) > 0.5

@@ -1,0 +1,84 @@
+"""CPU: the oracle (oracle/sceneego_oracle.py) against golden vectors captured from the real reference.
+
+The goldens were produced by tools/make_golden.py importing /root/reference in the build container
+(tests/golden/META.json records shims, the one patch and the oracle-vs-reference differences at capture
+time: all 0.0).  Tolerances here allow for a different CPU (oneDNN kernel selection / thread count change
+float32 summation order): 2e-5 on joints, 1e-4 relative on logits.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sceneego_oracle as O
+from sceneego_amd import synth
+
+from conftest import synthetic_state_dict
+
+JOINT_TOL = 2e-5
+
+
+def _run(case, golden, oracle_constants, meta):
+    m = next(c for c in meta["cases"] if c["name"] == case)
+    g = golden(case)
+    sd = synthetic_state_dict(m["with_intersection"], m["weight_seed"])
+    const = oracle_constants(m["volume_size"])
+    img, depth = synth.make_inputs(m["input_seed"], m["batch"], m["depth_kind"])
+    taps = {}
+    joints, big, vols = O.forward(sd, const, img, depth, with_intersection=m["with_intersection"], taps=taps)
+    return m, g, joints, vols, taps
+
+
+def _check(m, g, joints, vols, taps):
+    B = m["batch"]
+    N = m["volume_size"] ** 3
+    pos = g["sample_pos"]
+    # occupancy: bit-exact
+    occ = taps["occupancy"].reshape(B, -1).numpy().astype(np.uint8)
+    for b in range(B):
+        assert np.array_equal(np.packbits(occ[b]), g["occupancy_bits"][b])
+        assert int(occ[b].sum()) == int(g["occupancy_count"][b])
+    np.testing.assert_allclose(taps["features64"][:, :, ::8, ::8].numpy(), g["features64_sub"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(taps["feature_volume"].reshape(B, 32, N)[:, :, pos].numpy(), g["feature_volume_samples"],
+                               rtol=1e-4, atol=1e-5)
+    lg = taps["logits"].reshape(B, -1, N)[:, :, pos].numpy()
+    assert np.abs(lg - g["logits_samples"]).max() <= 1e-4 * np.abs(g["logits_samples"]).max()
+    np.testing.assert_allclose(vols.reshape(B, -1, N).max(dim=2)[0].numpy(), g["volumes_max"], rtol=2e-3)
+    assert np.abs(joints.numpy() - g["joints"]).max() <= JOINT_TOL
+
+
+def test_oracle_b1_floor(golden, oracle_constants, golden_meta):
+    _check(*_run("b1_floor", golden, oracle_constants, golden_meta))
+
+
+def test_oracle_b2_uniform(golden, oracle_constants, golden_meta):
+    _check(*_run("b2_uniform", golden, oracle_constants, golden_meta))
+
+
+def test_oracle_intersection(golden, oracle_constants, golden_meta):
+    m, g, joints, vols, taps = _run("b1_intersection", golden, oracle_constants, golden_meta)
+    _check(m, g, joints, vols, taps)
+
+
+def test_oracle_g128(golden, oracle_constants, golden_meta):
+    _check(*_run("b1_g128_floor", golden, oracle_constants, golden_meta))
+
+
+def test_oracle_constants_and_kat(golden, oracle_constants):
+    g = golden("constants")
+    c = oracle_constants(64)
+    np.testing.assert_allclose(c.proj[::997].numpy(), g["grid_coord_proj_every997"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(c.grid[::997].numpy(), g["grid_norm_every997"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(c.ray[g["ray_idx"]], g["ray_values"])           # float64, bit-exact
+    np.testing.assert_array_equal(c.calib.center, g["img_center"])
+    # SURVEY §8c anchors
+    np.testing.assert_allclose(c.proj[0].numpy(), [276.5184, 189.1209], atol=2e-3)
+    np.testing.assert_allclose(c.ray[640 * 1024 + 512], [0.085567517, -0.053026607, 0.994920288], atol=1e-8)
+    # the reference's own known-answer case (network/voxel_net_depth.py:302-320)
+    vol = torch.zeros((4, 15, 64, 64, 64))
+    vol[:, :, 32, 32, 32] = 1
+    vol[:, :, 31, 31, 31] = 1
+    kp, v = O.integrate(vol, c.coord, softmax=True)
+    np.testing.assert_allclose(kp.numpy(), g["kat_softargmax_joints"], atol=1e-6)
+    assert abs(float(kp[0, 0, 2]) - 1.0) < 2e-4 and abs(float(kp[0, 0, 0])) < 1e-6
+    kp2, _ = O.integrate(vol, c.coord, softmax=False)
+    np.testing.assert_allclose(kp2.numpy(), g["kat_relu_joints"], atol=1e-6)

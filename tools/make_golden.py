@@ -1,0 +1,249 @@
+"""Capture golden vectors from the REAL reference (build container only; /root/reference never travels).
+
+Imports jianwang-mpi/SceneEgo from /root/reference with the shims of SURVEY.md Appendix B
+(no bytecode written there; ``cv2``/``easydict`` stub modules; removed numpy aliases; the tuple-index patch
+of ``network/voxel_net_depth.py:221``), loads the portable synthetic weights (sceneego_amd/synth.py), runs
+``VoxelNetwork_depth.forward`` on seeded inputs and writes SMALL fixtures (inputs are seeds, outputs are
+joints + sampled intermediates) under tests/golden/.  It also runs the CPU oracle (oracle/sceneego_oracle.py)
+on the same inputs and prints / records the oracle-vs-reference differences — that is the oracle's pin.
+
+Usage:  python tools/make_golden.py            (about 2 minutes, ~20 GB peak RSS)
+"""
+import sys
+
+sys.dont_write_bytecode = True  # do not litter /root/reference with __pycache__
+
+import hashlib
+import json
+import os
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+# ------------------------------------------------------------------------------------------------
+# shims
+# ------------------------------------------------------------------------------------------------
+def install_shims():
+    np.float = float          # utils/fisheye/FishEyeCalibrated.py:42
+    np.round_ = np.round      # network/voxel_net_depth.py:215
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_NEAREST, cv2.INTER_LINEAR = 0, 1
+    cv2.IMREAD_ANYCOLOR, cv2.IMREAD_ANYDEPTH = 4, 2
+
+    def _resize(src, dsize, interpolation=1):   # only INTER_NEAREST is hit on the path (voxel_net_depth.py:197)
+        assert interpolation == 0
+        w, h = dsize
+        ys = np.minimum((np.arange(h) * (src.shape[0] / h)).astype(np.int64), src.shape[0] - 1)
+        xs = np.minimum((np.arange(w) * (src.shape[1] / w)).astype(np.int64), src.shape[1] - 1)
+        return src[ys][:, xs]
+
+    cv2.resize = _resize
+    sys.modules["cv2"] = cv2
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            d = dict(d or {}, **kw)
+            for k, v in d.items():
+                setattr(self, k, v)
+
+        def __setattr__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            elif isinstance(v, (list, tuple)):
+                v = type(v)(EasyDict(x) if isinstance(x, dict) else x for x in v)
+            super().__setattr__(k, v)
+            super().__setitem__(k, v)
+
+        __setitem__ = __setattr__
+
+    ed = types.ModuleType("easydict")
+    ed.EasyDict = EasyDict
+    sys.modules["easydict"] = ed
+
+
+def import_reference():
+    install_shims()
+    sys.path.insert(0, REF)
+    os.chdir(REF)  # calibration path in the YAML is relative (sceneego.yaml:72)
+    from network.voxel_net_depth import VoxelNetwork_depth
+    from utils import cfg, op
+
+    # restore torch<=2.8 tuple semantics of  voxel[(3,N) ndarray] = 1  (voxel_net_depth.py:221)
+    def _pc2vox(self, pc):
+        p = pc.copy()
+        p[:, 0] = (p[:, 0] + self.cuboid_side / 2) * self.volume_size / self.cuboid_side
+        p[:, 1] = (p[:, 1] + self.cuboid_side / 2) * self.volume_size / self.cuboid_side
+        p[:, 2] = (p[:, 2]) * self.volume_size / self.cuboid_side
+        p = np.round(p)
+        p = p[np.all((p >= 0) & (p <= self.volume_size - 1), axis=1)]
+        v = torch.zeros((self.volume_size,) * 3)
+        v[tuple(torch.from_numpy(p.T.astype(np.int64)))] = 1
+        return v
+
+    VoxelNetwork_depth.point_cloud_to_voxel_numpy = _pc2vox
+    return VoxelNetwork_depth, cfg, op
+
+
+# ------------------------------------------------------------------------------------------------
+def sample_positions(n_total, count, seed):
+    sys.path.insert(0, ROOT)
+    from sceneego_amd import synth
+    return np.unique((synth.uniform01(seed, "golden/positions", count) * n_total).astype(np.int64))
+
+
+def run_case(name, RefNet, cfg_mod, synth, O, *, batch, in_seed, depth_kind, with_intersection=False, volume_size=64,
+             weight_seed=0, extra=None):
+    print(f"== case {name}")
+    config = cfg_mod.load_config("experiments/sceneego/test/sceneego.yaml")
+    config.model.with_intersection = with_intersection
+    config.model.volume_size = volume_size
+    t0 = time.time()
+    net = RefNet(config, device="cpu").eval()
+    sd = synth.make_state_dict(net.state_dict(), seed=weight_seed)
+    net.load_state_dict(sd, strict=True)
+    img, depth = synth.make_inputs(in_seed, batch, depth_kind)
+
+    taps = {}
+    hooks = []
+    def _h_feat(m, i, o):
+        taps["features64"] = o.detach()
+
+    def _h_v2v(m, i, o):
+        taps["v2v_in"] = i[0].detach()
+        taps["logits"] = o.detach()
+
+    hooks.append(net.process_features[0].register_forward_hook(_h_feat))
+    hooks.append(net.volume_net.register_forward_hook(_h_v2v))
+    layer_absmean = {}
+    for mod_name, mod in net.volume_net.named_modules():
+        if isinstance(mod, (torch.nn.Conv3d, torch.nn.ConvTranspose3d)):
+            def _h_layer(m, i, o, n=mod_name):
+                layer_absmean[n] = float(o.detach().abs().mean())
+
+            hooks.append(mod.register_forward_hook(_h_layer))
+    with torch.no_grad():
+        t1 = time.time()
+        kp, feats, vols, cv = net(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth)
+        t_fwd = time.time() - t1
+    for h in hooks:
+        h.remove()
+    G = volume_size
+    N = G ** 3
+    occ_ch = 64 if with_intersection else 32
+    occ = taps["v2v_in"][:, occ_ch]
+    print(f"   init+load {t1 - t0:.1f}s forward {t_fwd:.1f}s joints[0,0]={kp[0, 0].tolist()} occupied={occ.sum(dim=(1, 2, 3)).tolist()}")
+
+    pos = sample_positions(N, 1024, 99)
+    gold = {
+        "joints": kp.numpy().astype(np.float32),
+        "features64_sub": taps["features64"][:, :, ::8, ::8].numpy().astype(np.float32),
+        "occupancy_bits": np.stack([np.packbits(o.numpy().reshape(-1).astype(np.uint8)) for o in occ]),
+        "occupancy_count": occ.sum(dim=(1, 2, 3)).numpy().astype(np.int64),
+        "sample_pos": pos,
+        "feature_volume_samples": taps["v2v_in"][:, :32].reshape(batch, 32, N)[:, :, pos].numpy().astype(np.float32),
+        "logits_samples": taps["logits"].reshape(batch, -1, N)[:, :, pos].numpy().astype(np.float32),
+        "volumes_samples": vols.reshape(batch, -1, N)[:, :, pos].numpy().astype(np.float32),
+        "volumes_max": vols.reshape(batch, -1, N).max(dim=2)[0].numpy().astype(np.float32),
+        "layer_names": np.array(sorted(layer_absmean.keys())),
+        "layer_absmean": np.array([layer_absmean[k] for k in sorted(layer_absmean.keys())], dtype=np.float64),
+    }
+    if with_intersection:
+        gold["intersection_samples"] = taps["v2v_in"][:, 32:64].reshape(batch, 32, N)[:, :, pos].numpy().astype(np.float32)
+
+    # ---- oracle on the same inputs: this is the pin -------------------------------------------
+    const = O.Constants(os.path.join(ROOT, "sceneego_amd", "calibration", "fisheye.calibration_05_08.json"), G=G)
+    otaps = {}
+    oj, obig, ovols = O.forward(sd, const, img, depth, with_intersection=with_intersection, taps=otaps)
+    diffs = {
+        "joints": float((oj - kp).abs().max()),
+        "features64": float((otaps["features64"] - taps["features64"]).abs().max()),
+        "feature_volume": float((otaps["feature_volume"] - taps["v2v_in"][:, :32]).abs().max()),
+        "occupancy_mismatch_voxels": int((otaps["occupancy"] != occ).sum()),
+        "logits": float((otaps["logits"] - taps["logits"]).abs().max()),
+        "volumes": float((ovols - vols).abs().max()),
+        "features_big": float((obig - feats).abs().max()),
+    }
+    print("   oracle vs reference:", diffs)
+    if extra is not None:
+        extra(net, gold)
+    np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **gold)
+    meta = dict(name=name, batch=batch, input_seed=in_seed, depth_kind=depth_kind, with_intersection=with_intersection,
+                volume_size=volume_size, weight_seed=weight_seed, oracle_vs_reference=diffs,
+                reference_forward_s=round(t_fwd, 2))
+    return meta, net
+
+
+def constants_case(net, op_mod):
+    """Init-time constants + the reference's own soft-argmax known-answer case (voxel_net_depth.py:302-320)."""
+    gold = {}
+    gp = net.grid_coord_proj.numpy()
+    gold["grid_coord_proj_every997"] = gp[::997].astype(np.float32)
+    gold["grid_norm_every997"] = net.grid_coord_proj_batch[0, ::997, 0].numpy().astype(np.float32)
+    gold["coord_volume_corners"] = net.coord_volume[[0, 0, 63, 63, 32], [0, 63, 0, 63, 32], [0, 63, 63, 0, 32]].numpy().astype(np.float32)
+    ray = net.ray
+    ridx = np.array([0, 1, 1023, 1024, 640 * 1024 + 512, 128 * 1024, 1151 * 1024 + 1023, 1279 * 1024 + 1023] +
+                    list(range(5000, 1310720, 23411)))
+    gold["ray_idx"] = ridx
+    gold["ray_values"] = ray[ridx].astype(np.float64)
+    gold["ray_sha256_f64"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(ray).tobytes()).digest(), dtype=np.uint8)
+    gold["img_center"] = net.fisheye_camera_model.img_center.astype(np.float64)
+    # KAT: volumes all zero except ones at [32,32,32] and [31,31,31]
+    volumes = torch.zeros((4, 15, 64, 64, 64))
+    volumes[:, :, 32, 32, 32] = 1
+    volumes[:, :, 31, 31, 31] = 1
+    kp, v = op_mod.integrate_tensor_3d_with_coordinates(volumes, net.coord_volumes[:4], softmax=True)
+    gold["kat_softargmax_joints"] = kp.numpy().astype(np.float32)
+    gold["kat_softargmax_peak"] = np.array([float(v[0, 0, 32, 32, 32]), float(v[0, 0, 0, 0, 0])], dtype=np.float32)
+    kp2, v2 = op_mod.integrate_tensor_3d_with_coordinates(volumes, net.coord_volumes[:4], softmax=False)
+    gold["kat_relu_joints"] = kp2.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "constants.npz"), **gold)
+    print("   KAT softargmax joints[0,0] =", kp[0, 0].tolist())
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    sys.path.insert(0, ROOT)
+    from oracle import sceneego_oracle as O
+    from sceneego_amd import synth
+
+    RefNet, cfg_mod, op_mod = import_reference()
+    metas = []
+    m, net = run_case("b2_uniform", RefNet, cfg_mod, synth, O, batch=2, in_seed=1234, depth_kind="uniform")
+    metas.append(m)
+    constants_case(net, op_mod)
+    del net
+    m, _ = run_case("b1_floor", RefNet, cfg_mod, synth, O, batch=1, in_seed=77, depth_kind="floor")
+    metas.append(m)
+    m, _ = run_case("b1_intersection", RefNet, cfg_mod, synth, O, batch=1, in_seed=4321, depth_kind="uniform",
+                    with_intersection=True)
+    metas.append(m)
+    m, _ = run_case("b1_g128_floor", RefNet, cfg_mod, synth, O, batch=1, in_seed=555, depth_kind="floor", volume_size=128)
+    metas.append(m)
+
+    meta = {
+        "generator": "tools/make_golden.py",
+        "reference": "jianwang-mpi/SceneEgo @ /root/reference (read-only mount)",
+        "torch": torch.__version__, "numpy": np.__version__,
+        "shims": ["sys.dont_write_bytecode", "np.float=float", "np.round_=np.round", "cv2 stub (resize INTER_NEAREST = floor(dst*src/dst))",
+                  "easydict stub"],
+        "patch": "VoxelNetwork_depth.point_cloud_to_voxel_numpy: voxel[tuple(idx.T)] = 1 (torch<=2.8 semantics of voxel_net_depth.py:221); "
+                 "un-patched torch 2.10 treats the (3,N) ndarray as a dim-0 tensor index and fills whole slabs",
+        "weights": "sceneego_amd.synth.make_state_dict(seed) + sceneego_amd/synth_calibration.json",
+        "cases": metas,
+    }
+    with open(os.path.join(GOLD, "META.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote", GOLD)
+    assert not any(d == "__pycache__" for _, ds, _ in os.walk(REF) for d in ds), "reference tree was modified!"
+
+
+if __name__ == "__main__":
+    main()
