@@ -136,10 +136,36 @@ def conv3d_pack(w, b, gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_
                                      _stream()), "se_conv3d_pack_f32")
 
 
+# Optional per-launch timing (bench.py's roofline leg): HIP events recorded on the launch stream around every
+# conv launch, keyed by shape.  None = off (the default; nothing is recorded in normal operation).
+_prof = None
+
+
+def start_profile():
+    global _prof
+    _prof = []
+
+
+def stop_profile():
+    """-> {key: [ms, ...]} ; caller must have synchronised the device."""
+    global _prof
+    rec, _prof = _prof, None
+    out = {}
+    for key, e0, e1 in rec or []:
+        out.setdefault(key, []).append(e0.elapsed_time(e1))
+    return out
+
+
 def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin_pad, cout, ksize, flags):
     require_hip(inp, out)
+    if _prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _check(load().se_conv3d_f32(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim, cin_pad,
                                 cout, ksize, flags, _stream()), "se_conv3d_f32")
+    if _prof is not None:
+        e1.record()
+        _prof.append((("conv3d", ksize, cin_pad, cout, dim), e0, e1))
 
 
 def deconv3d_k2s2(inp, wpack, bpack, residual, out, batch, dim, cin, cout, flags):
