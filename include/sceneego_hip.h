@@ -90,10 +90,16 @@ long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, int transpose
 /* Conv3d (k = 1, 3 or 7, stride 1, zero padding (k-1)/2) + folded BN + epilogue.
  * Replaces Basic3DBlock / Res3DBlock convs and output_layer (network/v2v.py:8-43,161).
  *   in  [B][D][D][D][cin_pad]   out [B][D][D][D][cout] (or planar, SE_EPI_OUT_PLANAR)
- *   residual: same shape as out (NDHWC) or NULL.  cin_pad % 16 == 0; cout % 16 == 0 unless planar. */
+ *   residual: same shape as out (NDHWC) or NULL.  cin = real input channels (<= cin_pad, the channel stride
+ *   of `in`; channels [cin, cin_pad) must hold finite values, they meet zero weights); cin_pad % 16 == 0;
+ *   cout % 16 == 0 unless planar.  Volumes with dim % 8 == 0 and dim >= 16 run the LDS-tiled kernels, everything
+ *   else the direct kernel; results are identical in both up to float32 summation order.
+ *   workspace (optional, may be NULL): `workspace_elems` floats of scratch; when given, small volumes
+ *   (too few voxels to fill 256 CUs) split the 27 taps over extra workgroups and reduce the partial sums
+ *   from the workspace in a fixed order (deterministic).  32 Mi floats cover every V2V level up to B = 64. */
 int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
-                  float* out, int batch, int dim, int cin_pad, int cout, int ksize, int flags,
-                  void* stream);
+                  float* out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
+                  float* workspace, long long workspace_elems, void* stream);
 
 /* ConvTranspose3d(k=2, s=2) + folded BN + ReLU (+ skip).  Replaces Upsample3DBlock and the decoder
  * adds (network/v2v.py:55-67,124-137).  in [B][D]^3[cin] -> out [B][2D]^3[cout]; residual like out. */

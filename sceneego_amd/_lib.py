@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -31,7 +31,7 @@ SIGNATURES = {
     "se_intersection_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "se_conv3d_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_packed_elems": (_ll, [_i, _i, _i, _i]),
-    "se_conv3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "se_conv3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
     "se_deconv3d_k2s2_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_maxpool3d_2_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "se_softargmax3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -156,13 +156,14 @@ def stop_profile():
     return out
 
 
-def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin_pad, cout, ksize, flags):
+def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksize, flags, workspace=None):
     require_hip(inp, out)
     if _prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _check(load().se_conv3d_f32(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim, cin_pad,
-                                cout, ksize, flags, _stream()), "se_conv3d_f32")
+    _check(load().se_conv3d_f32(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim, cin,
+                                cin_pad, cout, ksize, flags, _ptr(workspace),
+                                0 if workspace is None else workspace.numel(), _stream()), "se_conv3d_f32")
     if _prof is not None:
         e1.record()
         _prof.append((("conv3d", ksize, cin_pad, cout, dim), e0, e1))

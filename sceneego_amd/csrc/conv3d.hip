@@ -19,21 +19,23 @@
 // The LDS-tiled kernels for the 64^3/32^3 levels live in conv3d_tiled.hip.
 #include "common.h"
 
+#include "conv_common.h"
+
 namespace {
 
-__host__ __device__ inline int round_up16(int v) { return (v + 15) & ~15; }
-
 // ------------------------------------------------------------------------------------------------
-// weight packing: wpack[tap][cg][nt][lane][j] = W[cout = 16*nt + (lane&15)][cin = 16*cg + 4*(lane>>4) + j][tap] * scale[cout]
-// bpack[cout] = (b - mean) * scale + beta,  scale = gamma / sqrt(var + eps)    (identity without BN)
+// weight packing (see conv_common.h for the two block orders)
+//   section A: wpack[cg][tap][nt][lane][j] = W[cout = 16*nt + (lane&15)][cin = 16*cg + 4*(lane>>4) + j][tap] * scale[cout]
+//   section B (k = 7 only, read by the LDS-tiled 7x7x7 kernel: 4-channel chunks, 4 taps on the MFMA k lanes):
+//              wpack[A + [ch][g][nt][lane][j]] = W[cout][cin = 4*ch + j][tap = 4*g + (lane>>4)] * scale[cout]
+//   bpack[cout] = (b - mean) * scale + beta,  scale = gamma / sqrt(var + eps)    (identity without BN)
 // ------------------------------------------------------------------------------------------------
 __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict__ b,
                             const float* __restrict__ gamma, const float* __restrict__ beta,
                             const float* __restrict__ mean, const float* __restrict__ var, float eps,
                             float* __restrict__ wpack, float* __restrict__ bpack, int cout, int cin, int cin_pad,
-                            int taps, int transposed, long long total) {
+                            int taps, int transposed, long long total_a, long long total) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int cgs = cin_pad / 16;
     const int nts = round_up16(cout) / 16;
     if (t < round_up16(cout)) {
         float v = 0.f;
@@ -47,14 +49,22 @@ __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict
     if (t >= total) return;
     const int j = (int)(t & 3);
     const int lane = (int)((t >> 2) & 63);
-    long long r = t >> 8;
-    const int nt = (int)(r % nts); r /= nts;
-    const int cg = (int)(r % cgs); r /= cgs;
-    const int tap = (int)r;
+    int nt, tap, ci;
+    if (t < total_a) {
+        long long r = t >> 8;
+        nt = (int)(r % nts); r /= nts;
+        tap = (int)(r % taps); r /= taps;
+        ci = (int)r * 16 + 4 * (lane >> 4) + j;
+    } else {
+        long long r = (t - total_a) >> 8;
+        nt = (int)(r % nts); r /= nts;
+        const int g = (int)(r % SE_K7_GROUPS); r /= SE_K7_GROUPS;
+        tap = 4 * g + (lane >> 4);
+        ci = (int)r * 4 + j;
+    }
     const int co = nt * 16 + (lane & 15);
-    const int ci = cg * 16 + 4 * (lane >> 4) + j;
     float v = 0.f;
-    if (co < cout && ci < cin) {
+    if (co < cout && ci < cin && tap < taps) {
         const float sc = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
         const float wv = transposed ? w[((size_t)ci * cout + co) * taps + tap] : w[((size_t)co * cin + ci) * taps + tap];
         v = wv * sc;
@@ -65,20 +75,6 @@ __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // direct implicit-GEMM kernel
 // ------------------------------------------------------------------------------------------------
-struct ConvArgs {
-    const float* in;
-    const float* wpack;
-    const float* bpack;
-    const float* res;
-    float* out;
-    long long total_vox;  // B * dim^3 (input voxels)
-    int dim;
-    int cin_pad;
-    int cout;      // real output channels
-    int nts;       // cout tiles of 16 in the packed weights
-    int flags;
-};
-
 template <int KS, int M_T, int N_T, bool DECONV>
 __global__ __launch_bounds__(256) void conv3d_direct_kernel(ConvArgs a) {
     constexpr int P = (KS - 1) / 2;
@@ -88,7 +84,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(ConvArgs a) {
     const int vl = lane & 15;   // voxel within the 16-voxel tile / cout within the weight tile
     const int h = lane >> 4;    // k group
     const int dim = a.dim;
-    const int cgs = a.cin_pad >> 4;
+    const int cgs = (a.cin + 15) >> 4;   // channel groups that hold real channels
     const int nt0 = blockIdx.y * N_T;
     const int sub = DECONV ? blockIdx.z : 0;  // (a,b,c) sub-position of the 2x2x2 transposed kernel
 
@@ -135,7 +131,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(ConvArgs a) {
                 xf[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (ok[m]) xf[m] = *reinterpret_cast<const f32x4*>(src[m] + cg * 16);
             }
-            const f32x4* wrow = wp + ((size_t)(wtap * cgs + cg) * a.nts + nt0) * 64 + lane;
+            const f32x4* wrow = wp + ((size_t)(cg * (DECONV ? 8 : TAPS) + wtap) * a.nts + nt0) * 64 + lane;
 #pragma unroll
             for (int n = 0; n < N_T; ++n) {
                 const f32x4 wf = wrow[n * 64];
@@ -151,10 +147,6 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(ConvArgs a) {
     }
 
     // epilogue: lane owns couts co0..co0+3 of voxel (m, vl)
-    const bool relu = a.flags & SE_EPI_RELU;
-    const bool res_pre = (a.flags & SE_EPI_RES_PRE_RELU) && a.res;
-    const bool res_post = (a.flags & SE_EPI_RES_POST_RELU) && a.res;
-    const bool planar = a.flags & SE_EPI_OUT_PLANAR;
     const int odim = DECONV ? dim * 2 : dim;
     const long long ovox_per_b = (long long)odim * odim * odim;
 #pragma unroll
@@ -168,32 +160,77 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(ConvArgs a) {
         }
         const long long on = ((long long)oz * odim + oy) * odim + ox;  // voxel index inside the sample
 #pragma unroll
-        for (int n = 0; n < N_T; ++n) {
-            const int co0 = (nt0 + n) * 16 + 4 * h;
-            if (co0 >= a.cout) continue;
-            f32x4 v = acc[m][n] + *reinterpret_cast<const f32x4*>(a.bpack + co0);
-            if (planar) {
-                float* o = a.out + ((long long)vb[m] * a.cout + co0) * ovox_per_b + on;
-                const float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int n = 0; n < N_T; ++n) conv_epilogue(a, acc[m][n], vb[m], on, ovox_per_b, (nt0 + n) * 16 + 4 * h);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// split-K variant for the small pyramid levels (8^3, 4^3, 2^3: 128 -> 128 channels, a few thousand voxels).
+// There the direct kernel has only a handful of workgroups, each walking all 27 x 8 steps serially
+// (0.24 ms per conv, MFMA-latency-bound on <10 % of the chip).  Here grid.z splits the 27 taps, every
+// (voxel tile, cout tile, tap slice) is its own workgroup writing a partial sum to the workspace, and a second
+// tiny kernel adds the slices in a FIXED order (bitwise deterministic, no atomics) and applies the epilogue.
+// ------------------------------------------------------------------------------------------------
+template <int N_T>
+__global__ __launch_bounds__(256) void conv3d_k3_splitk_kernel(ConvArgs a, float* __restrict__ ws, int taps_per_split) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int vl = lane & 15;
+    const int h = lane >> 4;
+    const int dim = a.dim;
+    const int cgs = (a.cin + 15) >> 4;
+    const int nt0 = blockIdx.y * N_T;
+    const int split = blockIdx.z;
+
+    const long long vid = ((long long)blockIdx.x * 4 + wave) * 16 + vl;
+    const bool vok = vid < a.total_vox;
+    long long t = vok ? vid : 0;
+    const int vx = (int)(t % dim); t /= dim;
+    const int vy = (int)(t % dim); t /= dim;
+    const int vz = (int)(t % dim); t /= dim;
+    const int vb = (int)t;
+
+    f32x4 acc[N_T];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (co0 + r < a.cout) {
-                        float y = vv[r];
-                        if (relu) y = fmaxf(y, 0.f);
-                        o[(long long)r * ovox_per_b] = y;
-                    }
-                }
-            } else {
-                const long long ooff = ((long long)vb[m] * ovox_per_b + on) * a.cout + co0;
-                if (res_pre) v += *reinterpret_cast<const f32x4*>(a.res + ooff);
-                if (relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-                if (res_post) v += *reinterpret_cast<const f32x4*>(a.res + ooff);
-                *reinterpret_cast<f32x4*>(a.out + ooff) = v;
+    for (int n = 0; n < N_T; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack);
+    const int tap0 = split * taps_per_split;
+    for (int tap = tap0; tap < tap0 + taps_per_split; ++tap) {
+        const int zz = vz + tap / 9 - 1, yy = vy + (tap / 3) % 3 - 1, xx = vx + tap % 3 - 1;
+        const bool ok = vok && (unsigned)zz < (unsigned)dim && (unsigned)yy < (unsigned)dim && (unsigned)xx < (unsigned)dim;
+        const float* src = a.in + (ok ? ((((long long)vb * dim + zz) * dim + yy) * dim + xx) * a.cin_pad + 4 * h : 0);
+        for (int cg = 0; cg < cgs; ++cg) {
+            f32x4 xf = {0.f, 0.f, 0.f, 0.f};
+            if (ok) xf = *reinterpret_cast<const f32x4*>(src + cg * 16);
+            const f32x4* wrow = wp + ((size_t)(cg * 27 + tap) * a.nts + nt0) * 64 + lane;
+#pragma unroll
+            for (int n = 0; n < N_T; ++n) {
+                const f32x4 wf = wrow[n * 64];
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, xf.x, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, xf.y, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, xf.z, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, xf.w, acc[n], 0, 0, 0);
             }
         }
     }
+    if (!vok) return;
+    float* o = ws + ((size_t)split * a.total_vox + vid) * a.cout;
+#pragma unroll
+    for (int n = 0; n < N_T; ++n) *reinterpret_cast<f32x4*>(o + (nt0 + n) * 16 + 4 * h) = acc[n];
+}
+
+// thread = (voxel, cout quad): sum the split partials in order, then the usual epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, const float* __restrict__ ws, int splits) {
+    const int cq = a.cout >> 2;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.total_vox * cq) return;
+    const long long vid = t / cq;
+    const int q = (int)(t - vid * cq);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(ws + ((size_t)s * a.total_vox + vid) * a.cout + q * 4);
+    const long long per_b = (long long)a.dim * a.dim * a.dim;
+    const int b = (int)(vid / per_b);
+    conv_epilogue(a, v, b, vid - (long long)b * per_b, per_b, q * 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -238,11 +275,17 @@ int launch_direct(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int se_abi_version(void) { return 1; }
+extern "C" int se_abi_version(void) { return 3; }
 
-extern "C" long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, int transposed) {
+static long long packed_elems_a(int cout, int cin_pad, int ksize, int transposed) {
     const long long taps = transposed ? 8 : (long long)ksize * ksize * ksize;
     return taps * (cin_pad / 16) * (round_up16(cout) / 16) * 256;
+}
+
+extern "C" long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, int transposed) {
+    long long n = packed_elems_a(cout, cin_pad, ksize, transposed);
+    if (!transposed && ksize == 7) n += (long long)(cin_pad / 4) * SE_K7_GROUPS * (round_up16(cout) / 16) * 256;
+    return n;
 }
 
 extern "C" int se_conv3d_pack_f32(const float* w, const float* b, const float* gamma, const float* beta,
@@ -255,33 +298,54 @@ extern "C" int se_conv3d_pack_f32(const float* w, const float* b, const float* g
         return SE_ERR_BAD_ARG;
     const int taps = ksize * ksize * ksize;
     const long long total = se_conv3d_packed_elems(cout, cin_pad, ksize, transposed);
+    const long long total_a = packed_elems_a(cout, cin_pad, ksize, transposed);
     const long long threads = total > round_up16(cout) ? total : round_up16(cout);
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, se_stream(stream), w, b,
-                       gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_pad, taps, transposed, total);
+                       gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_pad, taps, transposed, total_a, total);
     SE_CHECK_LAUNCH();
     return 0;
 }
 
 // implemented in conv3d_tiled.hip; returns 1 if it took the launch, 0 if the shape is not covered, <0 / hipError on failure
-int se_conv3d_tiled_try(const float* in, const float* wpack, const float* bpack, const float* residual, float* out,
-                        int batch, int dim, int cin_pad, int cout, int ksize, int flags, hipStream_t s);
+int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s);
 
 extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
-                             float* out, int batch, int dim, int cin_pad, int cout, int ksize, int flags,
-                             void* stream) {
-    if (batch <= 0 || dim <= 0 || cin_pad <= 0 || (cin_pad & 15) || cout <= 0) return SE_ERR_BAD_ARG;
+                             float* out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
+                             float* workspace, long long workspace_elems, void* stream) {
+    if (batch <= 0 || dim <= 0 || cin <= 0 || cin_pad < cin || (cin_pad & 15) || cout <= 0) return SE_ERR_BAD_ARG;
     if (ksize != 1 && ksize != 3 && ksize != 7) return SE_ERR_BAD_ARG;
     const bool planar = flags & SE_EPI_OUT_PLANAR;
     if (!planar && (cout & 15)) return SE_ERR_BAD_ARG;
     if (planar && (flags & (SE_EPI_RES_PRE_RELU | SE_EPI_RES_POST_RELU))) return SE_ERR_BAD_ARG;
     if ((flags & SE_EPI_RES_PRE_RELU) && (flags & SE_EPI_RES_POST_RELU)) return SE_ERR_BAD_ARG;
     hipStream_t s = se_stream(stream);
-    const int took = se_conv3d_tiled_try(in, wpack, bpack, residual, out, batch, dim, cin_pad, cout, ksize, flags, s);
-    if (took != 0) return took > 0 ? 0 : took;
     ConvArgs a;
     a.in = in; a.wpack = wpack; a.bpack = bpack; a.res = residual; a.out = out;
     a.total_vox = (long long)batch * dim * dim * dim;
-    a.dim = dim; a.cin_pad = cin_pad; a.cout = cout; a.nts = round_up16(cout) / 16; a.flags = flags;
+    a.dim = dim; a.cin = cin; a.cin_pad = cin_pad; a.cout = cout; a.nts = round_up16(cout) / 16; a.flags = flags;
+    a.wpack_b = wpack + packed_elems_a(cout, cin_pad, ksize, 0);
+    const int took = se_conv3d_tiled_try(a, batch, ksize, s);
+    if (took != SE_TILED_NOT_TAKEN) return took;
+    // small volumes with wide channels: split the taps over grid.z when the plain launch would not fill the chip
+    if (ksize == 3 && !planar && workspace && a.nts % 2 == 0) {
+        const long long m_blocks = (a.total_vox + 63) / 64;
+        const long long wgs = m_blocks * (a.nts / 2);
+        if (wgs < 1024) {
+            int splits = 27;                                  // taps per split: 1, 3, 9 (or no split)
+            while (splits > 1 && (wgs * (splits / 3) >= 2048 || (long long)splits * a.total_vox * cout > workspace_elems))
+                splits /= 3;
+            if (splits > 1) {
+                hipLaunchKernelGGL((conv3d_k3_splitk_kernel<2>), dim3((unsigned)m_blocks, a.nts / 2, splits), dim3(256), 0, s,
+                                   a, workspace, 27 / splits);
+                SE_CHECK_LAUNCH();
+                const long long threads = a.total_vox * (cout / 4);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a,
+                                   workspace, splits);
+                SE_CHECK_LAUNCH();
+                return 0;
+            }
+        }
+    }
     switch (ksize) {
         case 1: return launch_direct<1>(a, s);
         case 3: return launch_direct<3>(a, s);
@@ -297,7 +361,8 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
     ConvArgs a;
     a.in = in; a.wpack = wpack; a.bpack = bpack; a.res = residual; a.out = out;
     a.total_vox = (long long)batch * dim * dim * dim;
-    a.dim = dim; a.cin_pad = cin; a.cout = cout; a.nts = cout / 16; a.flags = flags;
+    a.dim = dim; a.cin = cin; a.cin_pad = cin; a.cout = cout; a.nts = cout / 16; a.flags = flags;
+    a.wpack_b = nullptr;
     const long long vox_per_wg = 4 * 4 * 16;
     const unsigned gx = (unsigned)((a.total_vox + vox_per_wg - 1) / vox_per_wg);
     if (a.nts % 2 == 0) {

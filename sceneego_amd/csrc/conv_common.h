@@ -1,0 +1,52 @@
+// Shared between conv3d.hip (direct kernels, packer, C ABI) and conv3d_tiled.hip (LDS-tiled kernels).
+#pragma once
+#include "common.h"
+
+// 7x7x7 tiled kernel: the 343 taps are taken 4 at a time on the MFMA k lanes -> 86 groups (last one has 1 pad tap)
+#define SE_K7_TAPS 343
+#define SE_K7_GROUPS 86
+#define SE_TILED_NOT_TAKEN (-1000)
+
+__host__ __device__ inline int round_up16(int v) { return (v + 15) & ~15; }
+
+struct ConvArgs {
+    const float* in;
+    const float* wpack;    // section A: [cg][tap][nt][lane][4]
+    const float* wpack_b;  // section B (k = 7 only): [chunk4][group][nt][lane][4]
+    const float* bpack;
+    const float* res;
+    float* out;
+    long long total_vox;  // B * dim^3 (input voxels)
+    int dim;
+    int cin;       // real input channels (chunks beyond it are skipped: their weights are zero)
+    int cin_pad;   // channel stride of the input tensor
+    int cout;      // real output channels
+    int nts;       // cout tiles of 16 in the packed weights
+    int flags;
+};
+
+// Epilogue for one accumulator fragment: this lane owns output channels co0..co0+3 of one voxel
+// (`on` = voxel index inside sample `b`, `ovox_per_b` voxels per sample).  bias (+BN shift) -> [+res] -> [ReLU]
+// -> [+res] -> 16-byte channels-last store, or 4 planar stores for SE_EPI_OUT_PLANAR.
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 v, int b, long long on, long long ovox_per_b,
+                                              int co0) {
+    if (co0 >= a.cout) return;
+    v += *reinterpret_cast<const f32x4*>(a.bpack + co0);
+    const bool relu = a.flags & SE_EPI_RELU;
+    if (a.flags & SE_EPI_OUT_PLANAR) {
+        float* o = a.out + ((long long)b * a.cout + co0) * ovox_per_b + on;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (co0 + r < a.cout) o[(long long)r * ovox_per_b] = relu ? fmaxf(vv[r], 0.f) : vv[r];
+        }
+        return;
+    }
+    const long long ooff = ((long long)b * ovox_per_b + on) * a.cout + co0;
+    if ((a.flags & SE_EPI_RES_PRE_RELU) && a.res) v += *reinterpret_cast<const f32x4*>(a.res + ooff);
+    if (relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    if ((a.flags & SE_EPI_RES_POST_RELU) && a.res) v += *reinterpret_cast<const f32x4*>(a.res + ooff);
+    *reinterpret_cast<f32x4*>(a.out + ooff) = v;
+}

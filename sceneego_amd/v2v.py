@@ -141,7 +141,7 @@ class V2VModel(nn.Module):
 # the launch program
 # ------------------------------------------------------------------------------------------------
 class _PackedConv:
-    __slots__ = ("w", "b", "cin_pad", "cout", "k", "transposed")
+    __slots__ = ("w", "b", "cin", "cin_pad", "cout", "k", "transposed")
 
     def __init__(self, conv, bn, cin_pad=None):
         transposed = isinstance(conv, nn.ConvTranspose3d)
@@ -154,7 +154,7 @@ class _PackedConv:
             cout, cin = w.shape[0], w.shape[1]
             k = w.shape[2]
         self.cin_pad = cin_pad if cin_pad is not None else _round16(cin)
-        self.cout, self.k, self.transposed = cout, k, transposed
+        self.cin, self.cout, self.k, self.transposed = cin, cout, k, transposed
         n = _lib.conv3d_packed_elems(cout, self.cin_pad, k, transposed)
         self.w = torch.empty(n, device=dev, dtype=torch.float32)
         self.b = torch.empty(_round16(cout), device=dev, dtype=torch.float32)
@@ -191,6 +191,8 @@ class V2VProgram:
         self.back1 = basic(bl[1])
         self.back2 = basic(bl[2])
         self.out = _PackedConv(model.output_layer, None)
+        # scratch for the split-K path of the small pyramid levels (se_conv3d_f32 workspace): 32 Mi floats
+        self.workspace = torch.empty(32 << 20, device=self.device, dtype=torch.float32)
 
     @staticmethod
     def _pack_res(m):
@@ -206,7 +208,7 @@ class V2VProgram:
     def _conv(self, x, pc, B, dim, flags, residual=None, out=None):
         if out is None:
             out = self._new(B, dim, pc.cout)
-        _lib.conv3d(x, pc.w, pc.b, residual, out, B, dim, pc.cin_pad, pc.cout, pc.k, flags)
+        _lib.conv3d(x, pc.w, pc.b, residual, out, B, dim, pc.cin, pc.cin_pad, pc.cout, pc.k, flags, self.workspace)
         return out
 
     def _res(self, x, blk, B, dim):
@@ -257,5 +259,6 @@ class V2VProgram:
         x = self._conv(x, self.back2, B, G, _lib.EPI_RELU)
         if out is None:
             out = torch.empty((B, self.cout, G * G * G), device=self.device, dtype=torch.float32)
-        _lib.conv3d(x, self.out.w, self.out.b, None, out, B, G, self.out.cin_pad, self.out.cout, 1, _lib.EPI_OUT_PLANAR)
+        _lib.conv3d(x, self.out.w, self.out.b, None, out, B, G, self.out.cin, self.out.cin_pad, self.out.cout, 1,
+                    _lib.EPI_OUT_PLANAR)
         return out
