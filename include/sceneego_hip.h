@@ -119,6 +119,9 @@ int se_softargmax3d_f32(const float* vol, const float* coord, float* out_vol, fl
                         float* scratch, int rows, int voxels, int mode, void* stream);
 long long se_softargmax3d_scratch_elems(int rows);
 
+/* Debug / benchmarking only: selects alternative kernel variants for A/B timing (0 = production dispatch). */
+void se_debug_set_variant(int variant);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,7 +159,8 @@ CONV_CASES = [
     (1, 6, 16, 48, 3, True, True, True),        # odd number of cout tiles -> N_T = 1 path
     # LDS-tiled kernels (dim % 8 == 0, dim >= 16)
     (2, 16, 16, 32, 3, True, False, True),
-    (1, 32, 32, 32, 3, True, True, True),
+    (1, 32, 32, 32, 3, True, True, True),       # persistent LDS-weights kernel, 2 chunks
+    (2, 32, 16, 32, 3, True, False, True),      # persistent, 1 chunk
     (1, 16, 64, 64, 3, True, True, True),
     (2, 16, 128, 128, 3, False, False, True),
     (1, 24, 32, 64, 3, True, False, True),      # non power-of-two volume, tiled

@@ -1,0 +1,72 @@
+"""A/B timing of se_conv3d_f32 variants on the GPU (interleaved rounds in one process, guide rule 24).
+
+usage: python tools/bench_conv.py [--batch 8] [--rounds 10]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sceneego_amd import _lib  # noqa: E402
+from sceneego_amd.v2v import _PackedConv  # noqa: E402
+
+SHAPES = [  # (dim, cin, cin_pad, cout, k)
+    (64, 32, 32, 32, 3),
+    (64, 16, 16, 32, 3),
+    (64, 33, 48, 16, 7),
+    (32, 64, 64, 64, 3),
+    (32, 32, 32, 64, 3),
+    (16, 128, 128, 128, 3),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--rounds", type=int, default=10)
+    ap.add_argument("--variants", default="0,1")
+    ap.add_argument("--no-res", action="store_true")
+    args = ap.parse_args()
+    lib = _lib.load()
+    dev = "cuda:0"
+    B = args.batch
+    variants = [int(v) for v in args.variants.split(",")]
+    ws = torch.empty(32 << 20, device=dev)
+    for dim, cin, cin_pad, cout, k in SHAPES:
+        conv = torch.nn.Conv3d(cin, cout, k, padding=(k - 1) // 2).to(dev)
+        pc = _PackedConv(conv, None, cin_pad=cin_pad)
+        x = torch.randn(B, dim, dim, dim, cin_pad, device=dev)
+        res = torch.randn(B, dim, dim, dim, cout, device=dev)
+        out = torch.empty(B, dim, dim, dim, cout, device=dev)
+        flop = 2.0 * B * dim ** 3 * k ** 3 * cin * cout
+        times = {v: [] for v in variants}
+        outs = {}
+        for r in range(args.rounds + 2):
+            for v in variants:
+                lib.se_debug_set_variant(v)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.conv3d(x, pc.w, pc.b, None if args.no_res else res, out, B, dim, cin, cin_pad, cout, k,
+                            _lib.EPI_RELU | (0 if args.no_res else _lib.EPI_RES_PRE_RELU), ws)
+                e1.record()
+                torch.cuda.synchronize()
+                if r >= 2:
+                    times[v].append(e0.elapsed_time(e1))
+                if r == 0:
+                    outs[v] = out.clone()
+        lib.se_debug_set_variant(0)
+        base = outs[variants[0]]
+        msg = f"k{k} {cin:3d}->{cout:3d} @{dim}^3 B={B}:"
+        for v in variants:
+            t = sorted(times[v])
+            med = t[len(t) // 2]
+            diff = float((outs[v] - base).abs().max())
+            msg += f"  v{v}: med {med:.3f} ms min {t[0]:.3f} ({flop / med / 1e9:.1f} TF/s) maxdiff {diff:.2e}"
+        print(msg, flush=True)
+
+
+if __name__ == "__main__":
+    main()
