@@ -19,6 +19,10 @@
 // 4*M_T*N_T MFMAs of 32 cycles each (k3 32->32: 6 loads for 32 MFMAs = 1024 SIMD cycles).
 #include "conv_common.h"
 
+#include <type_traits>
+
+#define SE_K7_TSTRIDE 92   // per-k-lane row of the 7^3 tap-offset table (86 groups + pad, multiple of 4)
+
 int g_variant = 0;   // debug/bench switch (se_debug_set_variant): 1 = disable the persistent 64^3 kernel
 
 namespace {
@@ -384,6 +388,241 @@ int launch_k3_c32_persistent(const ConvArgs& a, int batch, hipStream_t s) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent 7x7x7 kernel (front conv of V2V: 33|65 -> 16 channels at 64^3, 32 % of all MACs).
+// One 512-thread workgroup per CU.  LDS: the packed weights of ONE 4-channel chunk (86 tap groups x 1 KiB),
+// TWO 10x14x14x4-channel halo tiles (double buffer, 31 KB each) and the 343-entry tap-offset table.
+// Loop order is chunk-outer / tile-inner, so a chunk's weights are loaded once per workgroup and stay put; the
+// price is that a tile's accumulators cannot live in registers across chunks: after every (tile, chunk) item
+// the 16-byte accumulator fragments are stored to the output tensor (used as scratch) and re-loaded as the
+// initial MFMA C operand when the same lane meets that tile again one chunk later — the summation order, and
+// therefore the result, is bit-identical to one long register-resident chain.  32 KB of read-modify-write per
+// 44k MFMA cycles is noise.  The next item's halo and partial sums are fetched into registers while the current
+// item computes; commit-to-LDS goes to the other buffer, so there is ONE barrier per item.
+// The last chunk of a 33/65-channel input holds 1 real channel: only MFMA j = 0 of each tap group is issued.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void conv3d_k7_persistent_kernel(ConvArgs a, int tiles_per_dim, int ztiles,
+                                                                   int total_tiles, int diag) {
+    constexpr int HZ = 10, HY = 14, HX = 14, HV = HZ * HY * HX;   // 1960 halo voxels, 16 B each
+    constexpr int W_FLOATS = SE_K7_GROUPS * 256;
+    constexpr int TILE_FLOATS = HV * 4;
+    constexpr int PF = (HV + 511) / 512;                           // 4 pieces per thread
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;
+    float* tiles = lds + W_FLOATS;                                 // 2 buffers
+    int* toff = reinterpret_cast<int*>(lds + W_FLOATS + 2 * TILE_FLOATS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int vl = lane & 15;
+    const int h = lane >> 4;
+    const int dim = a.dim;
+    const int chunks = (a.cin + 3) >> 2;
+    const int rem = a.cin & 3;                                     // real channels in the last chunk (0 = all 4)
+
+    for (int t = tid; t < 4 * SE_K7_TSTRIDE; t += 512) {          // table [h][g]: offset (floats) of tap 4g+h
+        const int hh = t / SE_K7_TSTRIDE, g = t - hh * SE_K7_TSTRIDE;
+        int tap = 4 * g + hh;
+        tap = tap < SE_K7_TAPS ? tap : 0;                          // pad taps: weights are zero
+        const int kz = tap / 49, r = tap - kz * 49, ky = r / 7, kx = r - ky * 7;
+        toff[t] = ((kz * HY + ky) * HX + kx) * 4;
+    }
+
+    int vbase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) vbase[m] = ((((wave >> 1) * HY) + (wave & 1) * 4 + m * 2 + (vl >> 3)) * HX + (vl & 7)) * 4;
+
+    // this workgroup's tiles: blockIdx.x, blockIdx.x + gridDim.x, ...
+    const int ntl = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (ntl <= 0) return;
+    const int n_items = chunks * ntl;
+    const bool keep_in_regs = ntl == 1;                            // same tile every item: no partial round trip
+
+    int p_hz[PF], p_hy[PF], p_hx[PF];
+    bool p_ok[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        const int hv = tid + k * 512;
+        p_ok[k] = hv < HV;
+        p_hx[k] = hv % HX;
+        const int t2 = hv / HX;
+        p_hy[k] = t2 % HY;
+        p_hz[k] = t2 / HY;
+    }
+
+    auto tile_coords = [&](int item, int& b, int& tz, int& ty, int& tx) {
+        int t = (int)blockIdx.x + (item % ntl) * (int)gridDim.x;
+        tx = t % tiles_per_dim; t /= tiles_per_dim;
+        ty = t % tiles_per_dim; t /= tiles_per_dim;
+        tz = t % ztiles; t /= ztiles;
+        b = t;
+    };
+    auto out_offset = [&](int item, int m) -> long long {
+        int b, tz, ty, tx;
+        tile_coords(item, b, tz, ty, tx);
+        const int oz = tz * 4 + (wave >> 1);
+        const int oy = ty * 8 + (wave & 1) * 4 + m * 2 + (vl >> 3);
+        const int ox = tx * 8 + (vl & 7);
+        return ((((long long)b * dim + oz) * dim + oy) * dim + ox) * 16 + 4 * h;
+    };
+
+    f32x4 pf[PF];
+    auto fetch = [&](int item) {
+        int b, tz, ty, tx;
+        tile_coords(item, b, tz, ty, tx);
+        const int ch = item / ntl;
+        const float* in_b = a.in + (size_t)b * dim * dim * dim * a.cin_pad + ch * 4;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int gz = tz * 4 - 3 + p_hz[k], gy = ty * 8 - 3 + p_hy[k], gx = tx * 8 - 3 + p_hx[k];
+            pf[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p_ok[k] && (unsigned)gz < (unsigned)dim && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim)
+                pf[k] = *reinterpret_cast<const f32x4*>(in_b + ((size_t)(gz * dim + gy) * dim + gx) * a.cin_pad);
+        }
+    };
+    auto commit = [&](int buf) {
+        float* tb = tiles + buf * TILE_FLOATS;
+#pragma unroll
+        for (int k = 0; k < PF; ++k)
+            if (p_ok[k]) *reinterpret_cast<f32x4*>(tb + (size_t)(tid + k * 512) * 4) = pf[k];
+    };
+    auto load_weights = [&](int ch) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack_b) + (size_t)ch * SE_K7_GROUPS * 64;
+        for (int i = tid; i < SE_K7_GROUPS * 64; i += 512) reinterpret_cast<f32x4*>(wl)[i] = src[i];
+    };
+
+    const bool relu = a.flags & SE_EPI_RELU;
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + 4 * h);
+    f32x4 acc[2], pn[2];
+    acc[0] = acc[1] = pn[0] = pn[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    commit(0);
+    load_weights(0);
+    __syncthreads();
+
+    for (int item = 0; item < n_items; ++item) {
+        const int ch = item / ntl;
+        const bool has_next = item + 1 < n_items;
+        const int ch_next = (item + 1) / ntl;
+        if (has_next) {
+            if (!(diag & 1)) fetch(item + 1);
+            if (ch_next > 0 && !keep_in_regs && !(diag & 2)) {
+                pn[0] = *reinterpret_cast<const f32x4*>(a.out + out_offset(item + 1, 0));
+                pn[1] = *reinterpret_cast<const f32x4*>(a.out + out_offset(item + 1, 1));
+            }
+        }
+
+        const float* tb = tiles + (item & 1) * TILE_FLOATS;
+        const int nj = (ch == chunks - 1 && rem != 0) ? rem : 4;   // uniform
+        const f32x4* wrow = reinterpret_cast<const f32x4*>(wl) + lane;
+        // Per-lane LDS offsets of tap 4g+h come from a table stored [h][g], so ONE ds_read_b128 yields the offsets of 4
+        // consecutive groups; it is fetched one 4-group block ahead, and the operands of group g+1 are read BEFORE
+        // the MFMAs of group g (ping-pong register sets A/B), so no LDS latency sits in front of an MFMA.
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4* otab = reinterpret_cast<const i32x4*>(toff + h * SE_K7_TSTRIDE);
+#define SE_K7_LOAD(X0, X1, W, OFF, G)                                                   \
+    X0 = *reinterpret_cast<const f32x4*>(tb + vbase[0] + (OFF));                        \
+    X1 = *reinterpret_cast<const f32x4*>(tb + vbase[1] + (OFF));                        \
+    W = wrow[(G) * 64];
+#define SE_K7_MFMA(X0, X1, W, NJ)                                                       \
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.x, X0.x, acc[0], 0, 0, 0);          \
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.x, X1.x, acc[1], 0, 0, 0);          \
+    if (NJ > 1) {                                                                       \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.y, X0.y, acc[0], 0, 0, 0);      \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.y, X1.y, acc[1], 0, 0, 0);      \
+    }                                                                                   \
+    if (NJ > 2) {                                                                       \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.z, X0.z, acc[0], 0, 0, 0);      \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.z, X1.z, acc[1], 0, 0, 0);      \
+    }                                                                                   \
+    if (NJ > 3) {                                                                       \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w, X0.w, acc[0], 0, 0, 0);      \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w, X1.w, acc[1], 0, 0, 0);      \
+    }
+#define SE_K7_SCHED(NJ)                                         \
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);          \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * (NJ), 0);
+        f32x4 xa0, xa1, wa, xb0, xb1, wb;
+        i32x4 o = otab[0];
+        SE_K7_LOAD(xa0, xa1, wa, o.x, 0)
+        auto body = [&](auto nj_tag) {
+            constexpr int NJ = decltype(nj_tag)::value;
+            for (int g4 = 0; g4 < SE_K7_GROUPS / 4; ++g4) {     // 21 blocks of 4 groups; groups 84, 85 below
+                const int g = 4 * g4;
+                const i32x4 on = otab[g4 + 1];
+                SE_K7_LOAD(xb0, xb1, wb, o.y, g + 1)
+                SE_K7_MFMA(xa0, xa1, wa, NJ)
+                SE_K7_SCHED(NJ)
+                SE_K7_LOAD(xa0, xa1, wa, o.z, g + 2)
+                SE_K7_MFMA(xb0, xb1, wb, NJ)
+                SE_K7_SCHED(NJ)
+                SE_K7_LOAD(xb0, xb1, wb, o.w, g + 3)
+                SE_K7_MFMA(xa0, xa1, wa, NJ)
+                SE_K7_SCHED(NJ)
+                SE_K7_LOAD(xa0, xa1, wa, on.x, g + 4)
+                SE_K7_MFMA(xb0, xb1, wb, NJ)
+                SE_K7_SCHED(NJ)
+                o = on;
+            }
+            SE_K7_LOAD(xb0, xb1, wb, o.y, SE_K7_GROUPS - 1)
+            SE_K7_MFMA(xa0, xa1, wa, NJ)
+            SE_K7_MFMA(xb0, xb1, wb, NJ)
+        };
+        if (nj == 4) body(std::integral_constant<int, 4>{});
+        else if (nj == 1) body(std::integral_constant<int, 1>{});      // 33 / 65 input channels: the occupancy chunk
+        else if (nj == 2) body(std::integral_constant<int, 2>{});
+        else body(std::integral_constant<int, 3>{});
+#undef SE_K7_LOAD
+#undef SE_K7_MFMA
+#undef SE_K7_SCHED
+
+        // item boundary: commit the prefetched halo first (its vmcnt wait must not cover this item's stores)
+        if (has_next && !(diag & 1)) commit((item + 1) & 1);
+        if (diag & 2) {
+        } else if (ch == chunks - 1) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x4 v = acc[m] + bias;
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<f32x4*>(a.out + out_offset(item, m)) = v;
+            }
+        } else if (!keep_in_regs) {
+            *reinterpret_cast<f32x4*>(a.out + out_offset(item, 0)) = acc[0];
+            *reinterpret_cast<f32x4*>(a.out + out_offset(item, 1)) = acc[1];
+        }
+        if (!has_next) break;
+        if (!keep_in_regs) {
+            if (ch_next > 0) { acc[0] = pn[0]; acc[1] = pn[1]; }
+            else acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (!(diag & 4)) __syncthreads();   // all waves: done reading this tile buffer and the weights; next buffer is complete
+        if (ch_next != ch) {
+            load_weights(ch_next);
+            __syncthreads();
+        }
+    }
+}
+
+int launch_k7_persistent(const ConvArgs& a, int batch, hipStream_t s) {
+    constexpr int LDS_BYTES = (SE_K7_GROUPS * 256 + 2 * 1960 * 4) * 4 + 4 * SE_K7_TSTRIDE * 4;
+    const int tiles = a.dim / 8, ztiles = a.dim / 4;
+    const int total_tiles = batch * ztiles * tiles * tiles;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k7_persistent_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int grid = total_tiles < g_num_cus ? total_tiles : g_num_cus;
+    hipLaunchKernelGGL(conv3d_k7_persistent_kernel, dim3(grid), dim3(512), LDS_BYTES, s, a, tiles, ztiles, total_tiles,
+                       g_variant >= 10 ? g_variant - 10 : 0);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int KS, int CK, int TZ, int N_T>
 int launch_tiled(const ConvArgs& a, int batch, hipStream_t s) {
     using G = TileGeom<KS, CK, TZ>;
@@ -425,7 +664,13 @@ int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) 
         if (nts % 2 == 0) return launch_tiled<3, 16, 4, 2>(a, batch, s);
         return launch_tiled<3, 16, 4, 1>(a, batch, s);
     }
-    if (ksize == 7 && nts == 1) return launch_tiled<7, 4, 4, 1>(a, batch, s);
+    if (ksize == 7 && nts == 1) {
+        if (g_variant != 1 && dim >= 32 && a.cout == 16 && !a.res && !(a.flags & SE_EPI_OUT_PLANAR)) {
+            ensure_device_info();
+            return launch_k7_persistent(a, batch, s);
+        }
+        return launch_tiled<7, 4, 4, 1>(a, batch, s);
+    }
     return SE_TILED_NOT_TAKEN;
 }
 

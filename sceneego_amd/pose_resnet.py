@@ -10,8 +10,9 @@ the code that builds and runs it is this build's own:
     ``final_layer`` (1x1, 256->16) is only evaluated when ``compute_heatmaps=True`` — the voxel path
     discards the heatmaps (``network/voxel_net_depth.py:235``);
   * ``FoldedBackbone`` is the inference executor used on the GPU: every BatchNorm is folded into the
-    preceding convolution once, tensors run channels-last so MIOpen picks its NHWC MFMA kernels, and
-    the residual add + ReLU are the only element-wise launches left.  The dense 2D convolutions are
+    preceding convolution once and the residual add + ReLU are the only element-wise launches left.
+    Layout is NCHW: on MI355X / MIOpen (ROCm 7.2) the fp32 NCHW kernels measured 2.7 ms per B=8 forward
+    against 3.9 ms channels-last (profiles/r01_backbone_variants.txt).  The dense 2D convolutions are
     the one place the north-star assigns to MIOpen rather than to hand-written HIP.
 """
 from __future__ import annotations
@@ -138,18 +139,19 @@ def _fold(conv_w, bn, transposed=False):
         w = conv_w * scale.view(1, -1, 1, 1)
     else:
         w = conv_w * scale.view(-1, 1, 1, 1)
-    return w.detach().contiguous(memory_format=torch.channels_last), shift.detach().contiguous()
+    return w.detach().contiguous(), shift.detach().contiguous()
 
 
 class FoldedBackbone:
-    """Folded copy of a ``PoseResNet`` in eval mode; ``__call__(images) -> features [B,256,64,64]`` (NHWC strides).
+    """Folded copy of a ``PoseResNet`` in eval mode; ``__call__(images) -> features [B,256,64,64]``.
 
     ``dtype`` torch.float32 (parity path) or torch.bfloat16 (BASELINE config 3).
     """
 
-    def __init__(self, net: PoseResNet, dtype=torch.float32):
+    def __init__(self, net: PoseResNet, dtype=torch.float32, channels_last: bool = False):
         self.dtype = dtype
-        cvt = lambda wb: (wb[0].to(dtype).contiguous(memory_format=torch.channels_last), wb[1].to(dtype))
+        self.memory_format = torch.channels_last if channels_last else torch.contiguous_format
+        cvt = lambda wb: (wb[0].to(dtype).contiguous(memory_format=self.memory_format), wb[1].to(dtype))
         self.stem = cvt(_fold(net.conv1.weight, net.bn1))
         self.blocks = []
         for si in range(1, 5):
@@ -166,7 +168,7 @@ class FoldedBackbone:
 
     @torch.no_grad()
     def __call__(self, images):
-        x = images.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        x = images.to(self.dtype).contiguous(memory_format=self.memory_format)
         x = F.relu_(F.conv2d(x, self.stem[0], self.stem[1], stride=2, padding=3))
         x = F.max_pool2d(x, 3, stride=2, padding=1)
         for c1, c2, c3, stride, ds in self.blocks:

@@ -138,7 +138,7 @@ class VoxelNetwork_depth(nn.Module):
                                          "there is no CPU fallback" % dev)
         fb = pose_resnet.FoldedBackbone(self.backbone, dtype=dtype)
         pf = self.process_features[0]
-        w = pf.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last)
+        w = pf.weight.detach().to(dtype).contiguous()
         b = pf.bias.detach().to(dtype)
         self._folded = (fb, w, b)
         self.volume_net.compile()
@@ -187,7 +187,7 @@ class VoxelNetwork_depth(nn.Module):
         fb, pw, pb = self._folded
 
         # 2D: backbone (MIOpen) + 1x1 channel reduction, channels-last
-        feat2d = torch.nn.functional.conv2d(fb(images), pw, pb)                  # [B,32,64,64], NHWC strides
+        feat2d = torch.nn.functional.conv2d(fb(images), pw, pb)                  # [B,32,64,64]
         feat_nhwc = feat2d.permute(0, 2, 3, 1)
         if feat_nhwc.dtype != torch.float32 or not feat_nhwc.is_contiguous():
             feat_nhwc = feat_nhwc.float().contiguous()
