@@ -83,6 +83,19 @@ def effective_cores():
     return n
 
 
+def pmc_traffic(batch, G):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (None if not measured for
+    this shape).  PMC counters cannot be read from inside this process; the passes are tools/pmc_round.sh."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+            d = json.load(f)
+        if d.get("batch") == batch and d.get("volume_size") == G:
+            return d["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(sd, volume_size):
     from oracle import sceneego_oracle as O
     from sceneego_amd import synth
@@ -166,8 +179,9 @@ def main():
         stage_tflops = V2V_GFLOP_PER_FRAME.get(G, 0) * args.batch / (conv_ms_per_step * 1e-3) / 1e3 if conv_ms_per_step else None
         line["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": f"conv3d 3x3x3 32->32 @{G}^3 f32 (v_mfma_f32_16x16x4_f32), {len(ms) // args.steps} launches/step",
+            "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(args.batch, G),
+            "kernel": f"conv3d 3x3x3 32->32 @{G}^3 f32 (conv3d_k3_c32_persistent_kernel, v_mfma_f32_16x16x4_f32), "
+                      f"{len(ms) // args.steps} launches/step",
             "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": flop,
             "stage": {"v2v_conv_ms_per_step": round(conv_ms_per_step, 3),
                       "v2v_tflops": round(stage_tflops, 2) if stage_tflops else None,
