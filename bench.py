@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--depth-kind", default="uniform", choices=["uniform", "floor"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--graphs", action="store_true", help="replay the forward as a captured hipGraph (implies --no-kernel-events)")
     return ap.parse_args()
 
 
@@ -128,6 +129,9 @@ def main():
     net, sd = build_network(args.volume_size, device)
     img, depth = device_inputs(args.batch, rank, device, args.depth_kind)
     G = args.volume_size
+    if args.graphs:
+        args.no_kernel_events = True
+        net.enable_graphs(True)
 
     def step():
         kp = net(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth)[0]
@@ -165,7 +169,8 @@ def main():
         "config": {"workload": f"batch={args.batch}/GPU synthetic 256x256 image N(0,1) + {args.depth_kind} depth 1024x1280, "
                                f"{G}^3 grid, 15 joints, fp32 (BASELINE configs[1])",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "volume_size": G,
-                   "parallelism": f"dp{world}" + (" + RCCL all_gather of [B,15,3] joints" if world > 1 else "")},
+                   "parallelism": f"dp{world}" + (" + RCCL all_gather of [B,15,3] joints" if world > 1 else ""),
+                   "hipgraph": bool(args.graphs)},
     }
     # ---- roofline of the dominant kernel, from the HIP events of the timed region ----------------
     key = ("conv3d", 3, 32, 32, G)

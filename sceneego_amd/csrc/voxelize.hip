@@ -55,6 +55,21 @@ __global__ __launch_bounds__(256) void voxelize_kernel(const float* __restrict__
     se_splat(r[0] * d, r[1] * d, r[2] * d, occ_b, G, half_side, dG, side);
 }
 
+// Clears the occupancy grid.  A kernel rather than hipMemsetAsync: on ROCm 7.2 a memset node captured into a
+// hipGraph from this call replayed with garbage (1e10) in the grid from the second replay on (tools/debug_graph2.py).
+__global__ __launch_bounds__(256) void zero_kernel(f32x4* __restrict__ p, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+int clear_occupancy(float* occ, size_t elems, hipStream_t s) {
+    if (elems & 3) return SE_ERR_BAD_ARG;   // G^3 with even G is a multiple of 8
+    const size_t n4 = elems / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<f32x4*>(occ), n4);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int se_voxelize_f64(const float* depth, const double* ray_tab, float* occ, int batch, int depth_h,
@@ -62,9 +77,8 @@ extern "C" int se_voxelize_f64(const float* depth, const double* ray_tab, float*
                                void* stream) {
     if (batch <= 0 || depth_h <= 0 || depth_w <= 0 || up <= 0 || volume_size <= 0 || pad_x < 0) return SE_ERR_BAD_ARG;
     hipStream_t s = se_stream(stream);
-    const size_t occ_bytes = (size_t)batch * volume_size * volume_size * volume_size * sizeof(float);
-    hipError_t e = hipMemsetAsync(occ, 0, occ_bytes, s);
-    if (e != hipSuccess) return (int)e;
+    const int rc = clear_occupancy(occ, (size_t)batch * volume_size * volume_size * volume_size, s);
+    if (rc != 0) return rc;
     dim3 grid((up * up + 255) / 256, batch);
     hipLaunchKernelGGL(voxelize_kernel, grid, dim3(256), 0, s, depth, ray_tab, occ, depth_h, depth_w, up, up,
                        pad_x > 0 ? 1 : 0, volume_size, cuboid_side);
@@ -77,9 +91,8 @@ extern "C" int se_voxelize_full_f64(const float* depth, const double* ray_tab, f
                                     void* stream) {
     if (batch <= 0 || depth_h <= 0 || depth_w <= 0 || volume_size <= 0) return SE_ERR_BAD_ARG;
     hipStream_t s = se_stream(stream);
-    const size_t occ_bytes = (size_t)batch * volume_size * volume_size * volume_size * sizeof(float);
-    hipError_t e = hipMemsetAsync(occ, 0, occ_bytes, s);
-    if (e != hipSuccess) return (int)e;
+    const int rc = clear_occupancy(occ, (size_t)batch * volume_size * volume_size * volume_size, s);
+    if (rc != 0) return rc;
     dim3 grid((depth_h * depth_w + 255) / 256, batch);
     // no resize (up == depth size => sy = y, sx = x) and no padding
     hipLaunchKernelGGL(voxelize_kernel, grid, dim3(256), 0, s, depth, ray_tab, occ, depth_h, depth_w, depth_h,

@@ -108,10 +108,13 @@ class VoxelNetwork_depth(nn.Module):
         self._tables_for = None
         self._gather_idx = self._gather_w = self._ray_tab = self._coord_flat = None
         self._folded = None
+        self.use_graphs = False
+        self._graphs = {}
 
     # ------------------------------------------------------------------------------------------
     def _invalidate(self):
         self._folded = None
+        self._graphs = {}
 
     def _load_from_state_dict(self, *a, **k):
         super()._load_from_state_dict(*a, **k)
@@ -170,6 +173,38 @@ class VoxelNetwork_depth(nn.Module):
                       self.cuboid_side)
         return occ
 
+    # ------------------------------------------------------------------------------------------
+    # hipGraph replay: at small batch the forward is ~250 short launches and the host (eager dispatch of the MIOpen
+    # backbone + ctypes calls) is slower than the GPU; capturing the whole forward once per (batch, depth shape) and
+    # replaying it removes that.  Inputs are copied into static buffers, outputs are static tensors that the next
+    # call overwrites (callers such as demo.py consume them immediately).
+    # ------------------------------------------------------------------------------------------
+    def enable_graphs(self, flag: bool = True):
+        self.use_graphs = flag
+        if not flag:
+            self._graphs = {}
+        return self
+
+    def _graph_for(self, images, depth, grid_coord_proj_batch, coord_volumes):
+        key = (tuple(images.shape), tuple(depth.shape), grid_coord_proj_batch.data_ptr(), coord_volumes.data_ptr())
+        ent = self._graphs.get(key)
+        if ent is not None:
+            return ent
+        s_img = torch.empty_like(images).copy_(images)
+        s_depth = torch.empty_like(depth).copy_(depth)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up off the capture: lazy compile(), MIOpen find, hipFuncSetAttribute
+            for _ in range(2):
+                self._forward_impl(s_img, grid_coord_proj_batch, coord_volumes, None, s_depth)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self._forward_impl(s_img, grid_coord_proj_batch, coord_volumes, None, s_depth)
+        ent = (graph, s_img, s_depth, out)
+        self._graphs[key] = ent
+        return ent
+
     @torch.no_grad()
     def forward(self, images, grid_coord_proj_batch, coord_volumes, scene_volumes=None, depth_map_batch=None):
         """See the module docstring; reference ``network/voxel_net_depth.py:224-275``."""
@@ -177,6 +212,18 @@ class VoxelNetwork_depth(nn.Module):
         if self.with_scene is True and scene_volumes is None and depth_map_batch is None:
             print("no scene volume or depth input!")
             return None
+        if getattr(self, "use_graphs", False) and depth_map_batch is not None and scene_volumes is None \
+                and _lib._prof is None and images.dtype == torch.float32 and depth_map_batch.dtype == torch.float32:
+            graph, s_img, s_depth, out = self._graph_for(images.contiguous(), depth_map_batch.contiguous(),
+                                                         grid_coord_proj_batch, coord_volumes)
+            s_img.copy_(images)
+            s_depth.copy_(depth_map_batch)
+            graph.replay()
+            return out
+        return self._forward_impl(images, grid_coord_proj_batch, coord_volumes, scene_volumes, depth_map_batch)
+
+    @torch.no_grad()
+    def _forward_impl(self, images, grid_coord_proj_batch, coord_volumes, scene_volumes=None, depth_map_batch=None):
         if self._folded is None:
             self.compile()
         dev = images.device

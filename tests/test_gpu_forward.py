@@ -130,3 +130,20 @@ def test_batch_larger_than_opt_batch_size(net64):
     kp = _forward(net64, img, depth)[0]
     assert tuple(kp.shape) == (42, 15, 3)
     assert float((kp[0] - kp[40]).abs().max()) < 1e-5
+
+
+def test_hipgraph_replay_matches_eager(net64):
+    """Captured-graph replay (small-batch latency path) returns the same joints as the eager launch sequence."""
+    img, depth = synth.make_inputs(91, 2, "floor")
+    kp_eager = _forward(net64, img, depth)[0].clone()
+    net64.enable_graphs(True)
+    try:
+        kp_g1 = _forward(net64, img, depth)[0].clone()
+        img2, depth2 = synth.make_inputs(92, 2, "uniform")
+        kp_other = _forward(net64, img2, depth2)[0].clone()
+        kp_g2 = _forward(net64, img, depth)[0].clone()
+    finally:
+        net64.enable_graphs(False)
+    assert float((kp_g1 - kp_eager).abs().max()) < 5e-5
+    assert float((kp_g2 - kp_g1).abs().max()) < 5e-5
+    assert float((kp_other - kp_g1).abs().max()) > 1e-3     # the replay really consumed the new inputs
