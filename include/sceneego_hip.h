@@ -121,6 +121,8 @@ long long se_softargmax3d_scratch_elems(int rows);
 
 /* Debug / benchmarking only: selects alternative kernel variants for A/B timing (0 = production dispatch). */
 void se_debug_set_variant(int variant);
+/* Debug only: u64 device buffer [workgroups][8 waves][4]; non-NULL switches the Winograd conv to its cycle-stamp build. */
+void se_debug_set_stamp_buffer(void* device_buffer);
 
 #ifdef __cplusplus
 }

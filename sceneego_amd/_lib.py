@@ -37,6 +37,7 @@ SIGNATURES = {
     "se_softargmax3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "se_softargmax3d_scratch_elems": (_ll, [_i]),
     "se_debug_set_variant": (None, [_i]),
+    "se_debug_set_stamp_buffer": (None, [_vp]),
 }
 
 _lib = None

@@ -55,6 +55,27 @@ __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict
         nt = (int)(r % nts); r /= nts;
         tap = (int)(r % taps); r /= taps;
         ci = (int)r * 16 + 4 * (lane >> 4) + j;
+    } else if (taps == 27) {
+        // section C: 1-D Winograd F(2,3) along z.  U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2 of the
+        // three z taps (g0: dz=-1) for every (dy,dx); blocks [cg][cb][tap2d][xi][nt2][lane][j], cb = 32-cout block
+        long long r = (t - total_a) >> 8;
+        const int nt2 = (int)(r % 2); r /= 2;
+        const int xi = (int)(r % 4); r /= 4;
+        const int tap2d = (int)(r % 9); r /= 9;
+        const int n_cb = nts / 2;
+        const int cb = (int)(r % n_cb); r /= n_cb;
+        const int co = cb * 32 + nt2 * 16 + (lane & 15);
+        const int cc = (int)r * 16 + 4 * (lane >> 4) + j;
+        float v = 0.f;
+        if (co < cout && cc < cin) {
+            const float sc = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
+            const float* wp = w + ((size_t)co * cin + cc) * 27 + tap2d;
+            const float g0 = wp[0], g1 = wp[9], g2 = wp[18];
+            const float u = xi == 0 ? g0 : xi == 1 ? (g0 + g1 + g2) * 0.5f : xi == 2 ? (g0 - g1 + g2) * 0.5f : g2;
+            v = u * sc;
+        }
+        wpack[t] = v;
+        return;
     } else {
         long long r = (t - total_a) >> 8;
         nt = (int)(r % nts); r /= nts;
@@ -285,6 +306,7 @@ static long long packed_elems_a(int cout, int cin_pad, int ksize, int transposed
 extern "C" long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, int transposed) {
     long long n = packed_elems_a(cout, cin_pad, ksize, transposed);
     if (!transposed && ksize == 7) n += (long long)(cin_pad / 4) * SE_K7_GROUPS * (round_up16(cout) / 16) * 256;
+    if (!transposed && ksize == 3 && cout % 32 == 0) n += (long long)(cin_pad / 16) * (cout / 32) * SE_WINO_CHUNK_FLOATS;
     return n;
 }
 
@@ -324,6 +346,8 @@ extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* b
     a.total_vox = (long long)batch * dim * dim * dim;
     a.dim = dim; a.cin = cin; a.cin_pad = cin_pad; a.cout = cout; a.nts = round_up16(cout) / 16; a.flags = flags;
     a.wpack_b = wpack + packed_elems_a(cout, cin_pad, ksize, 0);
+    if (ksize == 3 && (cout % 32)) a.wpack_b = nullptr;
+    if (ksize == 1) a.wpack_b = nullptr;
     const int took = se_conv3d_tiled_try(a, batch, ksize, s);
     if (took != SE_TILED_NOT_TAKEN) return took;
     // small volumes with wide channels: split the taps over grid.z when the plain launch would not fill the chip

@@ -647,13 +647,19 @@ int launch_tiled(const ConvArgs& a, int batch, hipStream_t s) {
 
 // Returns 0 if a tiled kernel took the launch, SE_TILED_NOT_TAKEN if the shape is left to the direct kernel,
 // otherwise the hipError_t of the failed launch.
+int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s);   // conv3d_wino.hip
+
 int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) {
     const int dim = a.dim;
+    if (ksize == 3 && (g_variant == 0 || g_variant >= 10)) {   // production: 1-D Winograd persistent kernel
+        const int rc = se_conv3d_wino_try(a, batch, s);
+        if (rc != SE_TILED_NOT_TAKEN) return rc;
+    }
     if (dim < 16 || (dim & 7)) return SE_TILED_NOT_TAKEN;   // small / odd volumes: direct kernel
     if (a.cout & 15) return SE_TILED_NOT_TAKEN;               // planar 15-channel output layer: direct kernel
     const int nts = a.nts;
     if (ksize == 3) {
-        if (g_variant != 1 && a.cout == 32 && dim >= 32 && (a.cin == 16 || a.cin == 32) && a.cin_pad == a.cin &&
+        if (g_variant != 1 && g_variant != 3 && a.cout == 32 && dim >= 32 && (a.cin == 16 || a.cin == 32) && a.cin_pad == a.cin &&
             !(a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR))) {
             ensure_device_info();
             if (g_variant == 2)

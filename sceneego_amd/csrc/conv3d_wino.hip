@@ -1,0 +1,368 @@
+// 3x3x3 convolution with a 1-D Winograd F(2,3) transform along z, on the f32 MFMA — the V2V workhorse.
+//
+// For two output voxels that are neighbours in z, (y0, y1), and the four inputs d0..d3 on that z line,
+//     m0 = (d0 - d2) g0      m1 = (d1 + d2)(g0+g1+g2)/2      m2 = (d2 - d1)(g0-g1+g2)/2      m3 = (d1 - d3) g2
+//     y0 = m0 + m1 + m2      y1 = m1 - m2 - m3
+// i.e. 4 multiplies instead of 6 per (dy, dx, cin, cout): the MFMA work of a 3x3x3 layer drops by 1.5x.  All of
+// it is linear, so the four M_xi = sum over (dy, dx, cin) of U_xi * V_xi are accumulated by the matrix cores
+// (U_xi: transformed weights, packed by se_conv3d_pack_f32 section C; V_xi: 3 packed adds per lane on the four
+// 16-byte activation fragments it has just read from LDS) and only the epilogue forms y0 / y1.
+// The LDS traffic per MFMA is the same as for the direct form (one ds_read_b128 per 4 MFMAs per operand), the
+// halo tile is the same 6 x 10 x 10, and no transformed tensor is ever materialised.
+//
+// Structure (as conv3d_k7_persistent_kernel): one persistent 512-thread workgroup per CU; a work unit is
+// (32-cout block, 4x8x8 output tile); loop order cout block -> 16-channel chunk -> unit, so the 72 KB of
+// transformed weights of a (block, chunk) are loaded once and the halo tiles are double buffered (one barrier per
+// item).  For cin > 16 the per-chunk results are summed through the output tensor (read y-partial, add, write),
+// prefetched one item ahead; residual add + ReLU happen on the last chunk.
+// Wave w of 8: z pair w>>2 (outputs z = 2*zp, 2*zp+1 of the tile), rows 2*(w&3), 2*(w&3)+1 -> one 16-position tile,
+// 4 xi x 2 cout tiles = 8 accumulators.
+#include "conv_common.h"
+
+#include <type_traits>
+#include <utility>
+
+extern int g_variant;
+
+namespace {
+
+constexpr int HZ = 6, HY = 10, HX = 10, HV = HZ * HY * HX;   // halo voxels of a 4x8x8 tile
+constexpr int TILE_FLOATS = HV * 16;                          // one 16-channel chunk
+constexpr int PF = (HV * 4 + 511) / 512;                      // 16-byte pieces per thread (5)
+
+template <typename F, int... S>
+__device__ __forceinline__ void for_each_index(F&& f, std::integer_sequence<int, S...>) {
+    (f(std::integral_constant<int, S>{}), ...);
+}
+
+struct WinoIter {   // uniform walk over this workgroup's items: runs of units with equal cout block, chunk-outer
+    int u_lo, n, cb, c, k;
+    bool valid;
+};
+
+template <bool STAMP>
+__global__ __launch_bounds__(512) void conv3d_k3_wino_kernel(ConvArgs a, int tiles_per_dim, int ztiles, int total_tiles,
+                                                             int n_cb, int units_per_wg, int diag,
+                                                             unsigned long long* __restrict__ dbg) {
+    // STAMP build only (diagnostics, never the production launch): per-wave cycle totals of the four phases of an item
+    unsigned long long t_setup = 0, t_mfma = 0, t_tail = 0, t_bar = 0, t_prev = 0;
+    auto stamp = [&](unsigned long long& acc_t) {
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long now;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            acc_t += now - t_prev;
+            t_prev = now;
+        }
+    };
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;                              // SE_WINO_CHUNK_FLOATS
+    float* tiles = lds + SE_WINO_CHUNK_FLOATS;    // 2 x TILE_FLOATS
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int vl = lane & 15;
+    const int h = lane >> 4;
+    const int dim = a.dim;
+    const int chunks = a.cin >> 4;
+    const int n_units = n_cb * total_tiles;
+    const int u_begin = (int)blockIdx.x * units_per_wg;
+    const int u_end = min(u_begin + units_per_wg, n_units);
+    if (u_begin >= u_end) return;
+
+    // lane's position inside the tile: z pair zp, row ry, column rx (halo coordinates are +1)
+    const int zp = wave >> 2;
+    const int ry = (wave & 3) * 2 + (vl >> 3);
+    const int rx = vl & 7;
+    const int vbase = ((2 * zp) * HY + ry) * HX + rx;          // halo voxel of d0 for (dy,dx) = (0,0)
+
+    int p_hz[PF], p_hy[PF], p_hx[PF], p_q[PF];
+    bool p_ok[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        const int it = tid + k * 512;
+        const int hv = it >> 2;
+        p_ok[k] = it < HV * 4;
+        p_q[k] = it & 3;
+        p_hx[k] = hv % HX;
+        const int t2 = hv / HX;
+        p_hy[k] = t2 % HY;
+        p_hz[k] = t2 / HY;
+    }
+
+    // (b, tz, ty, tx) of this workgroup's units, decoded ONCE into LDS: the 7 runtime integer divisions per lookup
+    // otherwise sit at the head of every item, where both waves of a SIMD execute them at the same time and the
+    // matrix pipe idles (measured: 20 % of the pure-compute loop).
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4* utab = reinterpret_cast<i32x4*>(lds + SE_WINO_CHUNK_FLOATS + 2 * TILE_FLOATS);
+    for (int i = tid; i < u_end - u_begin; i += 512) {
+        int t = (u_begin + i) % total_tiles;
+        i32x4 e;
+        e.w = t % tiles_per_dim; t /= tiles_per_dim;
+        e.z = t % tiles_per_dim; t /= tiles_per_dim;
+        e.y = t % ztiles; t /= ztiles;
+        e.x = t;
+        utab[i] = e;
+    }
+    __syncthreads();
+    auto unit_coords = [&](int u, int& b, int& tz, int& ty, int& tx) {
+        const i32x4 e = utab[u - u_begin];
+        b = e.x; tz = e.y; ty = e.z; tx = e.w;
+    };
+    // output offset of this lane's voxel (z = 2*zp of the pair) for cout tile 0 of block cb
+    auto out_offset = [&](int u, int cb) -> long long {
+        int b, tz, ty, tx;
+        unit_coords(u, b, tz, ty, tx);
+        const int oz = tz * 4 + 2 * zp, oy = ty * 8 + ry, ox = tx * 8 + rx;
+        return ((((long long)b * dim + oz) * dim + oy) * dim + ox) * a.cout + cb * 32 + 4 * h;
+    };
+    const long long zstride = (long long)dim * dim * a.cout;   // +1 in z
+
+    f32x4 pf[PF];
+    // Branch-free halo fetch (so it can be scheduled INSIDE the MFMA block of the current item): out-of-volume pieces
+    // load from offset 0 and are zeroed by a select afterwards.
+    int p_rel[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) p_rel[k] = ((p_hz[k] * dim + p_hy[k]) * dim + p_hx[k]) * a.cin_pad + p_q[k] * 4;
+    auto fetch = [&](int u, int c) {
+        int b, tz, ty, tx;
+        unit_coords(u, b, tz, ty, tx);
+        const int z0 = tz * 4 - 1, y0 = ty * 8 - 1, x0 = tx * 8 - 1;
+        const long long base = ((((long long)b * dim + z0) * dim + y0) * dim + x0) * a.cin_pad + c * 16;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const bool ok = p_ok[k] && (unsigned)(z0 + p_hz[k]) < (unsigned)dim && (unsigned)(y0 + p_hy[k]) < (unsigned)dim &&
+                            (unsigned)(x0 + p_hx[k]) < (unsigned)dim;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(a.in + (ok ? base + p_rel[k] : 0));
+            pf[k] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&](int buf) {
+        float* tb = tiles + buf * TILE_FLOATS;
+#pragma unroll
+        for (int k = 0; k < PF; ++k)
+            if (p_ok[k]) *reinterpret_cast<f32x4*>(tb + (size_t)(tid + k * 512) * 4) = pf[k];
+    };
+    auto load_weights = [&](int cb, int c) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack_b) + ((size_t)c * n_cb + cb) * (SE_WINO_CHUNK_FLOATS / 4);
+        for (int i = tid; i < SE_WINO_CHUNK_FLOATS / 4; i += 512) reinterpret_cast<f32x4*>(wl)[i] = src[i];
+    };
+    auto first_item = [&]() {
+        WinoIter it;
+        it.u_lo = u_begin;
+        it.cb = u_begin / total_tiles;
+        it.n = min(u_end, (it.cb + 1) * total_tiles) - u_begin;
+        it.c = 0; it.k = 0; it.valid = true;
+        return it;
+    };
+    auto next_item = [&](WinoIter it) {
+        if (++it.k == it.n) {
+            it.k = 0;
+            if (++it.c == chunks) {
+                it.c = 0;
+                it.u_lo += it.n;
+                if (it.u_lo >= u_end) { it.valid = false; return it; }
+                it.cb = it.u_lo / total_tiles;
+                it.n = min(u_end, (it.cb + 1) * total_tiles) - it.u_lo;
+            }
+        }
+        return it;
+    };
+
+    const bool relu = a.flags & SE_EPI_RELU;
+    const bool use_res = (a.flags & SE_EPI_RES_PRE_RELU) && a.res;
+
+    WinoIter cur = first_item();
+    fetch(cur.u_lo, 0);
+    commit(0);
+    load_weights(cur.cb, 0);
+    __syncthreads();
+
+    f32x4 part[2][2];   // [z of the pair][cout tile]: y-domain partial sums of the previous chunks (prefetched)
+    f32x4 resv[2][2];
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) part[z][n] = resv[z][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int buf = 0;
+    if constexpr (STAMP) { unsigned long long dummy = 0; stamp(dummy); }
+    while (true) {
+        const WinoIter nxt = next_item(cur);
+        const int u = cur.u_lo + cur.k;
+        const bool last_chunk = cur.c == chunks - 1;
+        // a run of one unit revisits the same tile in the very next item: its partial cannot be prefetched
+        const bool lone = cur.n == 1;
+        const int fetch_u = nxt.valid ? nxt.u_lo + nxt.k : u;      // (re-fetching the current item at the very end is harmless)
+        const int fetch_c = nxt.valid ? nxt.c : cur.c;
+        const long long o0 = out_offset(u, cur.cb);
+        if (cur.c > 0 && !lone && !(diag & 2)) {
+#pragma unroll
+            for (int z = 0; z < 2; ++z)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) part[z][n] = *reinterpret_cast<const f32x4*>(a.out + o0 + z * zstride + n * 16);
+        }
+        if (last_chunk && use_res) {
+#pragma unroll
+            for (int z = 0; z < 2; ++z)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) resv[z][n] = *reinterpret_cast<const f32x4*>(a.res + o0 + z * zstride + n * 16);
+        }
+
+        // ---- MFMA over the 9 (dy,dx) taps of this 16-channel chunk ----
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[x][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* tb = tiles + buf * TILE_FLOATS + vbase * 16 + 4 * h;
+        const f32x4* wrow = reinterpret_cast<const f32x4*>(wl) + lane;
+        // Software pipeline over the 36 sub-steps (tap, xi): the two weight fragments of sub-step s+1, and in the first
+        // sub-step of a tap the four activation fragments of the NEXT tap, are read before the 8 MFMAs of sub-step s;
+        // left to itself hipcc issues every ds_read directly in front of its first use (one exposed LDS round trip
+        // per 4 MFMAs: measured 78 % MFMA rate in this loop).
+#define SE_WINO_DLOAD(D, T2)                                                                      \
+    {                                                                                             \
+        const int off_ = (((T2) / 3) * HX + ((T2) % 3)) * 16;                                     \
+        D[0] = *reinterpret_cast<const f32x4*>(tb + off_);                                        \
+        D[1] = *reinterpret_cast<const f32x4*>(tb + off_ + 1 * HY * HX * 16);                     \
+        D[2] = *reinterpret_cast<const f32x4*>(tb + off_ + 2 * HY * HX * 16);                     \
+        D[3] = *reinterpret_cast<const f32x4*>(tb + off_ + 3 * HY * HX * 16);                     \
+    }
+        f32x4 dn[4], vc[4], wc[2], wn[2];
+        stamp(t_setup);
+        SE_WINO_DLOAD(dn, 0)
+        wc[0] = wrow[0];
+        wc[1] = wrow[64];
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        vc[0] = dn[0] - dn[2]; vc[1] = dn[1] + dn[2]; vc[2] = dn[2] - dn[1]; vc[3] = dn[1] - dn[3];
+        auto substep = [&](auto s_tag) {
+            constexpr int S = decltype(s_tag)::value;
+            constexpr int t2 = S / 4, x = S % 4;
+            constexpr bool more_w = S + 1 < 36;
+            constexpr bool more_d = x == 0 && t2 + 1 < 9;
+            if constexpr (S == 2) fetch(fetch_u, fetch_c);   // next item's halo: global loads issued under this item's MFMAs
+            if constexpr (more_d) SE_WINO_DLOAD(dn, t2 + 1)
+            if constexpr (more_w) {
+                wn[0] = wrow[((S + 1) * 2 + 0) * 64];
+                wn[1] = wrow[((S + 1) * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                acc[x][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[n].x, vc[x].x, acc[x][n], 0, 0, 0);
+                acc[x][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[n].y, vc[x].y, acc[x][n], 0, 0, 0);
+                acc[x][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[n].z, vc[x].z, acc[x][n], 0, 0, 0);
+                acc[x][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[n].w, vc[x].w, acc[x][n], 0, 0, 0);
+            }
+            if constexpr (more_d) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            else if constexpr (more_w) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            wc[0] = wn[0];
+            wc[1] = wn[1];
+            if constexpr (x == 3 && t2 + 1 < 9) {
+                if (diag & 8) { vc[0] = dn[0]; vc[1] = dn[1]; vc[2] = dn[2]; vc[3] = dn[3]; }
+                else { vc[0] = dn[0] - dn[2]; vc[1] = dn[1] + dn[2]; vc[2] = dn[2] - dn[1]; vc[3] = dn[1] - dn[3]; }
+            }
+        };
+        for_each_index(substep, std::make_integer_sequence<int, 36>{});
+        stamp(t_mfma);
+#undef SE_WINO_DLOAD
+
+        // ---- item boundary: commit the prefetched halo BEFORE issuing this item's stores (vmcnt is in issue order) ----
+        if (nxt.valid && !(diag & 1)) commit(buf ^ 1);
+        if (!(diag & 2))
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            f32x4 y0 = acc[0][n] + acc[1][n] + acc[2][n];
+            f32x4 y1 = acc[1][n] - acc[2][n] - acc[3][n];
+            if (cur.c > 0) {   // partial sums of the previous chunks (from memory, or kept in registers for a lone unit)
+                y0 += part[0][n];
+                y1 += part[1][n];
+            }
+            if (lone && !last_chunk) {   // same tile again next item: keep the running sum in registers, no round trip
+                part[0][n] = y0;
+                part[1][n] = y1;
+                continue;
+            }
+            if (last_chunk) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + cur.cb * 32 + n * 16 + 4 * h);
+                y0 += bias; y1 += bias;
+                if (use_res) { y0 += resv[0][n]; y1 += resv[1][n]; }
+                if (relu) {
+                    y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
+                    y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
+                }
+            }
+            *reinterpret_cast<f32x4*>(a.out + o0 + n * 16) = y0;
+            *reinterpret_cast<f32x4*>(a.out + o0 + zstride + n * 16) = y1;
+        }
+        stamp(t_tail);
+        if (!nxt.valid) break;
+        if (!(diag & 4)) __syncthreads();   // everyone is done with this halo buffer and these weights; the other buffer is complete
+        stamp(t_bar);
+        if (nxt.cb != cur.cb || nxt.c != cur.c) {
+            load_weights(nxt.cb, nxt.c);
+            __syncthreads();
+        }
+        cur = nxt;
+        buf ^= 1;
+    }
+    if constexpr (STAMP) {
+        if (lane == 0 && dbg) {
+            unsigned long long* o = dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+            o[0] = t_setup; o[1] = t_mfma; o[2] = t_tail; o[3] = t_bar;
+        }
+    }
+}
+
+int g_num_cus_wino = 0;
+unsigned long long* g_wino_dbg = nullptr;
+
+}  // namespace
+
+// Returns 0 on launch, SE_TILED_NOT_TAKEN if the shape/flags are not covered, else a hipError_t.
+int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
+    const int dim = a.dim;
+    if (!a.wpack_b || dim < 16 || (dim & 7) || (a.cout & 31) || (a.cin & 15) || a.cin_pad != a.cin) return SE_TILED_NOT_TAKEN;
+    if (a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR)) return SE_TILED_NOT_TAKEN;
+    constexpr int LDS_FIXED = (SE_WINO_CHUNK_FLOATS + 2 * TILE_FLOATS) * 4;
+    constexpr int LDS_BYTES = 160 * 1024;                       // fixed part + unit table (16 B per unit)
+    constexpr int MAX_UNITS_PER_WG = (LDS_BYTES - LDS_FIXED) / 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_wino_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_wino_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            g_num_cus_wino = n;
+        else
+            g_num_cus_wino = 256;
+        attr_set = true;
+    }
+    const int tiles = dim / 8, ztiles = dim / 4;
+    const int total_tiles = batch * ztiles * tiles * tiles;
+    const int n_cb = a.cout / 32;
+    const int n_units = n_cb * total_tiles;
+    const int grid = n_units < g_num_cus_wino ? n_units : g_num_cus_wino;
+    const int per = (n_units + grid - 1) / grid;
+    if (per > MAX_UNITS_PER_WG) return SE_TILED_NOT_TAKEN;      // B > ~150 at 64^3: fall back to the tiled kernel
+    if (g_wino_dbg) {   // diagnostic stamp build (se_debug_set_stamp_buffer)
+        hipLaunchKernelGGL(conv3d_k3_wino_kernel<true>, dim3((n_units + per - 1) / per), dim3(512), LDS_BYTES, s, a, tiles,
+                           ztiles, total_tiles, n_cb, per, 0, g_wino_dbg);
+    } else {
+        hipLaunchKernelGGL(conv3d_k3_wino_kernel<false>, dim3((n_units + per - 1) / per), dim3(512), LDS_BYTES, s, a, tiles,
+                           ztiles, total_tiles, n_cb, per, g_variant >= 10 ? g_variant - 10 : 0, nullptr);
+    }
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+// Debug only: device buffer (grid * 8 waves * 4 u64) that makes the Winograd kernel run its STAMP build.
+extern "C" void se_debug_set_stamp_buffer(void* p) { g_wino_dbg = reinterpret_cast<unsigned long long*>(p); }

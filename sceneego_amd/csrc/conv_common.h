@@ -6,13 +6,15 @@
 #define SE_K7_TAPS 343
 #define SE_K7_GROUPS 86
 #define SE_TILED_NOT_TAKEN (-1000)
+// 1-D Winograd section of the packed 3x3x3 weights: per (16-cin group, 32-cout block): 9 (dy,dx) x 4 xi x 2 cout tiles x 1 KiB
+#define SE_WINO_CHUNK_FLOATS (9 * 4 * 2 * 256)
 
 __host__ __device__ inline int round_up16(int v) { return (v + 15) & ~15; }
 
 struct ConvArgs {
     const float* in;
     const float* wpack;    // section A: [cg][tap][nt][lane][4]
-    const float* wpack_b;  // section B (k = 7 only): [chunk4][group][nt][lane][4]
+    const float* wpack_b;  // k = 7: section B [chunk4][group][nt][lane][4];  k = 3: Winograd section C (NULL if cout % 32)
     const float* bpack;
     const float* res;
     float* out;

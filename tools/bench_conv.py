@@ -29,13 +29,14 @@ def main():
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--variants", default="0,1")
     ap.add_argument("--no-res", action="store_true")
+    ap.add_argument("--only", type=int, default=-1, help="index into SHAPES")
     args = ap.parse_args()
     lib = _lib.load()
     dev = "cuda:0"
     B = args.batch
     variants = [int(v) for v in args.variants.split(",")]
     ws = torch.empty(32 << 20, device=dev)
-    for dim, cin, cin_pad, cout, k in SHAPES:
+    for dim, cin, cin_pad, cout, k in (SHAPES if args.only < 0 else SHAPES[args.only:args.only + 1]):
         conv = torch.nn.Conv3d(cin, cout, k, padding=(k - 1) // 2).to(dev)
         pc = _PackedConv(conv, None, cin_pad=cin_pad)
         x = torch.randn(B, dim, dim, dim, cin_pad, device=dev)
