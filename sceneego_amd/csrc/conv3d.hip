@@ -76,6 +76,26 @@ __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict
         }
         wpack[t] = v;
         return;
+    } else if (t - total_a >= (long long)(cin_pad / 4) * SE_K7_GROUPS * nts * 256) {
+        // section D (k = 7, cout <= 16): 1-D Winograd F(2,7) along z.  U_xi = sum_kz G[xi][kz] * W[..][kz][dy][dx];
+        // blocks [chunk4][g(13)][xi(8)][lane][j]: k lane h carries the (dy,dx) tap 4g+h (taps >= 49 are zero padding)
+        long long r = (t - total_a - (long long)(cin_pad / 4) * SE_K7_GROUPS * nts * 256) >> 8;
+        const int xi = (int)(r % 8); r /= 8;
+        const int g = (int)(r % SE_K7W_GROUPS); r /= SE_K7W_GROUPS;
+        const int tap2d = 4 * g + (lane >> 4);
+        const int cc = (int)r * 4 + j;
+        const int co = lane & 15;
+        float v = 0.f;
+        if (co < cout && cc < cin && tap2d < 49) {
+            const float sc = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
+            const float* wp = w + ((size_t)co * cin + cc) * 343 + tap2d;
+            float u = 0.f;
+#pragma unroll
+            for (int kz = 0; kz < 7; ++kz) u += se_wino27_G(xi, kz) * wp[kz * 49];
+            v = u * sc;
+        }
+        wpack[t] = v;
+        return;
     } else {
         long long r = (t - total_a) >> 8;
         nt = (int)(r % nts); r /= nts;
@@ -306,6 +326,7 @@ static long long packed_elems_a(int cout, int cin_pad, int ksize, int transposed
 extern "C" long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, int transposed) {
     long long n = packed_elems_a(cout, cin_pad, ksize, transposed);
     if (!transposed && ksize == 7) n += (long long)(cin_pad / 4) * SE_K7_GROUPS * (round_up16(cout) / 16) * 256;
+    if (!transposed && ksize == 7 && cout <= 16) n += (long long)(cin_pad / 4) * SE_K7W_CHUNK_FLOATS;
     if (!transposed && ksize == 3 && cout % 32 == 0) n += (long long)(cin_pad / 16) * (cout / 32) * SE_WINO_CHUNK_FLOATS;
     return n;
 }
@@ -346,6 +367,9 @@ extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* b
     a.total_vox = (long long)batch * dim * dim * dim;
     a.dim = dim; a.cin = cin; a.cin_pad = cin_pad; a.cout = cout; a.nts = round_up16(cout) / 16; a.flags = flags;
     a.wpack_b = wpack + packed_elems_a(cout, cin_pad, ksize, 0);
+    a.wpack_d = nullptr;
+    if (ksize == 7 && cout <= 16)
+        a.wpack_d = a.wpack_b + (long long)(cin_pad / 4) * SE_K7_GROUPS * (round_up16(cout) / 16) * 256;
     if (ksize == 3 && (cout % 32)) a.wpack_b = nullptr;
     if (ksize == 1) a.wpack_b = nullptr;
     const int took = se_conv3d_tiled_try(a, batch, ksize, s);
@@ -387,6 +411,7 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
     a.total_vox = (long long)batch * dim * dim * dim;
     a.dim = dim; a.cin = cin; a.cin_pad = cin; a.cout = cout; a.nts = cout / 16; a.flags = flags;
     a.wpack_b = nullptr;
+    a.wpack_d = nullptr;
     const long long vox_per_wg = 4 * 4 * 16;
     const unsigned gx = (unsigned)((a.total_vox + vox_per_wg - 1) / vox_per_wg);
     if (a.nts % 2 == 0) {

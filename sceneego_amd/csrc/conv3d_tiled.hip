@@ -648,6 +648,7 @@ int launch_tiled(const ConvArgs& a, int batch, hipStream_t s) {
 // Returns 0 if a tiled kernel took the launch, SE_TILED_NOT_TAKEN if the shape is left to the direct kernel,
 // otherwise the hipError_t of the failed launch.
 int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s);   // conv3d_wino.hip
+int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s);
 
 int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) {
     const int dim = a.dim;
@@ -671,6 +672,10 @@ int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) 
         return launch_tiled<3, 16, 4, 1>(a, batch, s);
     }
     if (ksize == 7 && nts == 1) {
+        if (g_variant == 0 || g_variant >= 10) {   // production: F(2,7) Winograd persistent kernel
+            const int rc = se_conv3d_k7_wino_try(a, batch, s);
+            if (rc != SE_TILED_NOT_TAKEN) return rc;
+        }
         if (g_variant != 1 && dim >= 32 && a.cout == 16 && !a.res && !(a.flags & SE_EPI_OUT_PLANAR)) {
             ensure_device_info();
             return launch_k7_persistent(a, batch, s);

@@ -317,6 +317,205 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino_kernel(ConvArgs a, int til
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 7x7x7 convolution (front layer, cout = 16) with a 1-D Winograd F(2,7) transform along z: 8 multiplies instead of 14
+// per pair of z-neighbouring outputs and (dy, dx, cin, cout) -> 1.65x fewer MFMAs than the direct form (49 taps
+// padded to 13 groups of 4 on the k lanes).  y = A^T [(G g) .* (B^T d)], points {0, +-1, +-2, +-1/2, inf}:
+//   B^T d is applied ONCE per element while the halo is committed to LDS (the inner loop has no VALU work at all):
+//   for each (y, x) column of the 4-channel chunk and each z pair, 8 raw slabs -> 8 transformed slabs V_xi;
+//   G g is folded into the packed weights (section D);  A^T runs in the epilogue.
+// fp32 error of the transform: ~1e-6 relative (tools/wino27_matrices.py), far inside the 1e-3 joint tolerance.
+// Persistent 512-thread workgroup per CU, chunk-outer with y-domain partial sums through the output tensor, like the
+// 3x3x3 kernel above.  LDS: 104 KB weights of one chunk + ONE transformed tile (2 z pairs x 8 xi x 14 x 14 x 16 B =
+// 49 KB); wave w: z pair w>>2, rows 2*(w&3), +1 -> one 16-position tile, 8 accumulators (one per xi).
+// ------------------------------------------------------------------------------------------------
+constexpr int K7_HY = 14, K7_HX = 14, K7_COLS = K7_HY * K7_HX;          // 196 halo columns
+constexpr int K7_VT_FLOATS = 2 * 8 * K7_COLS * 4;                        // transformed tile
+constexpr int K7_W_FLOATS = SE_K7W_CHUNK_FLOATS;
+
+__global__ __launch_bounds__(512) void conv3d_k7_wino_kernel(ConvArgs a, int tiles_per_dim, int ztiles, int total_tiles,
+                                                             int units_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;
+    float* vt = lds + K7_W_FLOATS;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4* utab = reinterpret_cast<i32x4*>(lds + K7_W_FLOATS + K7_VT_FLOATS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int vl = lane & 15;
+    const int h = lane >> 4;
+    const int dim = a.dim;
+    const int chunks = (a.cin + 3) >> 2;
+    const int rem = a.cin & 3;
+    const int u_begin = (int)blockIdx.x * units_per_wg;
+    const int u_end = min(u_begin + units_per_wg, total_tiles);
+    if (u_begin >= u_end) return;
+    const int n = u_end - u_begin;
+
+    for (int i = tid; i < n; i += 512) {
+        int t = u_begin + i;
+        i32x4 e;
+        e.w = t % tiles_per_dim; t /= tiles_per_dim;
+        e.z = t % tiles_per_dim; t /= tiles_per_dim;
+        e.y = t % ztiles; t /= ztiles;
+        e.x = t;
+        utab[i] = e;
+    }
+
+    // compute role: z pair zp, 16 positions (rows 2m, 2m+1 of the 8x8 tile)
+    const int zp = wave >> 2;
+    const int ry = (wave & 3) * 2 + (vl >> 3);
+    const int rx = vl & 7;
+    // per-lane LDS offsets (floats) of the 13 tap groups: tap 4g+h -> (dy,dx); constant for the whole kernel
+    int toff[SE_K7W_GROUPS];
+#pragma unroll
+    for (int g = 0; g < SE_K7W_GROUPS; ++g) {
+        int tap = 4 * g + h;
+        tap = tap < 49 ? tap : 0;   // zero-weight padding
+        toff[g] = (zp * 8 * K7_COLS + (ry + tap / 7) * K7_HX + rx + tap % 7) * 4;
+    }
+
+    // staging role: thread t < 392 owns halo column (t % 196) of z pair (t / 196): 8 raw slabs -> 8 transformed slabs
+    const bool s_on = tid < 2 * K7_COLS;
+    const int s_col = tid % K7_COLS, s_zp = tid / K7_COLS;
+    const int s_cy = s_col / K7_HX, s_cx = s_col % K7_HX;
+    f32x4 raw[8];
+    auto fetch = [&](int k, int c) {
+        const i32x4 e = utab[k];
+        const int gy = e.z * 8 - 3 + s_cy, gx = e.w * 8 - 3 + s_cx;
+        const int gz0 = e.y * 4 + 2 * s_zp - 3;
+        const bool okc = s_on && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim;
+        const long long base = ((((long long)e.x * dim) * dim + gy) * dim + gx) * a.cin_pad + c * 4;
+        const long long zs = (long long)dim * dim * a.cin_pad;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool ok = okc && (unsigned)(gz0 + q) < (unsigned)dim;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(a.in + (ok ? base + (gz0 + q) * zs : 0));
+            raw[q] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&]() {   // V = B^T d, rows as printed by tools/wino27_matrices.py
+        if (!s_on) return;
+        const f32x4 d0 = raw[0], d1 = raw[1], d2 = raw[2], d3 = raw[3], d4 = raw[4], d5 = raw[5], d6 = raw[6], d7 = raw[7];
+        f32x4 v[8];
+        v[0] = (d6 - d0) + 5.25f * (d2 - d4);
+        v[7] = (d7 - d1) + 5.25f * (d3 - d5);
+        const f32x4 e1 = d2 + d6 - 4.25f * d4, o1 = d1 + d5 - 4.25f * d3;
+        v[1] = e1 + o1;
+        v[2] = e1 - o1;
+        const f32x4 e2 = 0.25f * d2 - 1.25f * d4 + d6, o2 = 0.5f * d1 - 2.5f * d3 + 2.f * d5;
+        v[3] = e2 + o2;
+        v[4] = e2 - o2;
+        const f32x4 e3 = 4.f * d2 - 5.f * d4 + d6, o3 = 2.f * d1 - 2.5f * d3 + 0.5f * d5;
+        v[5] = e3 + o3;
+        v[6] = e3 - o3;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) *reinterpret_cast<f32x4*>(vt + ((s_zp * 8 + x) * K7_COLS + s_col) * 4) = v[x];
+    };
+    auto load_weights = [&](int c) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack_d) + (size_t)c * (K7_W_FLOATS / 4);
+        for (int i = tid; i < K7_W_FLOATS / 4; i += 512) reinterpret_cast<f32x4*>(wl)[i] = src[i];
+    };
+    auto out_offset = [&](int k) -> long long {
+        const i32x4 e = utab[k];
+        const int oz = e.y * 4 + 2 * zp, oy = e.z * 8 + ry, ox = e.w * 8 + rx;
+        return ((((long long)e.x * dim + oz) * dim + oy) * dim + ox) * 16 + 4 * h;
+    };
+    const long long zstride = (long long)dim * dim * 16;
+
+    const bool relu = a.flags & SE_EPI_RELU;
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + 4 * h);
+    const bool lone = n == 1;
+
+    __syncthreads();   // utab
+    fetch(0, 0);
+    commit();
+    load_weights(0);
+    __syncthreads();
+
+    f32x4 part[2];
+    part[0] = part[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int n_items = chunks * n;
+    for (int item = 0; item < n_items; ++item) {
+        const int c = item / n, k = item - c * n;
+        const bool has_next = item + 1 < n_items;
+        const int c_next = has_next ? (item + 1) / n : c;
+        const int k_next = has_next ? (item + 1) - c_next * n : k;
+        const bool last_chunk = c == chunks - 1;
+        const long long o0 = out_offset(k);
+        if (c > 0 && !lone) {
+            part[0] = *reinterpret_cast<const f32x4*>(a.out + o0);
+            part[1] = *reinterpret_cast<const f32x4*>(a.out + o0 + zstride);
+        }
+
+        f32x4 acc[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4* wrow = reinterpret_cast<const f32x4*>(wl) + lane;
+        const int nj = (last_chunk && rem != 0) ? rem : 4;   // uniform: real channels in this chunk
+        // software pipeline over the 104 sub-steps (tap group, xi): operands of sub-step s+1 are read before the MFMAs of s
+        f32x4 wc = wrow[0], vc = *reinterpret_cast<const f32x4*>(vt + toff[0]);
+        f32x4 wn = wc, vn = vc;
+        auto body = [&](auto nj_tag) {
+            constexpr int NJ = decltype(nj_tag)::value;
+            auto substep = [&](auto s_tag) {
+                constexpr int S = decltype(s_tag)::value;
+                constexpr int g = S / 8, x = S % 8;
+                if constexpr (S == 3) fetch(k_next, c_next);   // next item's raw columns: global loads under the MFMAs
+                if constexpr (S + 1 < 104) {
+                    constexpr int g1 = (S + 1) / 8, x1 = (S + 1) % 8;
+                    wn = wrow[(S + 1) * 64];
+                    vn = *reinterpret_cast<const f32x4*>(vt + toff[g1] + x1 * K7_COLS * 4);
+                }
+                acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.x, vc.x, acc[x], 0, 0, 0);
+                if constexpr (NJ > 1) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.y, vc.y, acc[x], 0, 0, 0);
+                if constexpr (NJ > 2) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.z, vc.z, acc[x], 0, 0, 0);
+                if constexpr (NJ > 3) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.w, vc.w, acc[x], 0, 0, 0);
+                if constexpr (S + 1 < 104) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if constexpr (NJ == 4) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                else if constexpr (NJ == 1) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                wc = wn;
+                vc = vn;
+                (void)g;
+            };
+            for_each_index(substep, std::make_integer_sequence<int, 104>{});
+        };
+        if (nj == 4) body(std::integral_constant<int, 4>{});
+        else if (nj == 1) body(std::integral_constant<int, 1>{});
+        else if (nj == 2) body(std::integral_constant<int, 2>{});
+        else body(std::integral_constant<int, 3>{});
+
+        // A^T: y0 = M0 + ... + M6 ; y1 = M1 - M2 + 2 M3 - 2 M4 + M5/2 - M6/2 + M7
+        f32x4 y0 = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + acc[6]);
+        f32x4 y1 = (acc[1] - acc[2]) + 2.f * (acc[3] - acc[4]) + 0.5f * (acc[5] - acc[6]) + acc[7];
+        if (c > 0) { y0 += part[0]; y1 += part[1]; }
+
+        // single transformed tile: every wave must be done reading it before the next item's columns are committed
+        __syncthreads();
+        if (has_next) {
+            commit();
+            if (c_next != c) load_weights(c_next);
+        }
+        if (lone && !last_chunk) {
+            part[0] = y0; part[1] = y1;
+        } else {
+            if (last_chunk) {
+                y0 += bias; y1 += bias;
+                if (relu) {
+                    y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
+                    y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
+                }
+            }
+            *reinterpret_cast<f32x4*>(a.out + o0) = y0;
+            *reinterpret_cast<f32x4*>(a.out + o0 + zstride) = y1;
+        }
+        if (!has_next) break;
+        __syncthreads();
+    }
+}
+
 int g_num_cus_wino = 0;
 unsigned long long* g_wino_dbg = nullptr;
 
@@ -366,3 +565,33 @@ int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
 
 // Debug only: device buffer (grid * 8 waves * 4 u64) that makes the Winograd kernel run its STAMP build.
 extern "C" void se_debug_set_stamp_buffer(void* p) { g_wino_dbg = reinterpret_cast<unsigned long long*>(p); }
+
+// Returns 0 on launch, SE_TILED_NOT_TAKEN if not covered, else a hipError_t.
+int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
+    const int dim = a.dim;
+    if (!a.wpack_d || dim < 16 || (dim & 7) || a.cout != 16 || a.res || (a.flags & (SE_EPI_OUT_PLANAR))) return SE_TILED_NOT_TAKEN;
+    constexpr int LDS_FIXED = (K7_W_FLOATS + K7_VT_FLOATS) * 4;
+    constexpr int LDS_BYTES = 160 * 1024;
+    constexpr int MAX_UNITS = (LDS_BYTES - LDS_FIXED) / 16;
+    static bool attr_set = false;
+    static int num_cus = 256;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k7_wino_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            num_cus = n;
+        attr_set = true;
+    }
+    const int tiles = dim / 8, ztiles = dim / 4;
+    const int total_tiles = batch * ztiles * tiles * tiles;
+    const int grid = total_tiles < num_cus ? total_tiles : num_cus;
+    const int per = (total_tiles + grid - 1) / grid;
+    if (per > MAX_UNITS) return SE_TILED_NOT_TAKEN;
+    hipLaunchKernelGGL(conv3d_k7_wino_kernel, dim3((total_tiles + per - 1) / per), dim3(512), LDS_BYTES, s, a, tiles, ztiles,
+                       total_tiles, per);
+    SE_CHECK_LAUNCH();
+    return 0;
+}

@@ -8,6 +8,24 @@
 #define SE_TILED_NOT_TAKEN (-1000)
 // 1-D Winograd section of the packed 3x3x3 weights: per (16-cin group, 32-cout block): 9 (dy,dx) x 4 xi x 2 cout tiles x 1 KiB
 #define SE_WINO_CHUNK_FLOATS (9 * 4 * 2 * 256)
+// 1-D Winograd F(2,7) section of the packed 7x7x7 weights: per 4-channel chunk 13 (dy,dx) tap groups x 8 xi x 1 KiB
+#define SE_K7W_GROUPS 13
+#define SE_K7W_CHUNK_FLOATS (SE_K7W_GROUPS * 8 * 256)
+
+// G matrix of F(2,7) with interpolation points {0, 1, -1, 2, -2, 1/2, -1/2, inf} (Cook-Toom; tools/wino27_matrices.py):
+// row xi, column kz.  y = A^T [(G g) .* (B^T d)].
+__host__ __device__ inline float se_wino27_G(int xi, int kz) {
+    switch (xi) {
+        case 0: return kz == 0 ? -1.f : 0.f;
+        case 1: return -2.f / 9.f;
+        case 2: return (kz & 1) ? 2.f / 9.f : -2.f / 9.f;
+        case 3: return (float)(1 << kz) / 90.f;
+        case 4: return ((kz & 1) ? -1.f : 1.f) * (float)(1 << kz) / 90.f;
+        case 5: return (float)(64 >> kz) / 90.f;
+        case 6: return ((kz & 1) ? -1.f : 1.f) * (float)(64 >> kz) / 90.f;
+        default: return kz == 6 ? 1.f : 0.f;
+    }
+}
 
 __host__ __device__ inline int round_up16(int v) { return (v + 15) & ~15; }
 
@@ -15,6 +33,7 @@ struct ConvArgs {
     const float* in;
     const float* wpack;    // section A: [cg][tap][nt][lane][4]
     const float* wpack_b;  // k = 7: section B [chunk4][group][nt][lane][4];  k = 3: Winograd section C (NULL if cout % 32)
+    const float* wpack_d;  // k = 7, cout <= 16: Winograd F(2,7) section D [chunk4][g13][xi8][lane][4] (else NULL)
     const float* bpack;
     const float* res;
     float* out;
