@@ -147,3 +147,38 @@ def test_hipgraph_replay_matches_eager(net64):
     assert float((kp_g1 - kp_eager).abs().max()) < 5e-5
     assert float((kp_g2 - kp_g1).abs().max()) < 5e-5
     assert float((kp_other - kp_g1).abs().max()) > 1e-3     # the replay really consumed the new inputs
+
+
+def test_demo_cli_single_frame(tmp_path, golden, golden_meta):
+    """BASELINE config 1 end to end through demo.py's classes: demo frame fixture + .npy depth -> pickle of [15,3] joints,
+    equal to the reference golden (<= 1e-3)."""
+    import os
+    import pickle
+    import sys
+    from PIL import Image
+    from conftest import GOLD, ROOT
+    sys.path.insert(0, ROOT)
+    import demo as demo_mod
+    m = next(c for c in golden_meta["cases"] if c["name"] == "demo_b1")
+    g = golden("demo_b1")
+    small = np.load(os.path.join(GOLD, "demo", "img_001000_256_bgr_u8.npz"))["img"]
+    # rebuild a 1280x1024 frame whose preprocessing gives exactly `small`: replicate each pixel 4x4, pad 128 columns
+    big = np.repeat(np.repeat(small, 4, axis=0), 4, axis=1)
+    frame = np.zeros((1024, 1280, 3), dtype=np.uint8)
+    frame[:, 128:-128] = big
+    img_dir, depth_dir, out_dir = tmp_path / "imgs", tmp_path / "depths", tmp_path / "out"
+    img_dir.mkdir(); depth_dir.mkdir()
+    Image.fromarray(frame[:, :, ::-1]).save(img_dir / "img_001000.png")        # lossless, RGB order on disk
+    _, depth = synth.make_inputs(m["input_seed"], 1, m["depth_kind"])
+    np.save(depth_dir / "img_001000.png.npy", depth[0].numpy().astype(np.float32))
+    cfg = load_config()
+    d = demo_mod.Demo(cfg, str(img_dir), str(depth_dir), weights="synthetic")
+    res = d.run()
+    assert len(res) == 1 and res[0]["predicted_keypoints"].shape == (15, 3)
+    err = float(np.abs(res[0]["predicted_keypoints"] - g["joints"][0]).max())
+    assert err <= JOINT_TOL, err
+    os.makedirs(out_dir, exist_ok=True)
+    with open(out_dir / "img_001000.png.pkl", "wb") as f:
+        pickle.dump(res[0]["predicted_keypoints"], f)
+    with open(out_dir / "img_001000.png.pkl", "rb") as f:
+        assert pickle.load(f).dtype == np.float32

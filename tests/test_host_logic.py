@@ -133,3 +133,25 @@ def test_synth_is_deterministic_and_portable():
     img, depth = synth.make_inputs(7, 1, "floor")
     assert tuple(img.shape) == (1, 3, 256, 256) and tuple(depth.shape) == (1, 1024, 1280)
     assert float(depth.max()) <= 10.0 and float(depth.min()) > 0.5
+
+
+def test_preprocessing_restatement(tmp_path):
+    """demo_dataset.py:67-98 restated: crop 128, exact-quarter bilinear (= rounded centre 2x2 mean), BGR + RGB statistics,
+    nearest depth resize (floor mapping) and the 10 m clamp."""
+    from sceneego_amd import preprocess as pp
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(1024, 1280, 3), dtype=np.uint8)
+    t = pp.preprocess_image(img)
+    assert tuple(t.shape) == (3, 256, 256) and t.dtype == torch.float32
+    crop = img[:, 128:-128].astype(np.float64)
+    want = (crop[1::4, 1::4] + crop[1::4, 2::4] + crop[2::4, 1::4] + crop[2::4, 2::4] + 2) // 4
+    ch0 = (want[:, :, 0] / 255.0 - 0.485) / 0.229            # B channel gets the "R" statistics (reference quirk)
+    np.testing.assert_allclose(t[0].numpy(), ch0, atol=1e-6)
+    d = np.linspace(0, 20, 512 * 640, dtype=np.float32).reshape(512, 640)
+    out = pp.prepare_depth(d)
+    assert tuple(out.shape) == (1024, 1280) and float(out.max()) == 10.0
+    assert float(out[3, 5]) == min(float(d[1, 2]), 10.0)      # floor(3*0.5)=1, floor(5*0.5)=2
+    np.save(tmp_path / "x.npy", d.astype(np.float16))
+    assert pp.load_depth(str(tmp_path / "x.npy")).dtype == np.float32
+    with pytest.raises(NotImplementedError):
+        pp.load_depth("whatever.exr")

@@ -23,6 +23,11 @@ def _run(case, golden, oracle_constants, meta):
     sd = synthetic_state_dict(m["with_intersection"], m["weight_seed"])
     const = oracle_constants(m["volume_size"])
     img, depth = synth.make_inputs(m["input_seed"], m["batch"], m["depth_kind"])
+    if case == "demo_b1":   # BASELINE config 1: derived fixture of the reference's demo frame
+        import os
+        from conftest import GOLD
+        from sceneego_amd.preprocess import normalize_u8
+        img = normalize_u8(np.load(os.path.join(GOLD, "demo", "img_001000_256_bgr_u8.npz"))["img"])[None]
     taps = {}
     joints, big, vols = O.forward(sd, const, img, depth, with_intersection=m["with_intersection"], taps=taps)
     return m, g, joints, vols, taps
@@ -57,6 +62,11 @@ def test_oracle_b2_uniform(golden, oracle_constants, golden_meta):
 def test_oracle_intersection(golden, oracle_constants, golden_meta):
     m, g, joints, vols, taps = _run("b1_intersection", golden, oracle_constants, golden_meta)
     _check(m, g, joints, vols, taps)
+
+
+def test_oracle_demo_frame(golden, oracle_constants, golden_meta):
+    """BASELINE config 1 (demo.py single frame, CPU): real demo image (derived fixture) + synthetic floor depth."""
+    _check(*_run("demo_b1", golden, oracle_constants, golden_meta))
 
 
 def test_oracle_g128(golden, oracle_constants, golden_meta):

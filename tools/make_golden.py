@@ -110,6 +110,10 @@ def run_case(name, RefNet, cfg_mod, synth, O, *, batch, in_seed, depth_kind, wit
     sd = synth.make_state_dict(net.state_dict(), seed=weight_seed)
     net.load_state_dict(sd, strict=True)
     img, depth = synth.make_inputs(in_seed, batch, depth_kind)
+    if name == "demo_b1":   # BASELINE config 1: the reference's demo frame (derived fixture) + seeded synthetic depth
+        from sceneego_amd.preprocess import normalize_u8
+        small = np.load(os.path.join(GOLD, "demo", "img_001000_256_bgr_u8.npz"))["img"]
+        img = normalize_u8(small)[None]
 
     taps = {}
     hooks = []
@@ -216,6 +220,14 @@ def main():
 
     RefNet, cfg_mod, op_mod = import_reference()
     metas = []
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-demo":
+        m, _ = run_case("demo_b1", RefNet, cfg_mod, synth, O, batch=1, in_seed=1000, depth_kind="floor")
+        with open(os.path.join(GOLD, "META.json")) as f:
+            meta = json.load(f)
+        meta["cases"] = [c for c in meta["cases"] if c["name"] != "demo_b1"] + [m]
+        with open(os.path.join(GOLD, "META.json"), "w") as f:
+            json.dump(meta, f, indent=1)
+        return
     m, net = run_case("b2_uniform", RefNet, cfg_mod, synth, O, batch=2, in_seed=1234, depth_kind="uniform")
     metas.append(m)
     constants_case(net, op_mod)
@@ -226,6 +238,8 @@ def main():
                     with_intersection=True)
     metas.append(m)
     m, _ = run_case("b1_g128_floor", RefNet, cfg_mod, synth, O, batch=1, in_seed=555, depth_kind="floor", volume_size=128)
+    metas.append(m)
+    m, _ = run_case("demo_b1", RefNet, cfg_mod, synth, O, batch=1, in_seed=1000, depth_kind="floor")
     metas.append(m)
 
     meta = {
