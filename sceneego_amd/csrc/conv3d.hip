@@ -55,6 +55,35 @@ __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict
         nt = (int)(r % nts); r /= nts;
         tap = (int)(r % taps); r /= taps;
         ci = (int)r * 16 + 4 * (lane >> 4) + j;
+    } else if (taps == 27 && t - total_a >= (long long)(cin_pad / 16) * (nts / 2) * SE_WINO_CHUNK_FLOATS) {
+        // section E: 1-D Winograd F(4,3) along z, U = G g with G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],
+        // [1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]; blocks [cg][cb][tap2d(9)][xi(6)][nt2][lane][j]
+        long long r = (t - total_a - (long long)(cin_pad / 16) * (nts / 2) * SE_WINO_CHUNK_FLOATS) >> 8;
+        const int nt2 = (int)(r % 2); r /= 2;
+        const int xi = (int)(r % 6); r /= 6;
+        const int tap2d = (int)(r % 9); r /= 9;
+        const int n_cb = nts / 2;
+        const int cb = (int)(r % n_cb); r /= n_cb;
+        const int co = cb * 32 + nt2 * 16 + (lane & 15);
+        const int cc = (int)r * 16 + 4 * (lane >> 4) + j;
+        float v = 0.f;
+        if (co < cout && cc < cin) {
+            const float sc = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
+            const float* wp = w + ((size_t)co * cin + cc) * 27 + tap2d;
+            const float g0 = wp[0], g1 = wp[9], g2 = wp[18];
+            float u;
+            switch (xi) {
+                case 0: u = g0 * 0.25f; break;
+                case 1: u = -(g0 + g1 + g2) * (1.f / 6.f); break;
+                case 2: u = -(g0 - g1 + g2) * (1.f / 6.f); break;
+                case 3: u = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f); break;
+                case 4: u = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f); break;
+                default: u = g2; break;
+            }
+            v = u * sc;
+        }
+        wpack[t] = v;
+        return;
     } else if (taps == 27) {
         // section C: 1-D Winograd F(2,3) along z.  U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2 of the
         // three z taps (g0: dz=-1) for every (dy,dx); blocks [cg][cb][tap2d][xi][nt2][lane][j], cb = 32-cout block
@@ -327,7 +356,8 @@ extern "C" long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, in
     long long n = packed_elems_a(cout, cin_pad, ksize, transposed);
     if (!transposed && ksize == 7) n += (long long)(cin_pad / 4) * SE_K7_GROUPS * (round_up16(cout) / 16) * 256;
     if (!transposed && ksize == 7 && cout <= 16) n += (long long)(cin_pad / 4) * SE_K7W_CHUNK_FLOATS;
-    if (!transposed && ksize == 3 && cout % 32 == 0) n += (long long)(cin_pad / 16) * (cout / 32) * SE_WINO_CHUNK_FLOATS;
+    if (!transposed && ksize == 3 && cout % 32 == 0)
+        n += (long long)(cin_pad / 16) * (cout / 32) * (SE_WINO_CHUNK_FLOATS + SE_WINO43_CHUNK_FLOATS);
     return n;
 }
 
@@ -370,6 +400,8 @@ extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* b
     a.wpack_d = nullptr;
     if (ksize == 7 && cout <= 16)
         a.wpack_d = a.wpack_b + (long long)(cin_pad / 4) * SE_K7_GROUPS * (round_up16(cout) / 16) * 256;
+    a.wpack_e = nullptr;
+    if (ksize == 3 && cout % 32 == 0) a.wpack_e = a.wpack_b + (long long)(cin_pad / 16) * (cout / 32) * SE_WINO_CHUNK_FLOATS;
     if (ksize == 3 && (cout % 32)) a.wpack_b = nullptr;
     if (ksize == 1) a.wpack_b = nullptr;
     const int took = se_conv3d_tiled_try(a, batch, ksize, s);
@@ -412,6 +444,7 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
     a.dim = dim; a.cin = cin; a.cin_pad = cin; a.cout = cout; a.nts = cout / 16; a.flags = flags;
     a.wpack_b = nullptr;
     a.wpack_d = nullptr;
+    a.wpack_e = nullptr;
     const long long vox_per_wg = 4 * 4 * 16;
     const unsigned gx = (unsigned)((a.total_vox + vox_per_wg - 1) / vox_per_wg);
     if (a.nts % 2 == 0) {

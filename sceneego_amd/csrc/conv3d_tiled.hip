@@ -652,7 +652,7 @@ int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s);
 
 int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) {
     const int dim = a.dim;
-    if (ksize == 3 && (g_variant == 0 || g_variant >= 10)) {   // production: 1-D Winograd persistent kernel
+    if (ksize == 3 && (g_variant == 0 || g_variant == 4 || g_variant >= 10)) {   // production: 1-D Winograd persistent kernels
         const int rc = se_conv3d_wino_try(a, batch, s);
         if (rc != SE_TILED_NOT_TAKEN) return rc;
     }

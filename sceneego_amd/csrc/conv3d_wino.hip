@@ -516,6 +516,222 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino_kernel(ConvArgs a, int til
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3x3 convolution with 1-D Winograd F(4,3) along z: 6 multiplies per 4 z-neighbouring outputs instead of 12
+// -> HALF the MFMAs of the direct form (F(2,3) above: 2/3).  Lavin-Gray matrices, points {0, +-1, +-2, inf}:
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]          (G is folded into the packed weights)
+// A 4x8x8 output tile is exactly one z quad; its 6 raw input slabs become 6 transformed slabs V_xi when the halo is
+// committed to LDS (B^T applied once per element, as in the 7^3 kernel), so the inner loop is LDS reads + MFMAs only.
+// LDS: 108 KB transformed weights of one (32-cout block, 16-channel chunk) + ONE 6 x 10 x 10 x 16-channel V tile
+// (38.4 KB).  Wave w of 8: 16 positions (rows 2(w&3), +1), cout tile w>>2 -> 6 accumulators (one per xi).
+// fp32 error of the transform ~4e-7 mean / 5e-6 max per 3-tap dot product (tools/wino_matrices.py).
+// ------------------------------------------------------------------------------------------------
+constexpr int W43_FLOATS = SE_WINO43_CHUNK_FLOATS;
+constexpr int V43_FLOATS = 6 * HY * HX * 16;
+
+__global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int tiles_per_dim, int ztiles, int total_tiles,
+                                                               int n_cb, int units_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;
+    float* vt = lds + W43_FLOATS;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4* utab = reinterpret_cast<i32x4*>(lds + W43_FLOATS + V43_FLOATS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int vl = lane & 15;
+    const int h = lane >> 4;
+    const int dim = a.dim;
+    const int chunks = a.cin >> 4;
+    const int n_units = n_cb * total_tiles;
+    const int u_begin = (int)blockIdx.x * units_per_wg;
+    const int u_end = min(u_begin + units_per_wg, n_units);
+    if (u_begin >= u_end) return;
+
+    for (int i = tid; i < u_end - u_begin; i += 512) {
+        int t = (u_begin + i) % total_tiles;
+        i32x4 e;
+        e.w = t % tiles_per_dim; t /= tiles_per_dim;
+        e.z = t % tiles_per_dim; t /= tiles_per_dim;
+        e.y = t % ztiles; t /= ztiles;
+        e.x = t;
+        utab[i] = e;
+    }
+
+    // compute role
+    const int nt = wave >> 2;
+    const int ry = (wave & 3) * 2 + (vl >> 3);
+    const int rx = vl & 7;
+    const float* vb = vt + (ry * HX + rx) * 16 + 4 * h;
+
+    // staging role: thread t < 400 owns halo column (t >> 2) and channel quad (t & 3): 6 raw slabs -> 6 V slabs
+    const bool s_on = tid < HY * HX * 4;
+    const int s_col = tid >> 2, s_q = tid & 3;
+    const int s_cy = s_col / HX, s_cx = s_col % HX;
+    f32x4 raw[6];
+    auto fetch = [&](int u, int c) {
+        const i32x4 e = utab[u - u_begin];
+        const int gy = e.z * 8 - 1 + s_cy, gx = e.w * 8 - 1 + s_cx, gz0 = e.y * 4 - 1;
+        const bool okc = s_on && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim;
+        const long long base = ((((long long)e.x * dim) * dim + gy) * dim + gx) * a.cin_pad + c * 16 + s_q * 4;
+        const long long zs = (long long)dim * dim * a.cin_pad;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const bool ok = okc && (unsigned)(gz0 + q) < (unsigned)dim;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(a.in + (ok ? base + (gz0 + q) * zs : 0));
+            raw[q] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&]() {
+        if (!s_on) return;
+        const f32x4 d0 = raw[0], d1 = raw[1], d2 = raw[2], d3 = raw[3], d4 = raw[4], d5 = raw[5];
+        f32x4 v[6];
+        v[0] = 4.f * d0 - 5.f * d2 + d4;
+        v[5] = 4.f * d1 - 5.f * d3 + d5;
+        const f32x4 e1 = d4 - 4.f * d2, o1 = d3 - 4.f * d1;
+        v[1] = e1 + o1;
+        v[2] = e1 - o1;
+        const f32x4 e2 = d4 - d2, o2 = 2.f * (d3 - d1);
+        v[3] = e2 + o2;
+        v[4] = e2 - o2;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) *reinterpret_cast<f32x4*>(vt + (x * HY * HX + s_col) * 16 + s_q * 4) = v[x];
+    };
+    auto load_weights = [&](int cb, int c) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack_e) + ((size_t)c * n_cb + cb) * (W43_FLOATS / 4);
+        for (int i = tid; i < W43_FLOATS / 4; i += 512) reinterpret_cast<f32x4*>(wl)[i] = src[i];
+    };
+    auto out_offset = [&](int u, int cb) -> long long {
+        const i32x4 e = utab[u - u_begin];
+        return ((((long long)e.x * dim + e.y * 4) * dim + e.z * 8 + ry) * dim + e.w * 8 + rx) * a.cout + cb * 32 + nt * 16 + 4 * h;
+    };
+    const long long zstride = (long long)dim * dim * a.cout;
+
+    auto first_item = [&]() {
+        WinoIter it;
+        it.u_lo = u_begin;
+        it.cb = u_begin / total_tiles;
+        it.n = min(u_end, (it.cb + 1) * total_tiles) - u_begin;
+        it.c = 0; it.k = 0; it.valid = true;
+        return it;
+    };
+    auto next_item = [&](WinoIter it) {
+        if (++it.k == it.n) {
+            it.k = 0;
+            if (++it.c == chunks) {
+                it.c = 0;
+                it.u_lo += it.n;
+                if (it.u_lo >= u_end) { it.valid = false; return it; }
+                it.cb = it.u_lo / total_tiles;
+                it.n = min(u_end, (it.cb + 1) * total_tiles) - it.u_lo;
+            }
+        }
+        return it;
+    };
+
+    const bool relu = a.flags & SE_EPI_RELU;
+    const bool use_res = (a.flags & SE_EPI_RES_PRE_RELU) && a.res;
+
+    __syncthreads();   // utab
+    WinoIter cur = first_item();
+    fetch(cur.u_lo, 0);
+    commit();
+    load_weights(cur.cb, 0);
+    __syncthreads();
+
+    f32x4 part[4], resv[4];
+#pragma unroll
+    for (int z = 0; z < 4; ++z) part[z] = resv[z] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    while (true) {
+        const WinoIter nxt = next_item(cur);
+        const int u = cur.u_lo + cur.k;
+        const bool last_chunk = cur.c == chunks - 1;
+        const bool lone = cur.n == 1;
+        const int fetch_u = nxt.valid ? nxt.u_lo + nxt.k : u;
+        const int fetch_c = nxt.valid ? nxt.c : cur.c;
+        const long long o0 = out_offset(u, cur.cb);
+        if (cur.c > 0 && !lone) {
+#pragma unroll
+            for (int z = 0; z < 4; ++z) part[z] = *reinterpret_cast<const f32x4*>(a.out + o0 + z * zstride);
+        }
+        if (last_chunk && use_res) {
+#pragma unroll
+            for (int z = 0; z < 4; ++z) resv[z] = *reinterpret_cast<const f32x4*>(a.res + o0 + z * zstride);
+        }
+
+        f32x4 acc[6];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4* wrow = reinterpret_cast<const f32x4*>(wl) + nt * 64 + lane;
+        f32x4 wc = wrow[0], vc = *reinterpret_cast<const f32x4*>(vb);
+        f32x4 wn = wc, vn = vc;
+        auto substep = [&](auto s_tag) {
+            constexpr int S = decltype(s_tag)::value;
+            constexpr int x = S % 6;
+            if constexpr (S == 3) fetch(fetch_u, fetch_c);   // next item's raw columns: global loads under the MFMAs
+            if constexpr (S + 1 < 54) {
+                constexpr int t1 = (S + 1) / 6, x1 = (S + 1) % 6;
+                wn = wrow[(S + 1) * 128];
+                vn = *reinterpret_cast<const f32x4*>(vb + (x1 * HY * HX + (t1 / 3) * HX + (t1 % 3)) * 16);
+            }
+            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.x, vc.x, acc[x], 0, 0, 0);
+            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.y, vc.y, acc[x], 0, 0, 0);
+            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.z, vc.z, acc[x], 0, 0, 0);
+            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.w, vc.w, acc[x], 0, 0, 0);
+            if constexpr (S + 1 < 54) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            wc = wn;
+            vc = vn;
+        };
+        for_each_index(substep, std::make_integer_sequence<int, 54>{});
+
+        // A^T
+        f32x4 y[4];
+        {
+            const f32x4 s12 = acc[1] + acc[2], d12 = acc[1] - acc[2], s34 = acc[3] + acc[4], d34 = acc[3] - acc[4];
+            y[0] = acc[0] + s12 + s34;
+            y[1] = d12 + 2.f * d34;
+            y[2] = s12 + 4.f * s34;
+            y[3] = d12 + 8.f * d34 + acc[5];
+        }
+        if (cur.c > 0) {
+#pragma unroll
+            for (int z = 0; z < 4; ++z) y[z] += part[z];
+        }
+        // single V tile: every wave must be done reading it before the next item's columns are committed
+        __syncthreads();
+        if (nxt.valid) {
+            commit();
+            if (nxt.cb != cur.cb || nxt.c != cur.c) load_weights(nxt.cb, nxt.c);
+        }
+        if (lone && !last_chunk) {
+#pragma unroll
+            for (int z = 0; z < 4; ++z) part[z] = y[z];
+        } else {
+            if (last_chunk) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + cur.cb * 32 + nt * 16 + 4 * h);
+#pragma unroll
+                for (int z = 0; z < 4; ++z) {
+                    y[z] += bias;
+                    if (use_res) y[z] += resv[z];
+                    if (relu) {
+                        y[z].x = fmaxf(y[z].x, 0.f); y[z].y = fmaxf(y[z].y, 0.f);
+                        y[z].z = fmaxf(y[z].z, 0.f); y[z].w = fmaxf(y[z].w, 0.f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int z = 0; z < 4; ++z) *reinterpret_cast<f32x4*>(a.out + o0 + z * zstride) = y[z];
+        }
+        if (!nxt.valid) break;
+        __syncthreads();
+        cur = nxt;
+    }
+}
+
 int g_num_cus_wino = 0;
 unsigned long long* g_wino_dbg = nullptr;
 
@@ -552,6 +768,23 @@ int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
     const int grid = n_units < g_num_cus_wino ? n_units : g_num_cus_wino;
     const int per = (n_units + grid - 1) / grid;
     if (per > MAX_UNITS_PER_WG) return SE_TILED_NOT_TAKEN;      // B > ~150 at 64^3: fall back to the tiled kernel
+    if (a.wpack_e && g_variant != 4 && !g_wino_dbg) {            // production: F(4,3)
+        constexpr int LDS43 = 160 * 1024;
+        constexpr int MAX43 = (LDS43 - (W43_FLOATS + V43_FLOATS) * 4) / 16;
+        static bool attr43 = false;
+        if (!attr43) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_wino43_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS43);
+            if (e != hipSuccess) return (int)e;
+            attr43 = true;
+        }
+        if (per <= MAX43) {
+            hipLaunchKernelGGL(conv3d_k3_wino43_kernel, dim3((n_units + per - 1) / per), dim3(512), LDS43, s, a, tiles, ztiles,
+                               total_tiles, n_cb, per);
+            SE_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (g_wino_dbg) {   // diagnostic stamp build (se_debug_set_stamp_buffer)
         hipLaunchKernelGGL(conv3d_k3_wino_kernel<true>, dim3((n_units + per - 1) / per), dim3(512), LDS_BYTES, s, a, tiles,
                            ztiles, total_tiles, n_cb, per, 0, g_wino_dbg);

@@ -8,6 +8,8 @@
 #define SE_TILED_NOT_TAKEN (-1000)
 // 1-D Winograd section of the packed 3x3x3 weights: per (16-cin group, 32-cout block): 9 (dy,dx) x 4 xi x 2 cout tiles x 1 KiB
 #define SE_WINO_CHUNK_FLOATS (9 * 4 * 2 * 256)
+// F(4,3) variant (section E): 9 (dy,dx) x 6 xi x 2 cout tiles x 1 KiB = 108 KB per (16-cin group, 32-cout block)
+#define SE_WINO43_CHUNK_FLOATS (9 * 6 * 2 * 256)
 // 1-D Winograd F(2,7) section of the packed 7x7x7 weights: per 4-channel chunk 13 (dy,dx) tap groups x 8 xi x 1 KiB
 #define SE_K7W_GROUPS 13
 #define SE_K7W_CHUNK_FLOATS (SE_K7W_GROUPS * 8 * 256)
@@ -33,6 +35,7 @@ struct ConvArgs {
     const float* in;
     const float* wpack;    // section A: [cg][tap][nt][lane][4]
     const float* wpack_b;  // k = 7: section B [chunk4][group][nt][lane][4];  k = 3: Winograd section C (NULL if cout % 32)
+    const float* wpack_e;  // k = 3, cout % 32 == 0: Winograd F(4,3) section E (else NULL)
     const float* wpack_d;  // k = 7, cout <= 16: Winograd F(2,7) section D [chunk4][g13][xi8][lane][4] (else NULL)
     const float* bpack;
     const float* res;
