@@ -35,6 +35,25 @@ __device__ __forceinline__ void for_each_index(F&& f, std::integer_sequence<int,
     (f(std::integral_constant<int, S>{}), ...);
 }
 
+// global -> LDS copy of N4 16-byte pieces by NT threads, 8 loads in flight per thread (a plain loop is compiled to
+// load / s_waitcnt vmcnt(0) / ds_write per iteration: one exposed L2 round trip per 16 bytes per thread).
+template <int NT>
+__device__ __forceinline__ void fill_lds(float* dst, const f32x4* __restrict__ src, int n4, int tid) {
+    for (int base = 0; base < n4; base += NT * 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + k * NT + tid;
+            t[k] = src[i < n4 ? i : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + k * NT + tid;
+            if (i < n4) reinterpret_cast<f32x4*>(dst)[i] = t[k];
+        }
+    }
+}
+
 struct WinoIter {   // uniform walk over this workgroup's items: runs of units with equal cout block, chunk-outer
     int u_lo, n, cb, c, k;
     bool valid;
@@ -146,8 +165,8 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino_kernel(ConvArgs a, int til
             if (p_ok[k]) *reinterpret_cast<f32x4*>(tb + (size_t)(tid + k * 512) * 4) = pf[k];
     };
     auto load_weights = [&](int cb, int c) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack_b) + ((size_t)c * n_cb + cb) * (SE_WINO_CHUNK_FLOATS / 4);
-        for (int i = tid; i < SE_WINO_CHUNK_FLOATS / 4; i += 512) reinterpret_cast<f32x4*>(wl)[i] = src[i];
+        fill_lds<512>(wl, reinterpret_cast<const f32x4*>(a.wpack_b) + ((size_t)c * n_cb + cb) * (SE_WINO_CHUNK_FLOATS / 4),
+                      SE_WINO_CHUNK_FLOATS / 4, tid);
     };
     auto first_item = [&]() {
         WinoIter it;
@@ -198,7 +217,8 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino_kernel(ConvArgs a, int til
         const int fetch_u = nxt.valid ? nxt.u_lo + nxt.k : u;      // (re-fetching the current item at the very end is harmless)
         const int fetch_c = nxt.valid ? nxt.c : cur.c;
         const long long o0 = out_offset(u, cur.cb);
-        if (cur.c > 0 && !lone && !(diag & 2)) {
+        if (cur.c > 0 && !(diag & 2)) {
+            if (lone) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // same tile as the previous item: stores first
 #pragma unroll
             for (int z = 0; z < 2; ++z)
 #pragma unroll
@@ -280,11 +300,6 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino_kernel(ConvArgs a, int til
             if (cur.c > 0) {   // partial sums of the previous chunks (from memory, or kept in registers for a lone unit)
                 y0 += part[0][n];
                 y1 += part[1][n];
-            }
-            if (lone && !last_chunk) {   // same tile again next item: keep the running sum in registers, no round trip
-                part[0][n] = y0;
-                part[1][n] = y1;
-                continue;
             }
             if (last_chunk) {
                 const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + cur.cb * 32 + n * 16 + 4 * h);
@@ -415,8 +430,7 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino_kernel(ConvArgs a, int til
         for (int x = 0; x < 8; ++x) *reinterpret_cast<f32x4*>(vt + ((s_zp * 8 + x) * K7_COLS + s_col) * 4) = v[x];
     };
     auto load_weights = [&](int c) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack_d) + (size_t)c * (K7_W_FLOATS / 4);
-        for (int i = tid; i < K7_W_FLOATS / 4; i += 512) reinterpret_cast<f32x4*>(wl)[i] = src[i];
+        fill_lds<512>(wl, reinterpret_cast<const f32x4*>(a.wpack_d) + (size_t)c * (K7_W_FLOATS / 4), K7_W_FLOATS / 4, tid);
     };
     auto out_offset = [&](int k) -> long long {
         const i32x4 e = utab[k];
@@ -445,7 +459,8 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino_kernel(ConvArgs a, int til
         const int k_next = has_next ? (item + 1) - c_next * n : k;
         const bool last_chunk = c == chunks - 1;
         const long long o0 = out_offset(k);
-        if (c > 0 && !lone) {
+        if (c > 0) {
+            if (lone) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // same tile as the previous item: stores first
             part[0] = *reinterpret_cast<const f32x4*>(a.out + o0);
             part[1] = *reinterpret_cast<const f32x4*>(a.out + o0 + zstride);
         }
@@ -498,19 +513,15 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino_kernel(ConvArgs a, int til
             commit();
             if (c_next != c) load_weights(c_next);
         }
-        if (lone && !last_chunk) {
-            part[0] = y0; part[1] = y1;
-        } else {
-            if (last_chunk) {
-                y0 += bias; y1 += bias;
-                if (relu) {
-                    y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
-                    y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
-                }
+        if (last_chunk) {
+            y0 += bias; y1 += bias;
+            if (relu) {
+                y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
+                y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
             }
-            *reinterpret_cast<f32x4*>(a.out + o0) = y0;
-            *reinterpret_cast<f32x4*>(a.out + o0 + zstride) = y1;
         }
+        *reinterpret_cast<f32x4*>(a.out + o0) = y0;        // (source registers are not touched again until the next A^T)
+        *reinterpret_cast<f32x4*>(a.out + o0 + zstride) = y1;
         if (!has_next) break;
         __syncthreads();
     }
@@ -530,8 +541,25 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino_kernel(ConvArgs a, int til
 constexpr int W43_FLOATS = SE_WINO43_CHUNK_FLOATS;
 constexpr int V43_FLOATS = 6 * HY * HX * 16;
 
+#ifdef SE_STAMP43
+#define SE_ST43(IDX)                                                                           \
+    {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        unsigned long long now_;                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        st_acc[IDX] += now_ - st_prev;                                                         \
+        st_prev = now_;                                                                        \
+    }
+#else
+#define SE_ST43(IDX)
+#endif
+
 __global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int tiles_per_dim, int ztiles, int total_tiles,
-                                                               int n_cb, int units_per_wg) {
+                                                               int n_cb, int units_per_wg, unsigned long long* dbg) {
+#ifdef SE_STAMP43
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;
     float* vt = lds + W43_FLOATS;
@@ -600,8 +628,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int t
         for (int x = 0; x < 6; ++x) *reinterpret_cast<f32x4*>(vt + (x * HY * HX + s_col) * 16 + s_q * 4) = v[x];
     };
     auto load_weights = [&](int cb, int c) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack_e) + ((size_t)c * n_cb + cb) * (W43_FLOATS / 4);
-        for (int i = tid; i < W43_FLOATS / 4; i += 512) reinterpret_cast<f32x4*>(wl)[i] = src[i];
+        fill_lds<512>(wl, reinterpret_cast<const f32x4*>(a.wpack_e) + ((size_t)c * n_cb + cb) * (W43_FLOATS / 4), W43_FLOATS / 4, tid);
     };
     auto out_offset = [&](int u, int cb) -> long long {
         const i32x4 e = utab[u - u_begin];
@@ -645,6 +672,9 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int t
 #pragma unroll
     for (int z = 0; z < 4; ++z) part[z] = resv[z] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#ifdef SE_STAMP43
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
     while (true) {
         const WinoIter nxt = next_item(cur);
         const int u = cur.u_lo + cur.k;
@@ -653,7 +683,9 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int t
         const int fetch_u = nxt.valid ? nxt.u_lo + nxt.k : u;
         const int fetch_c = nxt.valid ? nxt.c : cur.c;
         const long long o0 = out_offset(u, cur.cb);
-        if (cur.c > 0 && !lone) {
+        if (cur.c > 0) {
+            // a run of one unit meets the same tile again in the very next item: its stores must have landed first
+            if (lone) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int z = 0; z < 4; ++z) part[z] = *reinterpret_cast<const f32x4*>(a.out + o0 + z * zstride);
         }
@@ -661,11 +693,13 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int t
 #pragma unroll
             for (int z = 0; z < 4; ++z) resv[z] = *reinterpret_cast<const f32x4*>(a.res + o0 + z * zstride);
         }
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + cur.cb * 32 + nt * 16 + 4 * h);   // consumed in the epilogue
 
         f32x4 acc[6];
 #pragma unroll
         for (int x = 0; x < 6; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const f32x4* wrow = reinterpret_cast<const f32x4*>(wl) + nt * 64 + lane;
+        SE_ST43(0)   // setup
         f32x4 wc = wrow[0], vc = *reinterpret_cast<const f32x4*>(vb);
         f32x4 wn = wc, vn = vc;
         auto substep = [&](auto s_tag) {
@@ -687,6 +721,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int t
             vc = vn;
         };
         for_each_index(substep, std::make_integer_sequence<int, 54>{});
+        SE_ST43(1)   // mfma block
 
         // A^T
         f32x4 y[4];
@@ -703,37 +738,45 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int t
         }
         // single V tile: every wave must be done reading it before the next item's columns are committed
         __syncthreads();
+        SE_ST43(2)   // A^T + barrier 1
         if (nxt.valid) {
             commit();
             if (nxt.cb != cur.cb || nxt.c != cur.c) load_weights(nxt.cb, nxt.c);
         }
-        if (lone && !last_chunk) {
+        SE_ST43(3)   // commit
+        // NOTE: the registers holding y must not be written again soon after these stores: hipcc guards a store's
+        // source registers with s_waitcnt vmcnt(0), i.e. the full store latency (measured: 5.7k cycles per item when a
+        // loop-carried copy of y followed the stores).  y is rebuilt from scratch one MFMA block later.
+        if (last_chunk) {
 #pragma unroll
-            for (int z = 0; z < 4; ++z) part[z] = y[z];
-        } else {
-            if (last_chunk) {
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + cur.cb * 32 + nt * 16 + 4 * h);
-#pragma unroll
-                for (int z = 0; z < 4; ++z) {
-                    y[z] += bias;
-                    if (use_res) y[z] += resv[z];
-                    if (relu) {
-                        y[z].x = fmaxf(y[z].x, 0.f); y[z].y = fmaxf(y[z].y, 0.f);
-                        y[z].z = fmaxf(y[z].z, 0.f); y[z].w = fmaxf(y[z].w, 0.f);
-                    }
+            for (int z = 0; z < 4; ++z) {
+                y[z] += bias;
+                if (use_res) y[z] += resv[z];
+                if (relu) {
+                    y[z].x = fmaxf(y[z].x, 0.f); y[z].y = fmaxf(y[z].y, 0.f);
+                    y[z].z = fmaxf(y[z].z, 0.f); y[z].w = fmaxf(y[z].w, 0.f);
                 }
             }
-#pragma unroll
-            for (int z = 0; z < 4; ++z) *reinterpret_cast<f32x4*>(a.out + o0 + z * zstride) = y[z];
         }
+#pragma unroll
+        for (int z = 0; z < 4; ++z) *reinterpret_cast<f32x4*>(a.out + o0 + z * zstride) = y[z];
         if (!nxt.valid) break;
+        SE_ST43(4)   // epilogue
         __syncthreads();
+        SE_ST43(5)   // barrier 2
         cur = nxt;
     }
+#ifdef SE_STAMP43
+    if (lane == 0 && dbg) {
+        unsigned long long* o = dbg + ((size_t)blockIdx.x * 8 + wave) * 6;
+        for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
+    }
+#endif
 }
 
 int g_num_cus_wino = 0;
 unsigned long long* g_wino_dbg = nullptr;
+unsigned long long* g_wino_dbg43 = nullptr;
 
 }  // namespace
 
@@ -780,7 +823,7 @@ int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
         }
         if (per <= MAX43) {
             hipLaunchKernelGGL(conv3d_k3_wino43_kernel, dim3((n_units + per - 1) / per), dim3(512), LDS43, s, a, tiles, ztiles,
-                               total_tiles, n_cb, per);
+                               total_tiles, n_cb, per, g_wino_dbg43);
             SE_CHECK_LAUNCH();
             return 0;
         }
@@ -797,7 +840,13 @@ int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
 }
 
 // Debug only: device buffer (grid * 8 waves * 4 u64) that makes the Winograd kernel run its STAMP build.
-extern "C" void se_debug_set_stamp_buffer(void* p) { g_wino_dbg = reinterpret_cast<unsigned long long*>(p); }
+extern "C" void se_debug_set_stamp_buffer(void* p) {
+#ifdef SE_STAMP43
+    g_wino_dbg43 = reinterpret_cast<unsigned long long*>(p);
+#else
+    g_wino_dbg = reinterpret_cast<unsigned long long*>(p);
+#endif
+}
 
 // Returns 0 on launch, SE_TILED_NOT_TAKEN if not covered, else a hipError_t.
 int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
