@@ -71,6 +71,12 @@ int se_unproject_gather_f32(const float* feat, const int* idx, const float* w, f
 int se_intersection_f32(float* buf, const float* occ, int batch, int voxels, int channels,
                         int stride_c, void* stream);
 
+/* Fused bias (+ residual) (+ ReLU) epilogue for the backbone's MIOpen 2D convolutions (BatchNorm folded into weight
+ * and bias): replaces the bn / `out += residual` / relu element-wise passes of Bottleneck.forward
+ * (network/pose_resnet.py:72-90).  x, residual (or NULL), out: [batch][channels][hw] float32, out may alias x. */
+int se_bias_act_nchw_f32(const float* x, const float* bias, const float* residual, float* out,
+                         int batch, int channels, int hw, int relu, void* stream);
+
 /* Weight preparation: folds an eval-mode BatchNorm3d into the convolution and re-orders the weights
  * into the MFMA fragment order the conv kernels read (v_mfma_f32_16x16x4_f32 A-operand blocks).
  * Replaces nothing at run time in the reference — it is what makes Conv3d+BatchNorm3d(+ReLU)

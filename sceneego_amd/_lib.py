@@ -29,6 +29,7 @@ SIGNATURES = {
     "se_voxelize_full_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _vp]),
     "se_unproject_gather_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "se_intersection_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "se_bias_act_nchw_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_conv3d_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_packed_elems": (_ll, [_i, _i, _i, _i]),
     "se_conv3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
@@ -124,6 +125,16 @@ def intersection(buf, occ, batch, voxels, channels, stride_c):
     _chk_f32(buf, occ)
     _check(load().se_intersection_f32(_ptr(buf), _ptr(occ), batch, voxels, channels, stride_c, _stream()),
            "se_intersection_f32")
+
+
+def bias_act_nchw(x, bias, residual, relu):
+    """In place on ``x`` [N,C,H,W] (contiguous): x = relu?(x + bias[c] (+ residual))."""
+    require_hip(x, bias)
+    _chk_f32(x, bias, residual)
+    n, c, hh, ww = x.shape
+    _check(load().se_bias_act_nchw_f32(_ptr(x), _ptr(bias), _ptr(residual), _ptr(x), n, c, hh * ww, 1 if relu else 0,
+                                       _stream()), "se_bias_act_nchw_f32")
+    return x
 
 
 def conv3d_packed_elems(cout, cin_pad, ksize, transposed) -> int:

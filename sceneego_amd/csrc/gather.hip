@@ -76,3 +76,33 @@ extern "C" int se_intersection_f32(float* buf, const float* occ, int batch, int 
     SE_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// NCHW bias (+ residual) (+ ReLU) epilogue for the MIOpen 2D convolutions of the backbone: one pass instead of the
+// separate bias-add / add / clamp kernels PyTorch issues after F.conv2d (network/pose_resnet.py:52-90 per block).
+// x, res, out: [N][C][HW] float32 (out may alias x); bias [C].  HW % 4 == 0.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void bias_act_kernel(const f32x4* __restrict__ x, const float* __restrict__ bias,
+                                                       const f32x4* __restrict__ res, f32x4* __restrict__ out,
+                                                       long long total4, int hw4, int channels, int relu) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int c = (int)((i / hw4) % channels);
+        f32x4 v = x[i] + bias[c];
+        if (res) v += res[i];
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        out[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int se_bias_act_nchw_f32(const float* x, const float* bias, const float* residual, float* out, int batch,
+                                    int channels, int hw, int relu, void* stream) {
+    if (batch <= 0 || channels <= 0 || hw <= 0 || (hw & 3)) return SE_ERR_BAD_ARG;
+    const long long total4 = (long long)batch * channels * (hw / 4);
+    const unsigned grid = (unsigned)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bias_act_kernel, dim3(grid), dim3(256), 0, se_stream(stream), reinterpret_cast<const f32x4*>(x), bias,
+                       reinterpret_cast<const f32x4*>(residual), reinterpret_cast<f32x4*>(out), total4, hw / 4, channels, relu);
+    SE_CHECK_LAUNCH();
+    return 0;
+}

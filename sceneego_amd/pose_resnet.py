@@ -168,6 +168,8 @@ class FoldedBackbone:
 
     @torch.no_grad()
     def __call__(self, images):
+        if self.dtype == torch.float32 and self.memory_format == torch.contiguous_format and images.is_cuda:
+            return self._call_fused(images)
         x = images.to(self.dtype).contiguous(memory_format=self.memory_format)
         x = F.relu_(F.conv2d(x, self.stem[0], self.stem[1], stride=2, padding=3))
         x = F.max_pool2d(x, 3, stride=2, padding=1)
@@ -179,4 +181,21 @@ class FoldedBackbone:
             x = F.relu_(y.add_(sc))
         for w, b in self.ups:
             x = F.relu_(F.conv_transpose2d(x, w, b, stride=2, padding=1))
+        return x
+
+    def _call_fused(self, images):
+        """fp32 NCHW on a HIP device: MIOpen convolutions WITHOUT bias + one fused HIP epilogue
+        (``se_bias_act_nchw_f32``: bias, residual add, ReLU in a single pass)."""
+        from . import _lib
+        ba = _lib.bias_act_nchw
+        x = ba(F.conv2d(images.contiguous(), self.stem[0], None, stride=2, padding=3), self.stem[1], None, True)
+        x = F.max_pool2d(x, 3, stride=2, padding=1)
+        for c1, c2, c3, stride, ds in self.blocks:
+            y = ba(F.conv2d(x, c1[0]), c1[1], None, True)
+            y = ba(F.conv2d(y, c2[0], None, stride=stride, padding=1), c2[1], None, True)
+            y = F.conv2d(y, c3[0])
+            sc = x if ds is None else ba(F.conv2d(x, ds[0], None, stride=ds[2]), ds[1], None, False)
+            x = ba(y, c3[1], sc, True)
+        for w, b in self.ups:
+            x = ba(F.conv_transpose2d(x, w, None, stride=2, padding=1), b, None, True)
         return x

@@ -313,3 +313,21 @@ def test_softargmax_kat_and_random(oracle_constants, golden):
     lg2[0, 3, 63, 63, 63] = 80.0
     kp4, _ = op.integrate_tensor_3d_with_coordinates(lg2.to(DEV), cv[:2], softmax=True)
     assert float((kp4[0, 3].cpu() - c.coord[63, 63, 63]).abs().max()) < 1e-5
+
+
+def test_bias_act_and_fused_backbone():
+    x = torch.randn(2, 8, 6, 10, device=DEV)
+    b = torch.randn(8, device=DEV)
+    r = torch.randn(2, 8, 6, 10, device=DEV)
+    want = F.relu(x + b.view(1, -1, 1, 1) + r)
+    got = _lib.bias_act_nchw(x.clone(), b, r, True)
+    assert float((got - want).abs().max()) < 1e-6
+    got2 = _lib.bias_act_nchw(x.clone(), b, None, False)
+    assert float((got2 - (x + b.view(1, -1, 1, 1))).abs().max()) < 1e-6
+    from sceneego_amd import pose_resnet
+    net = pose_resnet.get_pose_net(None).to(DEV).eval()
+    img = torch.randn(2, 3, 256, 256, device=DEV)
+    with torch.no_grad():
+        ref = net(img, compute_heatmaps=False)[1]
+        fused = pose_resnet.FoldedBackbone(net)(img)
+    assert float((fused - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-5
