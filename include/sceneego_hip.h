@@ -107,6 +107,13 @@ int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const
                   float* out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
                   float* workspace, long long workspace_elems, void* stream);
 
+/* Fused V2V tail: two 1x1x1 32->32 convs (+BN+ReLU) and the 1x1x1 32->cout3 output layer in one pass
+ * (network/v2v.py:155-161 back_layers.1/.2 + output_layer :161,169).  in [B][D]^3[32]; out planar [B][cout3][D^3];
+ * wpackN / bpackN come from se_conv3d_pack_f32 (ksize 1, cin_pad 32); cout3 <= 16.                           */
+int se_pointwise_chain3_f32(const float* in, const float* wpack1, const float* bpack1,
+                            const float* wpack2, const float* bpack2, const float* wpack3, const float* bpack3,
+                            float* out, int batch, int dim, int cout3, void* stream);
+
 /* ConvTranspose3d(k=2, s=2) + folded BN + ReLU (+ skip).  Replaces Upsample3DBlock and the decoder
  * adds (network/v2v.py:55-67,124-137).  in [B][D]^3[cin] -> out [B][2D]^3[cout]; residual like out. */
 int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const float* bpack, const float* residual,

@@ -33,6 +33,7 @@ SIGNATURES = {
     "se_conv3d_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_packed_elems": (_ll, [_i, _i, _i, _i]),
     "se_conv3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
+    "se_pointwise_chain3_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "se_deconv3d_k2s2_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_maxpool3d_2_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "se_softargmax3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -180,6 +181,13 @@ def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksi
     if _prof is not None:
         e1.record()
         _prof.append((("conv3d", ksize, cin_pad, cout, dim), e0, e1))
+
+
+def pointwise_chain3(inp, pc1, pc2, pc3, out, batch, dim):
+    """back_layers.1 -> back_layers.2 -> output_layer in one launch; pc* are packed 1x1x1 convs (32->32, 32->32, 32->J)."""
+    require_hip(inp, out)
+    _check(load().se_pointwise_chain3_f32(_ptr(inp), _ptr(pc1.w), _ptr(pc1.b), _ptr(pc2.w), _ptr(pc2.b), _ptr(pc3.w),
+                                          _ptr(pc3.b), _ptr(out), batch, dim, pc3.cout, _stream()), "se_pointwise_chain3_f32")
 
 
 def deconv3d_k2s2(inp, wpack, bpack, residual, out, batch, dim, cin, cout, flags):

@@ -304,6 +304,67 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused tail of V2V: back_layers.1, back_layers.2 (1x1x1 32->32 + BN + ReLU each) and output_layer (1x1x1 32->J, planar
+// store) in ONE pass over the 64^3 activations (network/v2v.py:155-161,167-169): 128 B read + 4*J B written per voxel
+// instead of three read+write round trips.  No data movement is needed between the layers: with weights as the MFMA
+// A operand, the D fragment of cout tile nt (lane = voxel, 4 consecutive couts per lane) IS the B-operand fragment of
+// channel group cg = nt of the next layer.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pointwise_chain3_kernel(const float* __restrict__ in, const float* __restrict__ w1,
+                                                               const float* __restrict__ b1, const float* __restrict__ w2,
+                                                               const float* __restrict__ b2, const float* __restrict__ w3,
+                                                               const float* __restrict__ b3, float* __restrict__ out,
+                                                               long long total_vox, long long vox_per_b, int cout3) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int vl = lane & 15, h = lane >> 4;
+    const f32x4* W1 = reinterpret_cast<const f32x4*>(w1) + lane;   // blocks [cg][tap=0][nt][lane]: index (cg*2 + nt)*64
+    const f32x4* W2 = reinterpret_cast<const f32x4*>(w2) + lane;
+    const f32x4* W3 = reinterpret_cast<const f32x4*>(w3) + lane;   // nts = 1: index cg*64
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile * 16 < total_vox; tile += (long long)gridDim.x * 4) {
+        const long long vid = tile * 16 + vl;
+        const bool ok = vid < total_vox;
+        f32x4 x[2], y[2];
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg)
+            x[cg] = ok ? *reinterpret_cast<const f32x4*>(in + vid * 32 + cg * 16 + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#define SE_PW_LAYER(W, B, X, Y)                                                                 \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                          \
+        f32x4 acc = *reinterpret_cast<const f32x4*>(B + nt * 16 + 4 * h);                       \
+        _Pragma("unroll") for (int cg = 0; cg < 2; ++cg) {                                      \
+            const f32x4 wf = W[(cg * 2 + nt) * 64];                                             \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, X[cg].x, acc, 0, 0, 0);            \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, X[cg].y, acc, 0, 0, 0);            \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, X[cg].z, acc, 0, 0, 0);            \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, X[cg].w, acc, 0, 0, 0);            \
+        }                                                                                       \
+        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); \
+        Y[nt] = acc;                                                                            \
+    }
+        SE_PW_LAYER(W1, b1, x, y)
+        SE_PW_LAYER(W2, b2, y, x)
+#undef SE_PW_LAYER
+        f32x4 acc = *reinterpret_cast<const f32x4*>(b3 + 4 * h);
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+            const f32x4 wf = W3[cg * 64];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, x[cg].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, x[cg].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, x[cg].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, x[cg].w, acc, 0, 0, 0);
+        }
+        if (ok) {
+            const long long b = vid / vox_per_b, n = vid - b * vox_per_b;
+            float* o = out + (b * cout3 + 4 * h) * vox_per_b + n;
+            const float vv[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * h + r < cout3) o[(long long)r * vox_per_b] = vv[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // max-pool 2x2x2 stride 2, channels-last, 16 B per lane
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -452,6 +513,20 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
     } else {
         hipLaunchKernelGGL((conv3d_direct_kernel<1, 4, 1, true>), dim3(gx, a.nts, 8), dim3(256), 0, se_stream(stream), a);
     }
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int se_pointwise_chain3_f32(const float* in, const float* wpack1, const float* bpack1, const float* wpack2,
+                                       const float* bpack2, const float* wpack3, const float* bpack3, float* out,
+                                       int batch, int dim, int cout3, void* stream) {
+    if (batch <= 0 || dim <= 0 || cout3 <= 0 || cout3 > 16) return SE_ERR_BAD_ARG;
+    const long long vox_per_b = (long long)dim * dim * dim;
+    const long long total = vox_per_b * batch;
+    const long long tiles = (total + 15) / 16;
+    const unsigned grid = (unsigned)((tiles + 3) / 4 < 8192 ? (tiles + 3) / 4 : 8192);
+    hipLaunchKernelGGL(pointwise_chain3_kernel, dim3(grid), dim3(256), 0, se_stream(stream), in, wpack1, bpack1, wpack2, bpack2,
+                       wpack3, bpack3, out, total, vox_per_b, cout3);
     SE_CHECK_LAUNCH();
     return 0;
 }

@@ -650,7 +650,29 @@ int launch_tiled(const ConvArgs& a, int batch, hipStream_t s) {
 int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s);   // conv3d_wino.hip
 int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s);
 
+static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s);
+
+// The persistent kernels keep a per-workgroup table of their work units in the LDS left over beside weights and tiles
+// (a few hundred entries): large batches are cut into slices of 32 samples, one launch each (weak-scaling config 4 runs
+// 32 samples per GPU, i.e. exactly one slice).
 int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) {
+    constexpr int SLICE = 32;
+    if (batch <= SLICE) return tiled_try_one(a, batch, ksize, s);
+    const long long vox = (long long)a.dim * a.dim * a.dim;
+    for (int b0 = 0; b0 < batch; b0 += SLICE) {
+        const int nb = batch - b0 < SLICE ? batch - b0 : SLICE;
+        ConvArgs sl = a;
+        sl.in = a.in + (long long)b0 * vox * a.cin_pad;
+        sl.out = a.out + (long long)b0 * vox * a.cout;
+        if (a.res) sl.res = a.res + (long long)b0 * vox * a.cout;
+        sl.total_vox = (long long)nb * vox;
+        const int rc = tiled_try_one(sl, nb, ksize, s);
+        if (rc != 0) return rc;   // not taken (same decision for every slice: nothing launched yet) or an error
+    }
+    return 0;
+}
+
+static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s) {
     const int dim = a.dim;
     if (ksize == 3 && (g_variant == 0 || g_variant == 4 || g_variant >= 10)) {   // production: 1-D Winograd persistent kernels
         const int rc = se_conv3d_wino_try(a, batch, s);

@@ -255,10 +255,14 @@ class V2VProgram:
             dim *= 2
         # back layers + output (v2v.py:155-161)
         x = self._res(x, self.back_res, B, G)
-        x = self._conv(x, self.back1, B, G, _lib.EPI_RELU)
-        x = self._conv(x, self.back2, B, G, _lib.EPI_RELU)
         if out is None:
             out = torch.empty((B, self.cout, G * G * G), device=self.device, dtype=torch.float32)
+        if self.cout <= 16:
+            # back_layers.1 / .2 / output_layer fused: one read of x, one planar write of the logits
+            _lib.pointwise_chain3(x, self.back1, self.back2, self.out, out, B, G)
+            return out
+        x = self._conv(x, self.back1, B, G, _lib.EPI_RELU)
+        x = self._conv(x, self.back2, B, G, _lib.EPI_RELU)
         _lib.conv3d(x, self.out.w, self.out.b, None, out, B, G, self.out.cin, self.out.cin_pad, self.out.cout, 1,
                     _lib.EPI_OUT_PLANAR)
         return out

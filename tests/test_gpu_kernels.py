@@ -167,6 +167,7 @@ CONV_CASES = [
     (1, 16, 16, 48, 3, True, True, True),       # N_T = 1 tiled
     (1, 16, 32, 16, 7, True, False, True),      # tiled 7^3, 4-channel chunks / tap lanes
     (2, 24, 48, 16, 7, False, False, True),
+    (34, 16, 32, 32, 3, True, True, True),      # batch > 32: sliced launches of the persistent kernels
 ]
 
 
@@ -331,3 +332,16 @@ def test_bias_act_and_fused_backbone():
         ref = net(img, compute_heatmaps=False)[1]
         fused = pose_resnet.FoldedBackbone(net)(img)
     assert float((fused - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-5
+
+
+def test_pointwise_chain_matches_separate_layers():
+    """Fused back_layers.1/.2 + output_layer (one launch) == the three separate 1x1x1 launches == torch CPU."""
+    c1, c2, c3 = nn.Conv3d(32, 32, 1), nn.Conv3d(32, 32, 1), nn.Conv3d(32, 15, 1)
+    bn1, bn2 = _rand_bn(32, 1), _rand_bn(32, 2)
+    x = torch.from_numpy(synth.normal(3, "x", (2, 32, 8, 8, 8)))
+    with torch.no_grad():
+        want = c3(F.relu(bn2(c2(F.relu(bn1(c1(x)))))))
+    p1, p2, p3 = _PackedConv(c1.to(DEV), bn1.to(DEV)), _PackedConv(c2.to(DEV), bn2.to(DEV)), _PackedConv(c3.to(DEV), None)
+    out = torch.full((2, 15, 512), 3.0, device=DEV)
+    _lib.pointwise_chain3(_ndhwc(x).to(DEV), p1, p2, p3, out, 2, 8)
+    assert float((out.cpu().view(2, 15, 8, 8, 8) - want).abs().max()) < 2e-5

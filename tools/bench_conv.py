@@ -20,6 +20,8 @@ SHAPES = [  # (dim, cin, cin_pad, cout, k)
     (32, 64, 64, 64, 3),
     (32, 32, 32, 64, 3),
     (16, 128, 128, 128, 3),
+    (128, 32, 32, 32, 3),      # BASELINE config 5: 128^3 grid
+    (128, 33, 48, 16, 7),
 ]
 
 
