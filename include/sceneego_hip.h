@@ -49,6 +49,13 @@ int se_voxelize_f64(const float* depth, const double* ray_tab, float* occ,
                     int batch, int depth_h, int depth_w, int up, int pad_x,
                     int volume_size, double cuboid_side, void* stream);
 
+/* Same, writing straight into the V2V input buffer buf [B][G^3][stride_c]: channels [c_offset, c_offset+4) of every voxel
+ * are cleared, then channel c_offset receives the occupancy (replaces torch.stack/unsqueeze/cat,
+ * network/voxel_net_depth.py:256-262, for the with_scene && !with_intersection case).                   */
+int se_voxelize_strided_f64(const float* depth, const double* ray_tab, float* buf,
+                            int batch, int depth_h, int depth_w, int up, int pad_x,
+                            int volume_size, double cuboid_side, int stride_c, int c_offset, void* stream);
+
 /* Same for a full-width depth map without resize/pad: dataset/real_depth_utils.py:29-60
  * (`voxel_output=True` path).  ray_tab [depth_h][depth_w][3] float64 indexed [y][x].            */
 int se_voxelize_full_f64(const float* depth, const double* ray_tab, float* occ,

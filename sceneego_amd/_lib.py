@@ -26,6 +26,7 @@ _vp, _i, _f, _d, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_d
 SIGNATURES = {
     "se_abi_version": (_i, []),
     "se_voxelize_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _vp]),
+    "se_voxelize_strided_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "se_voxelize_full_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _vp]),
     "se_unproject_gather_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "se_intersection_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -103,6 +104,15 @@ def voxelize(depth, ray_tab, occ, batch, depth_h, depth_w, up, pad_x, volume_siz
     assert ray_tab.dtype == torch.float64 and ray_tab.is_contiguous()
     _check(load().se_voxelize_f64(_ptr(depth), _ptr(ray_tab), _ptr(occ), batch, depth_h, depth_w, up, pad_x,
                                   volume_size, float(cuboid_side), _stream()), "se_voxelize_f64")
+
+
+def voxelize_strided(depth, ray_tab, buf, batch, depth_h, depth_w, up, pad_x, volume_size, cuboid_side, stride_c, c_offset):
+    require_hip(depth, ray_tab, buf)
+    _chk_f32(depth, buf)
+    assert ray_tab.dtype == torch.float64 and ray_tab.is_contiguous()
+    _check(load().se_voxelize_strided_f64(_ptr(depth), _ptr(ray_tab), _ptr(buf), batch, depth_h, depth_w, up, pad_x,
+                                          volume_size, float(cuboid_side), stride_c, c_offset, _stream()),
+           "se_voxelize_strided_f64")
 
 
 def voxelize_full(depth, ray_tab, occ, batch, depth_h, depth_w, volume_size, cuboid_side):

@@ -12,7 +12,7 @@
 namespace {
 
 __device__ __forceinline__ void se_splat(double px, double py, double pz, float* __restrict__ occ_b,
-                                          int G, double half_side, double dG, double side) {
+                                          int G, double half_side, double dG, double side, int stride = 1) {
     // (p + side/2) * G / side, evaluated left to right like numpy (voxel_net_depth.py:209-213)
     double qx = ((px + half_side) * dG) / side;
     double qy = ((py + half_side) * dG) / side;
@@ -23,7 +23,7 @@ __device__ __forceinline__ void se_splat(double px, double py, double pz, float*
     const double hi = (double)(G - 1);
     if (qx >= 0.0 && qx <= hi && qy >= 0.0 && qy <= hi && qz >= 0.0 && qz <= hi) {  // :216-218
         const int ix = (int)qx, iy = (int)qy, iz = (int)qz;
-        occ_b[((size_t)ix * G + iy) * G + iz] = 1.0f;  // benign race: every writer stores 1.0f
+        occ_b[(((size_t)ix * G + iy) * G + iz) * stride] = 1.0f;  // benign race: every writer stores 1.0f
     }
 }
 
@@ -32,15 +32,16 @@ __device__ __forceinline__ void se_splat(double px, double py, double pz, float*
 __global__ __launch_bounds__(256) void voxelize_kernel(const float* __restrict__ depth,
                                                        const double* __restrict__ ray_tab,
                                                        float* __restrict__ occ, int depth_h, int depth_w,
-                                                       int up_h, int up_w, int has_pad, int G, double side) {
+                                                       int up_h, int up_w, int has_pad, int G, double side,
+                                                       int stride, int offset) {
     const int b = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
-    float* occ_b = occ + (size_t)b * G * G * G;
+    float* occ_b = occ + (size_t)b * G * G * G * stride + offset;
     const double half_side = side / 2.0;
     const double dG = (double)G;
     if (has_pad && pix == 0) {
         // the zero-padded columns (:198): depth 0 -> point (0,0,0)
-        se_splat(0.0, 0.0, 0.0, occ_b, G, half_side, dG, side);
+        se_splat(0.0, 0.0, 0.0, occ_b, G, half_side, dG, side, stride);
     }
     if (pix >= up_h * up_w) return;
     const int y = pix / up_w;
@@ -52,13 +53,19 @@ __global__ __launch_bounds__(256) void voxelize_kernel(const float* __restrict__
     sx = min(sx, depth_w - 1);
     const double d = (double)depth[((size_t)b * depth_h + sy) * depth_w + sx];
     const double* r = ray_tab + (size_t)pix * 3;
-    se_splat(r[0] * d, r[1] * d, r[2] * d, occ_b, G, half_side, dG, side);
+    se_splat(r[0] * d, r[1] * d, r[2] * d, occ_b, G, half_side, dG, side, stride);
 }
 
 // Clears the occupancy grid.  A kernel rather than hipMemsetAsync: on ROCm 7.2 a memset node captured into a
 // hipGraph from this call replayed with garbage (1e10) in the grid from the second replay on (tools/debug_graph2.py).
 __global__ __launch_bounds__(256) void zero_kernel(f32x4* __restrict__ p, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+// strided form: zero the 4 channels [offset, offset+4) of every voxel record
+__global__ __launch_bounds__(256) void zero_strided_kernel(float* __restrict__ p, size_t voxels, int stride, int offset) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < voxels; i += (size_t)gridDim.x * 256)
+        *reinterpret_cast<f32x4*>(p + i * stride + offset) = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
 int clear_occupancy(float* occ, size_t elems, hipStream_t s) {
@@ -81,7 +88,24 @@ extern "C" int se_voxelize_f64(const float* depth, const double* ray_tab, float*
     if (rc != 0) return rc;
     dim3 grid((up * up + 255) / 256, batch);
     hipLaunchKernelGGL(voxelize_kernel, grid, dim3(256), 0, s, depth, ray_tab, occ, depth_h, depth_w, up, up,
-                       pad_x > 0 ? 1 : 0, volume_size, cuboid_side);
+                       pad_x > 0 ? 1 : 0, volume_size, cuboid_side, 1, 0);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int se_voxelize_strided_f64(const float* depth, const double* ray_tab, float* buf, int batch, int depth_h,
+                                       int depth_w, int up, int pad_x, int volume_size, double cuboid_side,
+                                       int stride_c, int c_offset, void* stream) {
+    if (batch <= 0 || depth_h <= 0 || depth_w <= 0 || up <= 0 || volume_size <= 0 || pad_x < 0) return SE_ERR_BAD_ARG;
+    if ((stride_c & 3) || (c_offset & 3) || c_offset + 4 > stride_c) return SE_ERR_BAD_ARG;
+    hipStream_t s = se_stream(stream);
+    const size_t voxels = (size_t)batch * volume_size * volume_size * volume_size;
+    const unsigned zgrid = (unsigned)((voxels + 255) / 256 < 4096 ? (voxels + 255) / 256 : 4096);
+    hipLaunchKernelGGL(zero_strided_kernel, dim3(zgrid), dim3(256), 0, s, buf, voxels, stride_c, c_offset);
+    SE_CHECK_LAUNCH();
+    dim3 grid((up * up + 255) / 256, batch);
+    hipLaunchKernelGGL(voxelize_kernel, grid, dim3(256), 0, s, depth, ray_tab, buf, depth_h, depth_w, up, up,
+                       pad_x > 0 ? 1 : 0, volume_size, cuboid_side, stride_c, c_offset);
     SE_CHECK_LAUNCH();
     return 0;
 }
@@ -96,7 +120,7 @@ extern "C" int se_voxelize_full_f64(const float* depth, const double* ray_tab, f
     dim3 grid((depth_h * depth_w + 255) / 256, batch);
     // no resize (up == depth size => sy = y, sx = x) and no padding
     hipLaunchKernelGGL(voxelize_kernel, grid, dim3(256), 0, s, depth, ray_tab, occ, depth_h, depth_w, depth_h,
-                       depth_w, 0, volume_size, cuboid_side);
+                       depth_w, 0, volume_size, cuboid_side, 1, 0);
     SE_CHECK_LAUNCH();
     return 0;
 }

@@ -110,11 +110,13 @@ class VoxelNetwork_depth(nn.Module):
         self._folded = None
         self.use_graphs = False
         self._graphs = {}
+        self._xbuf = {}
 
     # ------------------------------------------------------------------------------------------
     def _invalidate(self):
         self._folded = None
         self._graphs = {}
+        self._xbuf = {}
 
     def _load_from_state_dict(self, *a, **k):
         super()._load_from_state_dict(*a, **k)
@@ -242,13 +244,26 @@ class VoxelNetwork_depth(nn.Module):
         # lift to the volume: V2V input buffer [B,G,G,G,cin_pad], zero beyond the real channels
         prog = self.volume_net.program
         C = FEATURE_CHANNELS
-        x = torch.empty((B, G, G, G, prog.cin_pad), device=dev, dtype=torch.float32)
-        if prog.cin_pad > C:
-            x[..., C:].zero_()
+        # V2V input buffer: persistent per batch size, zero-filled once (pad channels stay zero; every call rewrites
+        # the real channels), so no per-call clearing pass is needed
+        xkey = (B, G, prog.cin_pad, str(dev))
+        x = self._xbuf.get(xkey)
+        if x is None:
+            self._xbuf.clear()
+            x = torch.zeros((B, G, G, G, prog.cin_pad), device=dev, dtype=torch.float32)
+            self._xbuf[xkey] = x
         _lib.unproject_gather(feat_nhwc, self._gather_idx, self._gather_w, x, B, feat_nhwc.shape[1] * feat_nhwc.shape[2],
                               C, N, prog.cin_pad, 0)
 
-        if self.with_scene is True:
+        fast_occ = (self.with_scene is True and scene_volumes is None and not self.with_intersection
+                    and prog.cin_pad >= C + 4)
+        if fast_occ:
+            # occupancy straight into channel 32 of the V2V input (channels 33..35 cleared; 36.. are never read: the
+            # 7^3 kernels walk ceil(33/4) = 9 four-channel chunks and the packed weights beyond channel 32 are zero)
+            depth = depth_map_batch.reshape(B, depth_map_batch.shape[-2], depth_map_batch.shape[-1]).float().contiguous()
+            _lib.voxelize_strided(depth, self._ray_tab, x, B, depth.shape[1], depth.shape[2], op.UPSAMPLED, op.PAD_X, G,
+                                  self.cuboid_side, prog.cin_pad, C)
+        elif self.with_scene is True:
             # the reference's scene_volumes branch ignores with_intersection (:246-249); kept
             use_inter = self.with_intersection and scene_volumes is None
             if scene_volumes is not None:

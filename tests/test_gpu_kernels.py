@@ -345,3 +345,17 @@ def test_pointwise_chain_matches_separate_layers():
     out = torch.full((2, 15, 512), 3.0, device=DEV)
     _lib.pointwise_chain3(_ndhwc(x).to(DEV), p1, p2, p3, out, 2, 8)
     assert float((out.cpu().view(2, 15, 8, 8, 8) - want).abs().max()) < 2e-5
+
+
+def test_voxelize_strided_into_v2v_buffer(voxel_setup):
+    """Occupancy written straight into channel 32 of a [B,G^3,48] buffer: bit-exact, channels 33..35 cleared, others untouched."""
+    c, tab = voxel_setup
+    _, depth = synth.make_inputs(21, 2, "floor")
+    buf = torch.full((2, 64 ** 3, 48), 5.0, device=DEV)
+    _lib.voxelize_strided(depth.to(DEV), tab, buf, 2, 1024, 1280, 1024, 128, 64, 2, 48, 32)
+    got = buf.cpu()
+    for b in range(2):
+        want = O.depth_to_voxel(depth[b].numpy(), c.ray, 64, 2).reshape(-1)
+        assert torch.equal(got[b, :, 32], want)
+    assert float(got[..., 33:36].abs().max()) == 0.0
+    assert float(got[..., :32].min()) == 5.0 and float(got[..., 36:].min()) == 5.0
