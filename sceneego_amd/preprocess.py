@@ -10,8 +10,8 @@ Restates ``DemoDataset.__getitem__`` (reference ``dataset/demo_dataset.py:67-98`
 cv2 is not available in this image, so: JPEG decoding uses PIL (libjpeg; may differ from OpenCV's decoder by +-1
 level); the 1024 -> 256 bilinear resize is restated from OpenCV's pixel mapping (src = 4*dst + 1.5: the rounded mean of
 the central 2x2 pixels of every 4x4 block); the nearest resize is ``floor(dst * src / dst_size)``.  These three
-restatements are "parity unpinned" against real OpenCV.  EXR (PIZ-compressed HALF) decoding is not
-implemented yet: depth maps are accepted as ``.npy`` / ``.npz`` arrays; asking for an ``.exr`` raises.
+restatements are "parity unpinned" against real OpenCV.  EXR depth maps (the demo files are
+PIZ-compressed HALF) are decoded by ``sceneego_amd/exr.py``; ``.npy`` / ``.npz`` arrays are accepted too.
 """
 from __future__ import annotations
 
@@ -63,7 +63,7 @@ def normalize_u8(small_bgr_u8: np.ndarray) -> torch.Tensor:
 
 
 def load_depth(path: str) -> np.ndarray:
-    """Depth map in metres as float32 [H,W].  ``.npy`` / ``.npz`` (first array); ``.exr`` is not supported yet."""
+    """Depth map in metres as float32 [H,W]: ``.exr`` (first channel, like cv2's ``[:, :, 0]``), ``.npy`` / ``.npz``."""
     ext = os.path.splitext(path)[1].lower()
     if ext == ".npy":
         d = np.load(path)
@@ -71,9 +71,8 @@ def load_depth(path: str) -> np.ndarray:
         with np.load(path) as z:
             d = z[list(z.keys())[0]]
     elif ext == ".exr":
-        raise NotImplementedError(
-            "OpenEXR (PIZ, HALF) decoding is not implemented in this build yet (no OpenEXR/cv2 in the image); convert the "
-            "depth map to .npy (float16/float32 metres) — see SURVEY.md §8f-1")
+        from .exr import read_depth_exr
+        d = read_depth_exr(path)
     else:
         raise ValueError(f"unsupported depth file {path}")
     if d.ndim == 3:

@@ -49,6 +49,20 @@ def config():
 _SD_CACHE = {}
 
 
+def case_inputs(m):
+    """(image, depth) of a golden case (META.json entry), rebuilt exactly as tools/make_golden.py built them."""
+    from sceneego_amd import synth
+    kind = m["depth_kind"]
+    img, depth = synth.make_inputs(m["input_seed"], m["batch"], "floor" if kind == "demo_exr" else kind)
+    if m["name"].startswith("demo"):        # BASELINE config 1: derived fixture of the reference's demo frame
+        from sceneego_amd.preprocess import normalize_u8
+        img = normalize_u8(np.load(os.path.join(GOLD, "demo", "img_001000_256_bgr_u8.npz"))["img"])[None]
+    if kind == "demo_exr":                  # ... and the reference's own depth map, through sceneego_amd/exr.py
+        from sceneego_amd.preprocess import load_depth, prepare_depth
+        depth = prepare_depth(load_depth(os.path.join(GOLD, "demo", "img_001000.jpg.exr")))[None]
+    return img, depth
+
+
 def synthetic_state_dict(with_intersection=False, seed=0):
     """Synthetic weights for the (33|65)-channel network; cached per session (46 M parameters)."""
     from sceneego_amd import load_config, synth

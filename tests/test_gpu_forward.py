@@ -182,3 +182,26 @@ def test_demo_cli_single_frame(tmp_path, golden, golden_meta):
         pickle.dump(res[0]["predicted_keypoints"], f)
     with open(out_dir / "img_001000.png.pkl", "rb") as f:
         assert pickle.load(f).dtype == np.float32
+
+
+def test_demo_cli_exr_depth(tmp_path, golden):
+    """Config 1 with the reference's own depth map: demo.py reads the PIZ EXR (sceneego_amd/exr.py) next to the frame."""
+    import os
+    import shutil
+    import sys
+    from PIL import Image
+    from conftest import GOLD, ROOT
+    sys.path.insert(0, ROOT)
+    import demo as demo_mod
+    g = golden("demo_exr_b1")
+    small = np.load(os.path.join(GOLD, "demo", "img_001000_256_bgr_u8.npz"))["img"]
+    frame = np.zeros((1024, 1280, 3), dtype=np.uint8)
+    frame[:, 128:-128] = np.repeat(np.repeat(small, 4, axis=0), 4, axis=1)
+    img_dir, depth_dir = tmp_path / "imgs", tmp_path / "depths"
+    img_dir.mkdir(); depth_dir.mkdir()
+    Image.fromarray(frame[:, :, ::-1]).save(img_dir / "img_001000.png")
+    shutil.copy(os.path.join(GOLD, "demo", "img_001000.jpg.exr"), depth_dir / "img_001000.png.exr")
+    d = demo_mod.Demo(load_config(), str(img_dir), str(depth_dir), weights="synthetic")
+    res = d.run()
+    err = float(np.abs(res[0]["predicted_keypoints"] - g["joints"][0]).max())
+    assert err <= JOINT_TOL, err

@@ -12,7 +12,7 @@ import torch
 from oracle import sceneego_oracle as O
 from sceneego_amd import synth
 
-from conftest import synthetic_state_dict
+from conftest import case_inputs, synthetic_state_dict
 
 JOINT_TOL = 2e-5
 
@@ -22,12 +22,7 @@ def _run(case, golden, oracle_constants, meta):
     g = golden(case)
     sd = synthetic_state_dict(m["with_intersection"], m["weight_seed"])
     const = oracle_constants(m["volume_size"])
-    img, depth = synth.make_inputs(m["input_seed"], m["batch"], m["depth_kind"])
-    if case == "demo_b1":   # BASELINE config 1: derived fixture of the reference's demo frame
-        import os
-        from conftest import GOLD
-        from sceneego_amd.preprocess import normalize_u8
-        img = normalize_u8(np.load(os.path.join(GOLD, "demo", "img_001000_256_bgr_u8.npz"))["img"])[None]
+    img, depth = case_inputs(m)
     taps = {}
     joints, big, vols = O.forward(sd, const, img, depth, with_intersection=m["with_intersection"], taps=taps)
     return m, g, joints, vols, taps
@@ -67,6 +62,11 @@ def test_oracle_intersection(golden, oracle_constants, golden_meta):
 def test_oracle_demo_frame(golden, oracle_constants, golden_meta):
     """BASELINE config 1 (demo.py single frame, CPU): real demo image (derived fixture) + synthetic floor depth."""
     _check(*_run("demo_b1", golden, oracle_constants, golden_meta))
+
+
+def test_oracle_demo_frame_with_exr_depth(golden, oracle_constants, golden_meta):
+    """Config 1 with both real inputs: the demo frame and the reference's own depth map decoded by sceneego_amd/exr.py."""
+    _check(*_run("demo_exr_b1", golden, oracle_constants, golden_meta))
 
 
 def test_oracle_g128(golden, oracle_constants, golden_meta):

@@ -109,11 +109,16 @@ def run_case(name, RefNet, cfg_mod, synth, O, *, batch, in_seed, depth_kind, wit
     net = RefNet(config, device="cpu").eval()
     sd = synth.make_state_dict(net.state_dict(), seed=weight_seed)
     net.load_state_dict(sd, strict=True)
-    img, depth = synth.make_inputs(in_seed, batch, depth_kind)
+    img, depth = synth.make_inputs(in_seed, batch, "floor" if depth_kind == "demo_exr" else depth_kind)
     if name == "demo_b1":   # BASELINE config 1: the reference's demo frame (derived fixture) + seeded synthetic depth
         from sceneego_amd.preprocess import normalize_u8
         small = np.load(os.path.join(GOLD, "demo", "img_001000_256_bgr_u8.npz"))["img"]
         img = normalize_u8(small)[None]
+    if name == "demo_exr_b1":   # config 1 with the reference's own depth map, decoded by sceneego_amd/exr.py
+        from sceneego_amd.preprocess import normalize_u8, load_depth, prepare_depth
+        small = np.load(os.path.join(GOLD, "demo", "img_001000_256_bgr_u8.npz"))["img"]
+        img = normalize_u8(small)[None]
+        depth = prepare_depth(load_depth(os.path.join(GOLD, "demo", "img_001000.jpg.exr")))[None]
 
     taps = {}
     hooks = []
@@ -220,11 +225,14 @@ def main():
 
     RefNet, cfg_mod, op_mod = import_reference()
     metas = []
-    if len(sys.argv) > 1 and sys.argv[1] == "--only-demo":
-        m, _ = run_case("demo_b1", RefNet, cfg_mod, synth, O, batch=1, in_seed=1000, depth_kind="floor")
+    if len(sys.argv) > 1 and sys.argv[1] in ("--only-demo", "--only-demo-exr"):
+        if sys.argv[1] == "--only-demo":
+            m, _ = run_case("demo_b1", RefNet, cfg_mod, synth, O, batch=1, in_seed=1000, depth_kind="floor")
+        else:
+            m, _ = run_case("demo_exr_b1", RefNet, cfg_mod, synth, O, batch=1, in_seed=1000, depth_kind="demo_exr")
         with open(os.path.join(GOLD, "META.json")) as f:
             meta = json.load(f)
-        meta["cases"] = [c for c in meta["cases"] if c["name"] != "demo_b1"] + [m]
+        meta["cases"] = [c for c in meta["cases"] if c["name"] != m["name"]] + [m]
         with open(os.path.join(GOLD, "META.json"), "w") as f:
             json.dump(meta, f, indent=1)
         return
@@ -240,6 +248,8 @@ def main():
     m, _ = run_case("b1_g128_floor", RefNet, cfg_mod, synth, O, batch=1, in_seed=555, depth_kind="floor", volume_size=128)
     metas.append(m)
     m, _ = run_case("demo_b1", RefNet, cfg_mod, synth, O, batch=1, in_seed=1000, depth_kind="floor")
+    metas.append(m)
+    m, _ = run_case("demo_exr_b1", RefNet, cfg_mod, synth, O, batch=1, in_seed=1000, depth_kind="demo_exr")
     metas.append(m)
 
     meta = {
