@@ -139,6 +139,52 @@ int se_softargmax3d_f32(const float* vol, const float* coord, float* out_vol, fl
                         float* scratch, int rows, int voxels, int mode, void* stream);
 long long se_softargmax3d_scratch_elems(int rows);
 
+/* ------------------------------------------------------------------------------------------------
+ * bf16-storage V2V (BASELINE config 3): activations and weights bfloat16 in HBM, float32 accumulation on
+ * v_mfma_f32_16x16x32_bf16, float32 bias / BN shift, one round-to-nearest-even to bfloat16 per layer output.
+ * Same reference call sites as the _f32 entry points above; `se_bf16` is the raw 16-bit pattern.
+ * Volumes are channels-last [B][D][D][D][C] with C % 8 == 0 (a lane moves 8 channels = 16 bytes).
+ * ------------------------------------------------------------------------------------------------ */
+typedef unsigned short se_bf16;
+
+/* Weight preparation (BN folded, MFMA A-fragment order [cout tile][k step][lane][8]).  A k step covers 4 groups of
+ * (tap, 8 channels); the group order is [channel chunk of `chunk_octets` x 8 channels][tap][octet] with every chunk
+ * padded to whole k steps.  chunk_octets: 4 for cin_pad % 32 == 0, 2 for cin_pad == 16, 1 for the 7^3 front layer
+ * (cin_pad = 40 / 72), whose taps are stored in the bank-conflict-free pair order of the LDS kernel.
+ * transposed != 0: ConvTranspose3d k2s2 weight [cin][cout][2][2][2], the 8 output parities take the place of taps.
+ * cout % 32 == 0, or cout <= 16 (one tile).  wpack: se_conv3d_packed_elems_bf16(...) elements; bpack: float32,
+ * cout rounded up to 16.                                                                                        */
+int se_conv3d_pack_bf16(const float* w, const float* b, const float* gamma, const float* beta,
+                        const float* mean, const float* var, float eps,
+                        se_bf16* wpack, float* bpack,
+                        int cout, int cin, int cin_pad, int ksize, int transposed, void* stream);
+long long se_conv3d_packed_elems_bf16(int cout, int cin_pad, int ksize, int transposed);
+
+/* Conv3d k = 1, 3 or 7 + folded BN + epilogue (flags as se_conv3d_f32; SE_EPI_OUT_PLANAR is not supported: the
+ * float32 planar logits come from se_pointwise_chain3_bf16).  in [B][D]^3[cin_pad] -> out [B][D]^3[cout].      */
+int se_conv3d_bf16(const se_bf16* in, const se_bf16* wpack, const float* bpack, const se_bf16* residual,
+                   se_bf16* out, int batch, int dim, int cin_pad, int cout, int ksize, int flags, void* stream);
+
+/* V2V tail as se_pointwise_chain3_f32: bfloat16 in [B][D]^3[32], float32 planar logits out [B][cout3][D^3]. */
+int se_pointwise_chain3_bf16(const se_bf16* in, const se_bf16* wpack1, const float* bpack1,
+                             const se_bf16* wpack2, const float* bpack2, const se_bf16* wpack3, const float* bpack3,
+                             float* out, int batch, int dim, int cout3, void* stream);
+
+int se_deconv3d_k2s2_bf16(const se_bf16* in, const se_bf16* wpack, const float* bpack, const se_bf16* residual,
+                          se_bf16* out, int batch, int dim, int cin, int cout, int flags, void* stream);
+int se_maxpool3d_2_bf16(const se_bf16* in, se_bf16* out, int batch, int dim, int channels, void* stream);
+
+/* Producers of the bfloat16 V2V input records: as se_unproject_gather_f32 / se_voxelize_strided_f64
+ * (occupancy 1.0 = 0x3F80; clears the 8 channels [c_offset, c_offset + 8)).  Strides and offsets are in
+ * elements and multiples of 8.  (with_intersection / scene_volumes inputs are assembled in float32 by the
+ * _f32 entry points and converted once.)                                                                     */
+int se_unproject_gather_bf16(const float* feat, const int* idx, const float* w, se_bf16* out,
+                             int batch, int texels, int channels, int voxels, int out_stride_c, int out_c_offset,
+                             void* stream);
+int se_voxelize_strided_bf16(const float* depth, const double* ray_tab, se_bf16* buf, int batch, int depth_h,
+                             int depth_w, int up, int pad_x, int volume_size, double cuboid_side,
+                             int stride_c, int c_offset, void* stream);
+
 /* Debug / benchmarking only: selects alternative kernel variants for A/B timing (0 = production dispatch). */
 void se_debug_set_variant(int variant);
 /* Debug only: u64 device buffer [workgroups][8 waves][4]; non-NULL switches the Winograd conv to its cycle-stamp build. */

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -39,6 +39,14 @@ SIGNATURES = {
     "se_maxpool3d_2_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "se_softargmax3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "se_softargmax3d_scratch_elems": (_ll, [_i]),
+    "se_conv3d_pack_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_conv3d_packed_elems_bf16": (_ll, [_i, _i, _i, _i]),
+    "se_conv3d_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "se_pointwise_chain3_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "se_deconv3d_k2s2_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_maxpool3d_2_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "se_unproject_gather_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "se_voxelize_strided_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "se_debug_set_variant": (None, [_i]),
     "se_debug_set_stamp_buffer": (None, [_vp]),
 }
@@ -108,11 +116,12 @@ def voxelize(depth, ray_tab, occ, batch, depth_h, depth_w, up, pad_x, volume_siz
 
 def voxelize_strided(depth, ray_tab, buf, batch, depth_h, depth_w, up, pad_x, volume_size, cuboid_side, stride_c, c_offset):
     require_hip(depth, ray_tab, buf)
-    _chk_f32(depth, buf)
-    assert ray_tab.dtype == torch.float64 and ray_tab.is_contiguous()
-    _check(load().se_voxelize_strided_f64(_ptr(depth), _ptr(ray_tab), _ptr(buf), batch, depth_h, depth_w, up, pad_x,
-                                          volume_size, float(cuboid_side), stride_c, c_offset, _stream()),
-           "se_voxelize_strided_f64")
+    _chk_f32(depth)
+    assert ray_tab.dtype == torch.float64 and ray_tab.is_contiguous() and buf.is_contiguous()
+    fn = load().se_voxelize_strided_bf16 if buf.dtype == torch.bfloat16 else load().se_voxelize_strided_f64
+    assert buf.dtype in (torch.bfloat16, torch.float32)
+    _check(fn(_ptr(depth), _ptr(ray_tab), _ptr(buf), batch, depth_h, depth_w, up, pad_x,
+              volume_size, float(cuboid_side), stride_c, c_offset, _stream()), "se_voxelize_strided")
 
 
 def voxelize_full(depth, ray_tab, occ, batch, depth_h, depth_w, volume_size, cuboid_side):
@@ -125,10 +134,12 @@ def voxelize_full(depth, ray_tab, occ, batch, depth_h, depth_w, volume_size, cub
 
 def unproject_gather(feat, idx, w, out, batch, texels, channels, voxels, out_stride_c, out_c_offset):
     require_hip(feat, idx, w, out)
-    _chk_f32(feat, w, out)
-    assert idx.dtype == torch.int32 and idx.is_contiguous()
-    _check(load().se_unproject_gather_f32(_ptr(feat), _ptr(idx), _ptr(w), _ptr(out), batch, texels, channels,
-                                          voxels, out_stride_c, out_c_offset, _stream()), "se_unproject_gather_f32")
+    _chk_f32(feat, w)
+    assert idx.dtype == torch.int32 and idx.is_contiguous() and out.is_contiguous()
+    assert out.dtype in (torch.bfloat16, torch.float32)
+    fn = load().se_unproject_gather_bf16 if out.dtype == torch.bfloat16 else load().se_unproject_gather_f32
+    _check(fn(_ptr(feat), _ptr(idx), _ptr(w), _ptr(out), batch, texels, channels,
+              voxels, out_stride_c, out_c_offset, _stream()), "se_unproject_gather")
 
 
 def intersection(buf, occ, batch, voxels, channels, stride_c):
@@ -148,13 +159,23 @@ def bias_act_nchw(x, bias, residual, relu):
     return x
 
 
-def conv3d_packed_elems(cout, cin_pad, ksize, transposed) -> int:
-    return int(load().se_conv3d_packed_elems(cout, cin_pad, ksize, 1 if transposed else 0))
+def conv3d_packed_elems(cout, cin_pad, ksize, transposed, bf16=False) -> int:
+    fn = load().se_conv3d_packed_elems_bf16 if bf16 else load().se_conv3d_packed_elems
+    n = int(fn(cout, cin_pad, ksize, 1 if transposed else 0))
+    if n <= 0:
+        raise HipExtensionError(f"unsupported conv shape cout={cout} cin_pad={cin_pad} k={ksize}")
+    return n
 
 
 def conv3d_pack(w, b, gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_pad, ksize, transposed):
     require_hip(w, wpack, bpack)
-    _chk_f32(w, b, gamma, beta, mean, var, wpack, bpack)
+    _chk_f32(w, b, gamma, beta, mean, var, bpack)
+    if wpack.dtype == torch.bfloat16:
+        _check(load().se_conv3d_pack_bf16(_ptr(w), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), float(eps),
+                                          _ptr(wpack), _ptr(bpack), cout, cin, cin_pad, ksize, 1 if transposed else 0,
+                                          _stream()), "se_conv3d_pack_bf16")
+        return
+    _chk_f32(wpack)
     _check(load().se_conv3d_pack_f32(_ptr(w), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), float(eps),
                                      _ptr(wpack), _ptr(bpack), cout, cin, cin_pad, ksize, 1 if transposed else 0,
                                      _stream()), "se_conv3d_pack_f32")
@@ -185,30 +206,46 @@ def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksi
     if _prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _check(load().se_conv3d_f32(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim, cin,
-                                cin_pad, cout, ksize, flags, _ptr(workspace),
-                                0 if workspace is None else workspace.numel(), _stream()), "se_conv3d_f32")
+    if inp.dtype == torch.bfloat16:
+        assert wpack.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and inp.shape[-1] == cin_pad
+        assert residual is None or residual.dtype == torch.bfloat16
+        _check(load().se_conv3d_bf16(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim,
+                                     cin_pad, cout, ksize, flags, _stream()), "se_conv3d_bf16")
+    else:
+        _check(load().se_conv3d_f32(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim, cin,
+                                    cin_pad, cout, ksize, flags, _ptr(workspace),
+                                    0 if workspace is None else workspace.numel(), _stream()), "se_conv3d_f32")
     if _prof is not None:
         e1.record()
-        _prof.append((("conv3d", ksize, cin_pad, cout, dim), e0, e1))
+        _prof.append((("conv3d" if inp.dtype == torch.float32 else "conv3d_bf16", ksize, cin_pad, cout, dim), e0, e1))
 
 
 def pointwise_chain3(inp, pc1, pc2, pc3, out, batch, dim):
     """back_layers.1 -> back_layers.2 -> output_layer in one launch; pc* are packed 1x1x1 convs (32->32, 32->32, 32->J)."""
     require_hip(inp, out)
+    assert out.dtype == torch.float32
+    if inp.dtype == torch.bfloat16:
+        _check(load().se_pointwise_chain3_bf16(_ptr(inp), _ptr(pc1.w), _ptr(pc1.b), _ptr(pc2.w), _ptr(pc2.b), _ptr(pc3.w),
+                                               _ptr(pc3.b), _ptr(out), batch, dim, pc3.cout, _stream()),
+               "se_pointwise_chain3_bf16")
+        return
     _check(load().se_pointwise_chain3_f32(_ptr(inp), _ptr(pc1.w), _ptr(pc1.b), _ptr(pc2.w), _ptr(pc2.b), _ptr(pc3.w),
                                           _ptr(pc3.b), _ptr(out), batch, dim, pc3.cout, _stream()), "se_pointwise_chain3_f32")
 
 
 def deconv3d_k2s2(inp, wpack, bpack, residual, out, batch, dim, cin, cout, flags):
     require_hip(inp, out)
-    _check(load().se_deconv3d_k2s2_f32(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim,
-                                       cin, cout, flags, _stream()), "se_deconv3d_k2s2_f32")
+    fn = load().se_deconv3d_k2s2_bf16 if inp.dtype == torch.bfloat16 else load().se_deconv3d_k2s2_f32
+    assert out.dtype == inp.dtype and wpack.dtype == inp.dtype and (residual is None or residual.dtype == inp.dtype)
+    _check(fn(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim,
+              cin, cout, flags, _stream()), "se_deconv3d_k2s2")
 
 
 def maxpool3d_2(inp, out, batch, dim, channels):
     require_hip(inp, out)
-    _check(load().se_maxpool3d_2_f32(_ptr(inp), _ptr(out), batch, dim, channels, _stream()), "se_maxpool3d_2_f32")
+    fn = load().se_maxpool3d_2_bf16 if inp.dtype == torch.bfloat16 else load().se_maxpool3d_2_f32
+    assert out.dtype == inp.dtype
+    _check(fn(_ptr(inp), _ptr(out), batch, dim, channels, _stream()), "se_maxpool3d_2")
 
 
 def softargmax3d_scratch_elems(rows) -> int:

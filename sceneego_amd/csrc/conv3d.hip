@@ -406,7 +406,7 @@ int launch_direct(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int se_abi_version(void) { return 3; }
+extern "C" int se_abi_version(void) { return 4; }
 
 static long long packed_elems_a(int cout, int cin_pad, int ksize, int transposed) {
     const long long taps = transposed ? 8 : (long long)ksize * ksize * ksize;

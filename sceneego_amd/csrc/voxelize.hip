@@ -11,7 +11,12 @@
 
 namespace {
 
-__device__ __forceinline__ void se_splat(double px, double py, double pz, float* __restrict__ occ_b,
+template <typename T> __device__ __forceinline__ T se_one();
+template <> __device__ __forceinline__ float se_one<float>() { return 1.0f; }
+template <> __device__ __forceinline__ unsigned short se_one<unsigned short>() { return 0x3F80; }   // bfloat16 1.0
+
+template <typename T>
+__device__ __forceinline__ void se_splat(double px, double py, double pz, T* __restrict__ occ_b,
                                           int G, double half_side, double dG, double side, int stride = 1) {
     // (p + side/2) * G / side, evaluated left to right like numpy (voxel_net_depth.py:209-213)
     double qx = ((px + half_side) * dG) / side;
@@ -23,20 +28,21 @@ __device__ __forceinline__ void se_splat(double px, double py, double pz, float*
     const double hi = (double)(G - 1);
     if (qx >= 0.0 && qx <= hi && qy >= 0.0 && qy <= hi && qz >= 0.0 && qz <= hi) {  // :216-218
         const int ix = (int)qx, iy = (int)qy, iz = (int)qz;
-        occ_b[(((size_t)ix * G + iy) * G + iz) * stride] = 1.0f;  // benign race: every writer stores 1.0f
+        occ_b[(((size_t)ix * G + iy) * G + iz) * stride] = se_one<T>();  // benign race: every writer stores 1.0
     }
 }
 
 // grid: (ceil(up*up/256), B).  Thread = one pixel (y, x') of the resized depth; x' fastest => the
 // ray table (24 B/pixel) and the depth row are read coalesced.
+template <typename T>
 __global__ __launch_bounds__(256) void voxelize_kernel(const float* __restrict__ depth,
                                                        const double* __restrict__ ray_tab,
-                                                       float* __restrict__ occ, int depth_h, int depth_w,
+                                                       T* __restrict__ occ, int depth_h, int depth_w,
                                                        int up_h, int up_w, int has_pad, int G, double side,
                                                        int stride, int offset) {
     const int b = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
-    float* occ_b = occ + (size_t)b * G * G * G * stride + offset;
+    T* occ_b = occ + (size_t)b * G * G * G * stride + offset;
     const double half_side = side / 2.0;
     const double dG = (double)G;
     if (has_pad && pix == 0) {
@@ -62,8 +68,9 @@ __global__ __launch_bounds__(256) void zero_kernel(f32x4* __restrict__ p, size_t
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// strided form: zero the 4 channels [offset, offset+4) of every voxel record
-__global__ __launch_bounds__(256) void zero_strided_kernel(float* __restrict__ p, size_t voxels, int stride, int offset) {
+// strided form: zero 16 bytes (4 float32 / 8 bfloat16 channels) at [offset, ...) of every voxel record
+template <typename T>
+__global__ __launch_bounds__(256) void zero_strided_kernel(T* __restrict__ p, size_t voxels, int stride, int offset) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < voxels; i += (size_t)gridDim.x * 256)
         *reinterpret_cast<f32x4*>(p + i * stride + offset) = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
@@ -87,7 +94,7 @@ extern "C" int se_voxelize_f64(const float* depth, const double* ray_tab, float*
     const int rc = clear_occupancy(occ, (size_t)batch * volume_size * volume_size * volume_size, s);
     if (rc != 0) return rc;
     dim3 grid((up * up + 255) / 256, batch);
-    hipLaunchKernelGGL(voxelize_kernel, grid, dim3(256), 0, s, depth, ray_tab, occ, depth_h, depth_w, up, up,
+    hipLaunchKernelGGL(voxelize_kernel<float>, grid, dim3(256), 0, s, depth, ray_tab, occ, depth_h, depth_w, up, up,
                        pad_x > 0 ? 1 : 0, volume_size, cuboid_side, 1, 0);
     SE_CHECK_LAUNCH();
     return 0;
@@ -101,10 +108,27 @@ extern "C" int se_voxelize_strided_f64(const float* depth, const double* ray_tab
     hipStream_t s = se_stream(stream);
     const size_t voxels = (size_t)batch * volume_size * volume_size * volume_size;
     const unsigned zgrid = (unsigned)((voxels + 255) / 256 < 4096 ? (voxels + 255) / 256 : 4096);
-    hipLaunchKernelGGL(zero_strided_kernel, dim3(zgrid), dim3(256), 0, s, buf, voxels, stride_c, c_offset);
+    hipLaunchKernelGGL(zero_strided_kernel<float>, dim3(zgrid), dim3(256), 0, s, buf, voxels, stride_c, c_offset);
     SE_CHECK_LAUNCH();
     dim3 grid((up * up + 255) / 256, batch);
-    hipLaunchKernelGGL(voxelize_kernel, grid, dim3(256), 0, s, depth, ray_tab, buf, depth_h, depth_w, up, up,
+    hipLaunchKernelGGL(voxelize_kernel<float>, grid, dim3(256), 0, s, depth, ray_tab, buf, depth_h, depth_w, up, up,
+                       pad_x > 0 ? 1 : 0, volume_size, cuboid_side, stride_c, c_offset);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int se_voxelize_strided_bf16(const float* depth, const double* ray_tab, se_bf16* buf, int batch, int depth_h,
+                                        int depth_w, int up, int pad_x, int volume_size, double cuboid_side,
+                                        int stride_c, int c_offset, void* stream) {
+    if (batch <= 0 || depth_h <= 0 || depth_w <= 0 || up <= 0 || volume_size <= 0 || pad_x < 0) return SE_ERR_BAD_ARG;
+    if ((stride_c & 7) || (c_offset & 7) || c_offset + 8 > stride_c) return SE_ERR_BAD_ARG;
+    hipStream_t s = se_stream(stream);
+    const size_t voxels = (size_t)batch * volume_size * volume_size * volume_size;
+    const unsigned zgrid = (unsigned)((voxels + 255) / 256 < 4096 ? (voxels + 255) / 256 : 4096);
+    hipLaunchKernelGGL(zero_strided_kernel<unsigned short>, dim3(zgrid), dim3(256), 0, s, buf, voxels, stride_c, c_offset);
+    SE_CHECK_LAUNCH();
+    dim3 grid((up * up + 255) / 256, batch);
+    hipLaunchKernelGGL(voxelize_kernel<unsigned short>, grid, dim3(256), 0, s, depth, ray_tab, buf, depth_h, depth_w, up, up,
                        pad_x > 0 ? 1 : 0, volume_size, cuboid_side, stride_c, c_offset);
     SE_CHECK_LAUNCH();
     return 0;
@@ -119,7 +143,7 @@ extern "C" int se_voxelize_full_f64(const float* depth, const double* ray_tab, f
     if (rc != 0) return rc;
     dim3 grid((depth_h * depth_w + 255) / 256, batch);
     // no resize (up == depth size => sy = y, sx = x) and no padding
-    hipLaunchKernelGGL(voxelize_kernel, grid, dim3(256), 0, s, depth, ray_tab, occ, depth_h, depth_w, depth_h,
+    hipLaunchKernelGGL(voxelize_kernel<float>, grid, dim3(256), 0, s, depth, ray_tab, occ, depth_h, depth_w, depth_h,
                        depth_w, 0, volume_size, cuboid_side, 1, 0);
     SE_CHECK_LAUNCH();
     return 0;

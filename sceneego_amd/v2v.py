@@ -26,6 +26,10 @@ def _round16(c):
     return (c + 15) // 16 * 16
 
 
+def _round8(c):
+    return (c + 7) // 8 * 8
+
+
 # ------------------------------------------------------------------------------------------------
 # parameter containers (reference key names)
 # ------------------------------------------------------------------------------------------------
@@ -107,9 +111,10 @@ class V2VModel(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     # -- execution ---------------------------------------------------------------------------
-    def compile(self) -> "V2VProgram":
-        """(Re)build the HIP launch program from the current parameters (call after loading weights)."""
-        self._program = V2VProgram(self)
+    def compile(self, dtype=None) -> "V2VProgram":
+        """(Re)build the HIP launch program from the current parameters (call after loading weights).
+        ``dtype``: torch.float32 (default; parity path) or torch.bfloat16 (bf16 storage, float32 accumulation)."""
+        self._program = V2VProgram(self, dtype or getattr(self, "program_dtype", torch.float32))
         return self._program
 
     @property
@@ -131,7 +136,7 @@ class V2VModel(nn.Module):
         _lib.require_hip(x)
         B, C, G = x.shape[0], x.shape[1], x.shape[2]
         prog = self.program
-        buf = torch.zeros((B, G, G, G, prog.cin_pad), device=x.device, dtype=torch.float32)
+        buf = torch.zeros((B, G, G, G, prog.cin_pad), device=x.device, dtype=prog.dtype)
         buf[..., :C] = x.permute(0, 2, 3, 4, 1)
         logits = prog.run(buf, B, G)
         return logits.view(B, self.output_channels, G, G, G)
@@ -143,7 +148,7 @@ class V2VModel(nn.Module):
 class _PackedConv:
     __slots__ = ("w", "b", "cin", "cin_pad", "cout", "k", "transposed")
 
-    def __init__(self, conv, bn, cin_pad=None):
+    def __init__(self, conv, bn, cin_pad=None, dtype=torch.float32):
         transposed = isinstance(conv, nn.ConvTranspose3d)
         w = conv.weight.detach().float().contiguous()
         dev = w.device
@@ -153,10 +158,11 @@ class _PackedConv:
         else:
             cout, cin = w.shape[0], w.shape[1]
             k = w.shape[2]
-        self.cin_pad = cin_pad if cin_pad is not None else _round16(cin)
+        bf16 = dtype == torch.bfloat16
+        self.cin_pad = cin_pad if cin_pad is not None else (_round8(cin) if bf16 else _round16(cin))
         self.cin, self.cout, self.k, self.transposed = cin, cout, k, transposed
-        n = _lib.conv3d_packed_elems(cout, self.cin_pad, k, transposed)
-        self.w = torch.empty(n, device=dev, dtype=torch.float32)
+        n = _lib.conv3d_packed_elems(cout, self.cin_pad, k, transposed, bf16=bf16)
+        self.w = torch.empty(n, device=dev, dtype=dtype)
         self.b = torch.empty(_round16(cout), device=dev, dtype=torch.float32)
         f = lambda t: None if t is None else t.detach().float().contiguous()
         if bn is not None:
@@ -169,7 +175,9 @@ class _PackedConv:
 
 
 class V2VProgram:
-    def __init__(self, model: V2VModel):
+    def __init__(self, model: V2VModel, dtype=torch.float32):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.dtype = dtype
         p = next(model.parameters())
         if not p.is_cuda:
             raise _lib.HipExtensionError("V2VModel must live on a HIP device to be compiled (got %s)" % p.device)
@@ -177,9 +185,9 @@ class V2VProgram:
         self.device = p.device
         self.cout = model.output_channels
         self.cin = model.input_channels
-        self.cin_pad = _round16(self.cin)
+        self.cin_pad = _round8(self.cin) if dtype == torch.bfloat16 else _round16(self.cin)
         fl, ed, bl = model.front_layers, model.encoder_decoder, model.back_layers
-        basic = lambda m, cin_pad=None: _PackedConv(m.block[0], m.block[1], cin_pad)
+        basic = lambda m, cin_pad=None: _PackedConv(m.block[0], m.block[1], cin_pad, dtype)
         self.front0 = basic(fl[0], self.cin_pad)
         self.front_res = [self._pack_res(fl[i]) for i in (1, 2, 3)]
         self.enc = [self._pack_res(getattr(ed, f"encoder_res{k}")) for k in range(1, 6)]
@@ -190,20 +198,19 @@ class V2VProgram:
         self.back_res = self._pack_res(bl[0])
         self.back1 = basic(bl[1])
         self.back2 = basic(bl[2])
-        self.out = _PackedConv(model.output_layer, None)
+        self.out = _PackedConv(model.output_layer, None, None, dtype)
         # scratch for the split-K path of the small pyramid levels (se_conv3d_f32 workspace): 32 Mi floats
-        self.workspace = torch.empty(32 << 20, device=self.device, dtype=torch.float32)
+        self.workspace = torch.empty(32 << 20, device=self.device, dtype=torch.float32) if dtype == torch.float32 else None
 
-    @staticmethod
-    def _pack_res(m):
-        c1 = _PackedConv(m.res_branch[0], m.res_branch[1])
-        c2 = _PackedConv(m.res_branch[3], m.res_branch[4])
-        sk = _PackedConv(m.skip_con[0], m.skip_con[1]) if len(m.skip_con) else None
+    def _pack_res(self, m):
+        c1 = _PackedConv(m.res_branch[0], m.res_branch[1], None, self.dtype)
+        c2 = _PackedConv(m.res_branch[3], m.res_branch[4], None, self.dtype)
+        sk = _PackedConv(m.skip_con[0], m.skip_con[1], None, self.dtype) if len(m.skip_con) else None
         return (c1, c2, sk)
 
     # -- primitive launches ------------------------------------------------------------------
     def _new(self, B, dim, c):
-        return torch.empty((B, dim, dim, dim, c), device=self.device, dtype=torch.float32)
+        return torch.empty((B, dim, dim, dim, c), device=self.device, dtype=self.dtype)
 
     def _conv(self, x, pc, B, dim, flags, residual=None, out=None):
         if out is None:
@@ -232,7 +239,7 @@ class V2VProgram:
     # -- the network -------------------------------------------------------------------------
     def run(self, x, B, G, out=None):
         """x: [B,G,G,G,cin_pad] channels-last (channels >= cin zero) -> planar logits [B,cout,G^3]."""
-        assert x.shape[-1] == self.cin_pad and x.is_contiguous()
+        assert x.shape[-1] == self.cin_pad and x.is_contiguous() and x.dtype == self.dtype
         if G % 32:
             raise ValueError("volume_size must be a multiple of 32 (five 2x max-pools), got %d" % G)
         x = self._conv(x, self.front0, B, G, _lib.EPI_RELU)

@@ -111,6 +111,19 @@ class VoxelNetwork_depth(nn.Module):
         self.use_graphs = False
         self._graphs = {}
         self._xbuf = {}
+        # V2V storage type: "fp32" (parity path, default) or "bf16" (BASELINE config 3: bf16 activations/weights,
+        # float32 accumulation; joints differ from the float32 reference by more than 1e-3)
+        self.v2v_dtype = torch.bfloat16 if str(config.model.get("v2v_dtype", "fp32")).lower() in ("bf16", "bfloat16") \
+            else torch.float32
+
+    def set_v2v_dtype(self, dtype):
+        """'fp32' / 'bf16' (or the torch dtypes); takes effect at the next forward."""
+        if isinstance(dtype, str):
+            dtype = torch.bfloat16 if dtype.lower() in ("bf16", "bfloat16") else torch.float32
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.v2v_dtype = dtype
+        self._invalidate()
+        return self
 
     # ------------------------------------------------------------------------------------------
     def _invalidate(self):
@@ -146,7 +159,7 @@ class VoxelNetwork_depth(nn.Module):
         w = pf.weight.detach().to(dtype).contiguous()
         b = pf.bias.detach().to(dtype)
         self._folded = (fb, w, b)
-        self.volume_net.compile()
+        self.volume_net.compile(self.v2v_dtype)
         return self
 
     def _device_tables(self, grid_coord_proj_batch, coord_volumes, device):
@@ -246,17 +259,22 @@ class VoxelNetwork_depth(nn.Module):
         C = FEATURE_CHANNELS
         # V2V input buffer: persistent per batch size, zero-filled once (pad channels stay zero; every call rewrites
         # the real channels), so no per-call clearing pass is needed
-        xkey = (B, G, prog.cin_pad, str(dev))
+        bf16 = prog.dtype == torch.bfloat16
+        fast_occ = (self.with_scene is True and scene_volumes is None and not self.with_intersection
+                    and prog.cin_pad >= C + (8 if bf16 else 4))
+        xkey = (B, G, prog.cin_pad, str(dev), prog.dtype)
         x = self._xbuf.get(xkey)
         if x is None:
             self._xbuf.clear()
-            x = torch.zeros((B, G, G, G, prog.cin_pad), device=dev, dtype=torch.float32)
+            x = torch.zeros((B, G, G, G, prog.cin_pad), device=dev, dtype=prog.dtype)
             self._xbuf[xkey] = x
+        xb = None
+        if bf16 and not fast_occ and self.with_scene is True:
+            # scene_volumes / with_intersection inputs: assembled in float32 by the _f32 operators, rounded once
+            xb, x = x, torch.zeros((B, G, G, G, prog.cin_pad), device=dev, dtype=torch.float32)
         _lib.unproject_gather(feat_nhwc, self._gather_idx, self._gather_w, x, B, feat_nhwc.shape[1] * feat_nhwc.shape[2],
                               C, N, prog.cin_pad, 0)
 
-        fast_occ = (self.with_scene is True and scene_volumes is None and not self.with_intersection
-                    and prog.cin_pad >= C + 4)
         if fast_occ:
             # occupancy straight into channel 32 of the V2V input (channels 33..35 cleared; 36.. are never read: the
             # 7^3 kernels walk ceil(33/4) = 9 four-channel chunks and the packed weights beyond channel 32 are zero)
@@ -276,6 +294,9 @@ class VoxelNetwork_depth(nn.Module):
             else:
                 x[..., C] = occ
 
+        if xb is not None:
+            xb.copy_(x)
+            x = xb
         logits = prog.run(x, B, G)                                               # [B,J,N] planar
         if self.volume_multiplier != 1.0:
             logits = logits * self.volume_multiplier

@@ -1,0 +1,204 @@
+"""GPU: the bf16-storage V2V path (BASELINE config 3) through the C ABI.
+
+Kernel tests compare against plain PyTorch-CPU float32 ops evaluated on the SAME bf16-rounded operands (inputs, folded
+weights), so the only differences are float32 summation order and the single round-to-nearest-even of the output:
+|got - want| <= 2^-8 |want| + 1e-3 * max|want|.  The end-to-end test reports the bf16 joint error against the float32
+reference golden; it is expected to exceed the 1e-3 parity tolerance and is bounded at 3e-2 m.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from sceneego_amd import _lib, load_config, op, synth
+from sceneego_amd.v2v import V2VModel, _PackedConv
+from sceneego_amd.voxel_net_depth import VoxelNetwork_depth
+
+from conftest import case_inputs, synthetic_state_dict
+from test_gpu_kernels import _ncdhw, _ndhwc, _rand_bn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def _r(x):
+    """round a float32 tensor to bf16 values (kept in float32)"""
+    return x.to(BF).float()
+
+
+def _close(got, want, what=""):
+    tol = want.abs() * 2.0 ** -8 + 1e-3 * float(want.abs().max())
+    bad = (got - want).abs() > tol
+    assert not bool(bad.any()), (what, float((got - want).abs().max()), int(bad.sum()))
+
+
+def _folded(conv, bn):
+    """float32 weight/bias after BN folding, weight rounded to bf16 exactly as se_conv3d_pack_bf16 does"""
+    w, b = conv.weight.detach().clone(), conv.bias.detach().clone()
+    transposed = isinstance(conv, nn.ConvTranspose3d)
+    if bn is not None:
+        sc = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        w = w * (sc.view(1, -1, 1, 1, 1) if transposed else sc.view(-1, 1, 1, 1, 1))
+        b = (b - bn.running_mean) * sc + bn.bias
+    return _r(w.detach()), b.detach()
+
+
+CASES = [
+    # (B, dim, cin, cin_pad, cout, k, relu, residual, bn)
+    (2, 8, 16, 16, 32, 3, True, False, True),
+    (1, 16, 32, 32, 32, 3, True, True, True),
+    (2, 32, 32, 32, 32, 3, True, True, True),
+    (1, 64, 32, 32, 32, 3, True, False, True),
+    (1, 32, 16, 16, 32, 3, True, False, True),
+    (2, 16, 64, 64, 64, 3, True, True, True),
+    (1, 32, 32, 32, 64, 3, True, False, True),
+    (1, 16, 128, 128, 128, 3, False, False, True),
+    (3, 4, 64, 64, 64, 3, False, False, True),
+    (8, 2, 128, 128, 128, 3, True, True, True),
+    (2, 8, 128, 128, 128, 3, True, True, True),
+    (2, 8, 16, 16, 32, 1, False, False, True),
+    (1, 16, 32, 32, 64, 1, False, False, True),
+    (1, 8, 64, 64, 128, 1, False, False, True),
+    (1, 8, 33, 40, 16, 7, True, False, True),
+    (2, 16, 33, 40, 16, 7, True, False, True),
+    (1, 32, 33, 40, 16, 7, True, False, True),
+    (1, 16, 65, 72, 16, 7, True, False, True),
+]
+
+
+@pytest.mark.parametrize("B,dim,cin,cin_pad,cout,k,relu,residual,bn", CASES)
+def test_conv3d_bf16_vs_torch(B, dim, cin, cin_pad, cout, k, relu, residual, bn):
+    seed = hash((B, dim, cin, cout, k)) % 1000
+    conv = nn.Conv3d(cin, cout, k, padding=(k - 1) // 2)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(synth.normal(seed, "w", tuple(conv.weight.shape), (2.0 / (cin * k ** 3)) ** 0.5)))
+        conv.bias.copy_(torch.from_numpy(synth.uniform(seed, "cb", (cout,), -0.2, 0.2)))
+    bnm = _rand_bn(cout, seed) if bn else None
+    x = _r(torch.from_numpy(synth.normal(seed, "x", (B, cin, dim, dim, dim))))
+    res = _r(torch.from_numpy(synth.normal(seed, "r", (B, cout, dim, dim, dim)))) if residual else None
+    w, b = _folded(conv, bnm)
+    with torch.no_grad():
+        want = F.conv3d(x, w, b, padding=(k - 1) // 2)
+        if residual:
+            want = want + res
+        if relu:
+            want = F.relu(want)
+    pc = _PackedConv(conv.to(DEV), bnm.to(DEV) if bnm is not None else None, cin_pad, BF)
+    xin = torch.full((B, dim, dim, dim, cin_pad), 3.0, device=DEV, dtype=BF)     # finite garbage in the pad channels
+    xin[..., :cin] = _ndhwc(x).to(DEV).to(BF)
+    out = torch.full((B, dim, dim, dim, cout), -77.0, device=DEV, dtype=BF)
+    flags = (_lib.EPI_RELU if relu else 0) | (_lib.EPI_RES_PRE_RELU if residual else 0)
+    _lib.conv3d(xin, pc.w, pc.b, _ndhwc(res).to(DEV).to(BF) if residual else None, out, B, dim, cin, cin_pad, cout, k, flags)
+    _close(_ncdhw(out.float().cpu()), want)
+
+
+@pytest.mark.parametrize("B,dim,cin,cout,skip", [(2, 4, 128, 128, True), (1, 8, 128, 64, True), (1, 16, 64, 32, False),
+                                                 (8, 1, 128, 128, True)])
+def test_deconv_bf16_vs_torch(B, dim, cin, cout, skip):
+    seed = cin + cout + dim
+    dc = nn.ConvTranspose3d(cin, cout, 2, stride=2)
+    with torch.no_grad():
+        dc.weight.copy_(torch.from_numpy(synth.normal(seed, "w", tuple(dc.weight.shape), (2.0 / cin) ** 0.5)))
+        dc.bias.copy_(torch.from_numpy(synth.uniform(seed, "b", (cout,), -0.2, 0.2)))
+    bnm = _rand_bn(cout, seed)
+    x = _r(torch.from_numpy(synth.normal(seed, "x", (B, cin, dim, dim, dim))))
+    sk = _r(torch.from_numpy(synth.normal(seed, "s", (B, cout, 2 * dim, 2 * dim, 2 * dim)))) if skip else None
+    w, b = _folded(dc, bnm)
+    with torch.no_grad():
+        want = F.relu(F.conv_transpose3d(x, w, b, stride=2))
+        if skip:
+            want = want + sk
+    pc = _PackedConv(dc.to(DEV), bnm.to(DEV), None, BF)
+    out = torch.full((B, 2 * dim, 2 * dim, 2 * dim, cout), -9.0, device=DEV, dtype=BF)
+    _lib.deconv3d_k2s2(_ndhwc(x).to(DEV).to(BF), pc.w, pc.b, _ndhwc(sk).to(DEV).to(BF) if skip else None, out, B, dim, cin,
+                       cout, _lib.EPI_RELU | (_lib.EPI_RES_POST_RELU if skip else 0))
+    _close(_ncdhw(out.float().cpu()), want)
+
+
+def test_maxpool_bf16_exact():
+    x = _r(torch.from_numpy(synth.normal(3, "x", (2, 48, 8, 8, 8))))
+    out = torch.empty((2, 4, 4, 4, 48), device=DEV, dtype=BF)
+    _lib.maxpool3d_2(_ndhwc(x).to(DEV).to(BF), out, 2, 8, 48)
+    assert torch.equal(_ncdhw(out.float().cpu()), F.max_pool3d(x, 2, 2))
+
+
+def test_pointwise_chain_bf16():
+    model = V2VModel(33, 15).eval()
+    sd = synth.make_state_dict(model.state_dict(), seed=3)
+    model.load_state_dict(sd)
+    bl = model.back_layers
+    x = _r(torch.from_numpy(synth.normal(11, "x", (2, 32, 16, 16, 16))).abs())
+    with torch.no_grad():
+        w1, b1 = _folded(bl[1].block[0], bl[1].block[1])
+        w2, b2 = _folded(bl[2].block[0], bl[2].block[1])
+        w3, b3 = _r(model.output_layer.weight.detach()), model.output_layer.bias.detach()
+        h = _r(F.relu(F.conv3d(x, w1, b1)))
+        h = _r(F.relu(F.conv3d(h, w2, b2)))
+        want = F.conv3d(h, w3, b3)
+    model = model.to(DEV)
+    pcs = [_PackedConv(bl[1].block[0], bl[1].block[1], None, BF), _PackedConv(bl[2].block[0], bl[2].block[1], None, BF),
+           _PackedConv(model.output_layer, None, None, BF)]
+    out = torch.full((2, 15, 16 ** 3), -3.0, device=DEV)
+    _lib.pointwise_chain3(_ndhwc(x).to(DEV).to(BF), pcs[0], pcs[1], pcs[2], out, 2, 16)
+    got = out.cpu().view(2, 15, 16, 16, 16)
+    # the two hidden roundings may flip by one bf16 ulp when the float32 sums differ in the last bits: 2^-7 relative
+    assert float((got - want).abs().max()) <= 2.0 ** -6 * float(want.abs().max())
+
+
+def test_gather_and_voxelize_bf16(oracle_constants):
+    c = oracle_constants(64)
+    feat = torch.from_numpy(synth.normal(1, "feat", (2, 32, 64, 64)))
+    idx, w = op.build_gather_table(c.grid, (1024, 1280), 64)
+    f_nhwc = feat.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ref = torch.zeros((2, 64 ** 3, 48), device=DEV)
+    _lib.unproject_gather(f_nhwc, idx.to(DEV), w.to(DEV), ref, 2, 4096, 32, 64 ** 3, 48, 0)
+    out = torch.full((2, 64 ** 3, 40), -5.0, device=DEV, dtype=BF)
+    _lib.unproject_gather(f_nhwc, idx.to(DEV), w.to(DEV), out, 2, 4096, 32, 64 ** 3, 40, 0)
+    assert torch.equal(out[..., :32], ref[..., :32].to(BF))                 # float32 gather rounded once
+    assert float(out[..., 32:].float().min()) == -5.0
+    # occupancy channel: identical voxel set to the float32 voxeliser
+    tab = torch.from_numpy(op.build_voxelizer_ray_table(c.ray, 1280, 1024)).to(DEV)
+    _, depth = synth.make_inputs(5, 2, "floor")
+    occ = torch.empty((2, 64, 64, 64), device=DEV)
+    _lib.voxelize(depth.to(DEV), tab, occ, 2, 1024, 1280, op.UPSAMPLED, op.PAD_X, 64, 2.0)
+    _lib.voxelize_strided(depth.to(DEV), tab, out, 2, 1024, 1280, op.UPSAMPLED, op.PAD_X, 64, 2.0, 40, 32)
+    assert torch.equal(out[..., 32].float().view(2, 64, 64, 64), occ)
+    assert float(out[..., 33:].float().abs().max()) == 0.0
+    assert torch.equal(out[..., :32], ref[..., :32].to(BF))                 # feature channels untouched
+
+
+def test_bad_arguments_bf16():
+    lib = _lib.load()
+    assert lib.se_conv3d_packed_elems_bf16(48, 32, 3, 0) == -1               # cout neither <= 16 nor a multiple of 32
+    assert lib.se_conv3d_packed_elems_bf16(32, 12, 3, 0) == -1               # cin_pad not a multiple of 8
+    assert lib.se_conv3d_bf16(None, None, None, None, None, 1, 8, 32, 32, 5, 0, None) == -1
+    assert lib.se_conv3d_bf16(None, None, None, None, None, 1, 8, 32, 32, 3, _lib.EPI_OUT_PLANAR, None) == -1
+    assert lib.se_maxpool3d_2_bf16(None, None, 1, 8, 12, None) == -1
+
+
+# ------------------------------------------------------------------------------------------------
+# end to end
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["b2_uniform", "b1_intersection"])
+def test_forward_bf16_error_against_reference(case, golden, golden_meta):
+    m = next(c for c in golden_meta["cases"] if c["name"] == case)
+    g = golden(case)
+    cfg = load_config()
+    cfg.model.with_intersection = m["with_intersection"]
+    cfg.model.v2v_dtype = "bf16"
+    net = VoxelNetwork_depth(cfg, device="cpu")
+    net.load_state_dict(synthetic_state_dict(m["with_intersection"], m["weight_seed"]), strict=True)
+    net = net.to(DEV).eval()
+    img, depth = case_inputs(m)
+    kp, _, vols, _ = net(img.to(DEV), net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth.to(DEV))
+    assert net.volume_net.program.dtype == BF
+    err = float(np.abs(kp.cpu().numpy() - g["joints"]).max())
+    print(f"bf16 V2V joint error vs float32 reference ({case}): {err:.2e} m")
+    assert err < 3e-2, err
+    assert torch.isfinite(vols).all()
+    # switching back to float32 restores parity (weights are re-packed)
+    net.set_v2v_dtype("fp32")
+    kp32, _, _, _ = net(img.to(DEV), net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth.to(DEV))
+    assert float(np.abs(kp32.cpu().numpy() - g["joints"]).max()) <= 3e-4
