@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--depth-kind", default="uniform", choices=["uniform", "floor"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--v2v-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32: BASELINE configs[1] (default, the headline); bf16: configs[2] (bf16 storage, f32 accumulate)")
+    ap.add_argument("--dump-kernel-events", action="store_true", help="per-shape conv launch times to stderr")
     ap.add_argument("--graphs", action="store_true", help="replay the forward as a captured hipGraph (implies --no-kernel-events)")
     return ap.parse_args()
 
@@ -129,6 +132,9 @@ def main():
     net, sd = build_network(args.volume_size, device)
     img, depth = device_inputs(args.batch, rank, device, args.depth_kind)
     G = args.volume_size
+    bf16 = args.v2v_dtype == "bf16"
+    if bf16:
+        net.set_v2v_dtype("bf16")
     if args.graphs:
         args.no_kernel_events = True
         net.enable_graphs(True)
@@ -165,9 +171,9 @@ def main():
                   f"frames/sec VoxelNetDepth forward (256x256 img+depth, {G}^3 grid)",
         "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "bf16 storage + f32 accumulate (V2V), f32 backbone" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": f"batch={args.batch}/GPU synthetic 256x256 image N(0,1) + {args.depth_kind} depth 1024x1280, "
-                               f"{G}^3 grid, 15 joints, fp32 (BASELINE configs[1])",
+                               f"{G}^3 grid, 15 joints, " + ("bf16 V2V (BASELINE configs[2])" if bf16 else "fp32 (BASELINE configs[1])"),
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "volume_size": G,
                    "parallelism": f"dp{world}" + (" + RCCL all_gather of [B,15,3] joints" if world > 1 else ""),
                    "hipgraph": bool(args.graphs)},
@@ -195,6 +201,29 @@ def main():
                       "v2v_tflops": round(stage_tflops, 2) if stage_tflops else None,
                       "v2v_hbm_frac": round(V2V_GB_PER_FRAME.get(G, 0) * args.batch / (conv_ms_per_step * 1e-3) / HBM_PEAK_GBS, 4)
                       if conv_ms_per_step else None,
+                      "conv7_avg_ms": round(sum(k7[0]) / len(k7[0]), 4) if k7 else None},
+        }
+    if args.dump_kernel_events:
+        for k in sorted(prof, key=lambda k: -sum(prof[k])):
+            v = prof[k]
+            print(f"{str(k):44s} {len(v) // args.steps:3d}/step avg {sum(v) / len(v):8.4f} ms  per-step {sum(v) / args.steps:8.4f} ms",
+                  file=sys.stderr)
+    keyb = ("conv3d_bf16", 3, 32, 32, G)
+    if keyb in prof:
+        ms = prof[keyb]
+        avg_ms = sum(ms) / len(ms)
+        nbytes = 2.0 * args.batch * G ** 3 * (32 + 32)           # bf16 input + output records of one launch (skip reads excluded)
+        flop = 2.0 * args.batch * G ** 3 * 27 * 32 * 32
+        conv_ms_per_step = sum(sum(v) for v in prof.values()) / args.steps
+        k7 = [v for k, v in prof.items() if k[1] == 7]
+        line["roofline"] = {
+            "bound": "hbm", "achieved": round(nbytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(nbytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": f"conv3d 3x3x3 32->32 @{G}^3 bf16 storage (v_mfma_f32_16x16x32_bf16), {len(ms) // args.steps} launches/step",
+            "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": nbytes,
+            "mfma_tflops": round(flop / (avg_ms * 1e-3) / 1e12, 1), "mfma_frac_of_2500": round(flop / (avg_ms * 1e-3) / 2.5e15, 4),
+            "stage": {"v2v_conv_ms_per_step": round(conv_ms_per_step, 3),
+                      "v2v_hbm_frac": round(0.5 * V2V_GB_PER_FRAME.get(G, 0) * args.batch / (conv_ms_per_step * 1e-3) / HBM_PEAK_GBS, 4),
                       "conv7_avg_ms": round(sum(k7[0]) / len(k7[0]), 4) if k7 else None},
         }
     if world == 1 and not args.no_cpu_baseline:

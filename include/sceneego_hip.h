@@ -149,8 +149,9 @@ typedef unsigned short se_bf16;
 
 /* Weight preparation (BN folded, MFMA A-fragment order [cout tile][k step][lane][8]).  A k step covers 4 groups of
  * (tap, 8 channels); the group order is [channel chunk of `chunk_octets` x 8 channels][tap][octet] with every chunk
- * padded to whole k steps.  chunk_octets: 4 for cin_pad % 32 == 0, 2 for cin_pad == 16, 1 for the 7^3 front layer
- * (cin_pad = 40 / 72), whose taps are stored in the bank-conflict-free pair order of the LDS kernel.
+ * padded to whole k steps.  chunk_octets: 2 for 3^3 convs (cin_pad % 16 == 0); 4 (cin_pad % 32 == 0) or 2 for 1^3 and
+ * transposed convs; 1 for the 7^3 front layer (cin_pad = 40 / 72), whose taps are stored in the bank-conflict-free
+ * pair order of the LDS kernel.
  * transposed != 0: ConvTranspose3d k2s2 weight [cin][cout][2][2][2], the 8 output parities take the place of taps.
  * cout % 32 == 0, or cout <= 16 (one tile).  wpack: se_conv3d_packed_elems_bf16(...) elements; bpack: float32,
  * cout rounded up to 16.                                                                                        */

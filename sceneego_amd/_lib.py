@@ -201,6 +201,28 @@ def stop_profile():
     return out
 
 
+class _timed:
+    """HIP events around one launch when profiling is on (bench.py); a no-op otherwise."""
+
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        if _prof is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _prof is not None and exc[0] is None:
+            self.e1.record()
+            _prof.append((self.key, self.e0, self.e1))
+        return False
+
+
+def _tag(t):
+    return "" if t.dtype == torch.float32 else "_bf16"
+
+
 def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksize, flags, workspace=None):
     require_hip(inp, out)
     if _prof is not None:
@@ -224,28 +246,27 @@ def pointwise_chain3(inp, pc1, pc2, pc3, out, batch, dim):
     """back_layers.1 -> back_layers.2 -> output_layer in one launch; pc* are packed 1x1x1 convs (32->32, 32->32, 32->J)."""
     require_hip(inp, out)
     assert out.dtype == torch.float32
-    if inp.dtype == torch.bfloat16:
-        _check(load().se_pointwise_chain3_bf16(_ptr(inp), _ptr(pc1.w), _ptr(pc1.b), _ptr(pc2.w), _ptr(pc2.b), _ptr(pc3.w),
-                                               _ptr(pc3.b), _ptr(out), batch, dim, pc3.cout, _stream()),
-               "se_pointwise_chain3_bf16")
-        return
-    _check(load().se_pointwise_chain3_f32(_ptr(inp), _ptr(pc1.w), _ptr(pc1.b), _ptr(pc2.w), _ptr(pc2.b), _ptr(pc3.w),
-                                          _ptr(pc3.b), _ptr(out), batch, dim, pc3.cout, _stream()), "se_pointwise_chain3_f32")
+    fn = load().se_pointwise_chain3_bf16 if inp.dtype == torch.bfloat16 else load().se_pointwise_chain3_f32
+    with _timed(("tail" + _tag(inp), 1, 32, pc3.cout, dim)):
+        _check(fn(_ptr(inp), _ptr(pc1.w), _ptr(pc1.b), _ptr(pc2.w), _ptr(pc2.b), _ptr(pc3.w),
+                  _ptr(pc3.b), _ptr(out), batch, dim, pc3.cout, _stream()), "se_pointwise_chain3")
 
 
 def deconv3d_k2s2(inp, wpack, bpack, residual, out, batch, dim, cin, cout, flags):
     require_hip(inp, out)
     fn = load().se_deconv3d_k2s2_bf16 if inp.dtype == torch.bfloat16 else load().se_deconv3d_k2s2_f32
     assert out.dtype == inp.dtype and wpack.dtype == inp.dtype and (residual is None or residual.dtype == inp.dtype)
-    _check(fn(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim,
-              cin, cout, flags, _stream()), "se_deconv3d_k2s2")
+    with _timed(("deconv" + _tag(inp), 2, cin, cout, dim)):
+        _check(fn(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim,
+                  cin, cout, flags, _stream()), "se_deconv3d_k2s2")
 
 
 def maxpool3d_2(inp, out, batch, dim, channels):
     require_hip(inp, out)
     fn = load().se_maxpool3d_2_bf16 if inp.dtype == torch.bfloat16 else load().se_maxpool3d_2_f32
     assert out.dtype == inp.dtype
-    _check(fn(_ptr(inp), _ptr(out), batch, dim, channels, _stream()), "se_maxpool3d_2")
+    with _timed(("maxpool" + _tag(inp), 2, channels, channels, dim)):
+        _check(fn(_ptr(inp), _ptr(out), batch, dim, channels, _stream()), "se_maxpool3d_2")
 
 
 def softargmax3d_scratch_elems(rows) -> int:

@@ -43,7 +43,10 @@ __host__ __device__ inline PackGeomB pack_geom_b(int cout, int cin_pad, int ksiz
     PackGeomB p;
     const int octs = cin_pad / 8;
     p.taps = transposed ? 8 : ksize * ksize * ksize;
-    p.oc = (!transposed && ksize == 7) ? 1 : (octs % 4 == 0 ? 4 : (octs % 2 == 0 ? 2 : 1));
+    // 3^3: 16-channel chunks (one k step = 2 taps x 2 octets) keep the LDS tile of conv_bf16_k3_kernel at 62 KB
+    p.oc = (!transposed && ksize == 7) ? 1
+         : (!transposed && ksize == 3) ? (octs % 2 == 0 ? 2 : 1)
+         : (octs % 4 == 0 ? 4 : (octs % 2 == 0 ? 2 : 1));
     p.nchunk = octs / p.oc;
     p.kpc = (!transposed && ksize == 7) ? SE_K7B_KPC : (p.taps * p.oc + 3) / 4;
     p.ksteps = p.nchunk * p.kpc;

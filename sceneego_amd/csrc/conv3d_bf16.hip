@@ -330,8 +330,7 @@ extern "C" int se_conv3d_bf16(const se_bf16* in, const se_bf16* wpack, const flo
     const bool small = a.total_vox * (cout / 16) < 256 * 4 * 32;
     if (ksize == 7) return pair ? launch_direct_b<7, 1, 2, 2>(a, s) : launch_direct_b<7, 1, 1, 2>(a, s);
     if (ksize == 3) {
-        if (p.oc == 4) return !pair ? launch_direct_b<3, 4, 1, 2>(a, s) : small ? launch_direct_b<3, 4, 2, 1>(a, s) : launch_direct_b<3, 4, 2, 2>(a, s);
-        if (p.oc == 2) return pair ? launch_direct_b<3, 2, 2, 2>(a, s) : launch_direct_b<3, 2, 1, 2>(a, s);
+        if (p.oc == 2) return !pair ? launch_direct_b<3, 2, 1, 2>(a, s) : small ? launch_direct_b<3, 2, 2, 1>(a, s) : launch_direct_b<3, 2, 2, 2>(a, s);
         return pair ? launch_direct_b<3, 1, 2, 2>(a, s) : launch_direct_b<3, 1, 1, 2>(a, s);
     }
     if (p.oc == 4) return pair ? launch_direct_b<1, 4, 2, 4>(a, s) : launch_direct_b<1, 4, 1, 4>(a, s);

@@ -32,18 +32,22 @@ def main():
     ap.add_argument("--variants", default="0,1")
     ap.add_argument("--no-res", action="store_true")
     ap.add_argument("--only", type=int, default=-1, help="index into SHAPES")
+    ap.add_argument("--bf16", action="store_true", help="time se_conv3d_bf16 (bf16 storage) instead")
     args = ap.parse_args()
     lib = _lib.load()
     dev = "cuda:0"
     B = args.batch
     variants = [int(v) for v in args.variants.split(",")]
     ws = torch.empty(32 << 20, device=dev)
+    dt = torch.bfloat16 if args.bf16 else torch.float32
     for dim, cin, cin_pad, cout, k in (SHAPES if args.only < 0 else SHAPES[args.only:args.only + 1]):
+        if args.bf16:
+            cin_pad = (cin + 7) // 8 * 8
         conv = torch.nn.Conv3d(cin, cout, k, padding=(k - 1) // 2).to(dev)
-        pc = _PackedConv(conv, None, cin_pad=cin_pad)
-        x = torch.randn(B, dim, dim, dim, cin_pad, device=dev)
-        res = torch.randn(B, dim, dim, dim, cout, device=dev)
-        out = torch.empty(B, dim, dim, dim, cout, device=dev)
+        pc = _PackedConv(conv, None, cin_pad, dt)
+        x = torch.randn(B, dim, dim, dim, cin_pad, device=dev).to(dt)
+        res = torch.randn(B, dim, dim, dim, cout, device=dev).to(dt)
+        out = torch.empty(B, dim, dim, dim, cout, device=dev, dtype=dt)
         flop = 2.0 * B * dim ** 3 * k ** 3 * cin * cout
         times = {v: [] for v in variants}
         outs = {}
@@ -53,7 +57,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 _lib.conv3d(x, pc.w, pc.b, None if args.no_res else res, out, B, dim, cin, cin_pad, cout, k,
-                            _lib.EPI_RELU | (0 if args.no_res else _lib.EPI_RES_PRE_RELU), ws)
+                            _lib.EPI_RELU | (0 if args.no_res else _lib.EPI_RES_PRE_RELU), None if args.bf16 else ws)
                 e1.record()
                 torch.cuda.synchronize()
                 if r >= 2:
@@ -66,8 +70,9 @@ def main():
         for v in variants:
             t = sorted(times[v])
             med = t[len(t) // 2]
-            diff = float((outs[v] - base).abs().max())
-            msg += f"  v{v}: med {med:.3f} ms min {t[0]:.3f} ({flop / med / 1e9:.1f} TF/s) maxdiff {diff:.2e}"
+            diff = float((outs[v].float() - base.float()).abs().max())
+            gbs = B * dim ** 3 * (cin_pad + cout * (1 if args.no_res else 2)) * x.element_size() / med / 1e6
+            msg += f"  v{v}: med {med:.3f} ms min {t[0]:.3f} ({flop / med / 1e9:.1f} TF/s, {gbs:.0f} GB/s) maxdiff {diff:.2e}"
         print(msg, flush=True)
 
 
