@@ -162,7 +162,9 @@ int se_conv3d_pack_bf16(const float* w, const float* b, const float* gamma, cons
 long long se_conv3d_packed_elems_bf16(int cout, int cin_pad, int ksize, int transposed);
 
 /* Conv3d k = 1, 3 or 7 + folded BN + epilogue (flags as se_conv3d_f32; SE_EPI_OUT_PLANAR is not supported: the
- * float32 planar logits come from se_pointwise_chain3_bf16).  in [B][D]^3[cin_pad] -> out [B][D]^3[cout].      */
+ * float32 planar logits come from se_pointwise_chain3_bf16).  in [B][D]^3[cin_pad] -> out [B][D]^3[cout].
+ * k = 7 (the front layer) reads its input OCTET-PLANAR: in [B][cin_pad/8][D]^3[8] — the layer walks the input one
+ * 8-channel octet at a time, and a channels-last record of 80 B would be fetched five times for 16 B each.      */
 int se_conv3d_bf16(const se_bf16* in, const se_bf16* wpack, const float* bpack, const se_bf16* residual,
                    se_bf16* out, int batch, int dim, int cin_pad, int cout, int ksize, int flags, void* stream);
 
@@ -175,16 +177,16 @@ int se_deconv3d_k2s2_bf16(const se_bf16* in, const se_bf16* wpack, const float* 
                           se_bf16* out, int batch, int dim, int cin, int cout, int flags, void* stream);
 int se_maxpool3d_2_bf16(const se_bf16* in, se_bf16* out, int batch, int dim, int channels, void* stream);
 
-/* Producers of the bfloat16 V2V input records: as se_unproject_gather_f32 / se_voxelize_strided_f64
- * (occupancy 1.0 = 0x3F80; clears the 8 channels [c_offset, c_offset + 8)).  Strides and offsets are in
- * elements and multiples of 8.  (with_intersection / scene_volumes inputs are assembled in float32 by the
- * _f32 entry points and converted once.)                                                                     */
+/* Producers of the bfloat16 V2V input, octet-planar buf [B][octs_total][voxels][8]: as se_unproject_gather_f32 /
+ * se_voxelize_strided_f64.  The gather writes `channels` (% 8) channels starting at channel out_c_offset (% 8); the
+ * voxeliser clears octet c_offset / 8 and writes the occupancy (1.0 = 0x3F80) into channel c_offset (% 8 == 0).
+ * (with_intersection / scene_volumes inputs are assembled in float32 by the _f32 entry points and converted once.) */
 int se_unproject_gather_bf16(const float* feat, const int* idx, const float* w, se_bf16* out,
-                             int batch, int texels, int channels, int voxels, int out_stride_c, int out_c_offset,
+                             int batch, int texels, int channels, int voxels, int octs_total, int out_c_offset,
                              void* stream);
 int se_voxelize_strided_bf16(const float* depth, const double* ray_tab, se_bf16* buf, int batch, int depth_h,
                              int depth_w, int up, int pad_x, int volume_size, double cuboid_side,
-                             int stride_c, int c_offset, void* stream);
+                             int octs_total, int c_offset, void* stream);
 
 /* Debug / benchmarking only: selects alternative kernel variants for A/B timing (0 = production dispatch). */
 void se_debug_set_variant(int variant);

@@ -118,10 +118,15 @@ def voxelize_strided(depth, ray_tab, buf, batch, depth_h, depth_w, up, pad_x, vo
     require_hip(depth, ray_tab, buf)
     _chk_f32(depth)
     assert ray_tab.dtype == torch.float64 and ray_tab.is_contiguous() and buf.is_contiguous()
-    fn = load().se_voxelize_strided_bf16 if buf.dtype == torch.bfloat16 else load().se_voxelize_strided_f64
     assert buf.dtype in (torch.bfloat16, torch.float32)
-    _check(fn(_ptr(depth), _ptr(ray_tab), _ptr(buf), batch, depth_h, depth_w, up, pad_x,
-              volume_size, float(cuboid_side), stride_c, c_offset, _stream()), "se_voxelize_strided")
+    if buf.dtype == torch.bfloat16:     # octet-planar [B][stride_c / 8][N][8]
+        _check(load().se_voxelize_strided_bf16(_ptr(depth), _ptr(ray_tab), _ptr(buf), batch, depth_h, depth_w, up, pad_x,
+                                               volume_size, float(cuboid_side), stride_c // 8, c_offset, _stream()),
+               "se_voxelize_strided_bf16")
+        return
+    _check(load().se_voxelize_strided_f64(_ptr(depth), _ptr(ray_tab), _ptr(buf), batch, depth_h, depth_w, up, pad_x,
+                                          volume_size, float(cuboid_side), stride_c, c_offset, _stream()),
+           "se_voxelize_strided_f64")
 
 
 def voxelize_full(depth, ray_tab, occ, batch, depth_h, depth_w, volume_size, cuboid_side):
@@ -137,9 +142,12 @@ def unproject_gather(feat, idx, w, out, batch, texels, channels, voxels, out_str
     _chk_f32(feat, w)
     assert idx.dtype == torch.int32 and idx.is_contiguous() and out.is_contiguous()
     assert out.dtype in (torch.bfloat16, torch.float32)
-    fn = load().se_unproject_gather_bf16 if out.dtype == torch.bfloat16 else load().se_unproject_gather_f32
-    _check(fn(_ptr(feat), _ptr(idx), _ptr(w), _ptr(out), batch, texels, channels,
-              voxels, out_stride_c, out_c_offset, _stream()), "se_unproject_gather")
+    if out.dtype == torch.bfloat16:     # octet-planar [B][out_stride_c / 8][voxels][8]
+        _check(load().se_unproject_gather_bf16(_ptr(feat), _ptr(idx), _ptr(w), _ptr(out), batch, texels, channels,
+                                               voxels, out_stride_c // 8, out_c_offset, _stream()), "se_unproject_gather_bf16")
+        return
+    _check(load().se_unproject_gather_f32(_ptr(feat), _ptr(idx), _ptr(w), _ptr(out), batch, texels, channels,
+                                          voxels, out_stride_c, out_c_offset, _stream()), "se_unproject_gather_f32")
 
 
 def intersection(buf, occ, batch, voxels, channels, stride_c):
@@ -229,7 +237,8 @@ def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksi
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if inp.dtype == torch.bfloat16:
-        assert wpack.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and inp.shape[-1] == cin_pad
+        assert wpack.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
+        assert inp.shape[-1] == (8 if ksize == 7 else cin_pad)       # the 7^3 layer reads octet-planar input
         assert residual is None or residual.dtype == torch.bfloat16
         _check(load().se_conv3d_bf16(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim,
                                      cin_pad, cout, ksize, flags, _stream()), "se_conv3d_bf16")

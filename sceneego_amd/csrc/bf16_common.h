@@ -27,7 +27,7 @@ __host__ __device__ inline bool se_k7b_slot(int slot, int& dx, int& dy, int& dz)
     const int r = slot - dz * SE_K7B_SLOTS_PER_DZ;
     if (r < 28) { dy = 2 * (r / 7); dx = r % 7; return true; }
     if (r < 49) { dy = 1 + 2 * ((r - 28) / 7); dx = (r - 28) % 7; return true; }
-    dx = dy = 0;
+    dx = 6; dy = 5;   // padding slots alias the last real tap's address (zero weights): keeps the read conflict-free
     return false;
 }
 

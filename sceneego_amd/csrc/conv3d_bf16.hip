@@ -110,7 +110,13 @@ __global__ __launch_bounds__(256) void conv_bf16_direct_kernel(ConvBArgs a) {
                 u16x8 Bf = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (ok) {
                     const long long nb = vox[n] + ((long long)(dx - H) * D + (dy - H)) * D + (dz - H);
-                    Bf = *reinterpret_cast<const u16x8*>(a.in + nb * a.cin_pad + coff);
+                    if (KS == 7) {   // octet-planar input [B][octs][N][8]; OC == 1, so the chunk index is the octet
+                        const long long N = (long long)D * D * D;
+                        const long long bq = nb / N;
+                        Bf = *reinterpret_cast<const u16x8*>(a.in + ((bq * a.nchunk + c) * N + (nb - bq * N)) * 8);
+                    } else {
+                        Bf = *reinterpret_cast<const u16x8*>(a.in + nb * a.cin_pad + coff);
+                    }
                 }
 #pragma unroll
                 for (int m = 0; m < M_T; ++m) acc[m][n] = mfma_bf16(A[m], Bf, acc[m][n]);
@@ -259,13 +265,14 @@ __global__ __launch_bounds__(256) void pointwise_chain3_bf16_kernel(
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_bf16_kernel(const float* __restrict__ feat, const int4* __restrict__ idx,
                                                           const f32x4* __restrict__ w, unsigned short* __restrict__ out,
-                                                          int texels, int octs, int voxels, int out_stride_c,
-                                                          int out_c_offset) {
+                                                          int texels, int octs, int voxels, int octs_total,
+                                                          int oct_offset) {
     const int b = blockIdx.y;
+    // octet-major thread order: the 16-byte records of one octet plane are written contiguously
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int v = (int)(t / octs);
-    const int o = (int)(t - (long long)v * octs);
-    if (v >= voxels) return;
+    const int o = (int)(t / voxels);
+    const int v = (int)(t - (long long)o * voxels);
+    if (o >= octs) return;
     const int4 id = idx[v];
     const f32x4 wt = w[v];
     const int C = octs * 8;
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(256) void gather_bf16_kernel(const float* __restric
     u16x8 r;
     r[0] = f2bf(a0.x); r[1] = f2bf(a0.y); r[2] = f2bf(a0.z); r[3] = f2bf(a0.w);
     r[4] = f2bf(a1.x); r[5] = f2bf(a1.y); r[6] = f2bf(a1.z); r[7] = f2bf(a1.w);
-    *reinterpret_cast<u16x8*>(out + ((size_t)b * voxels + v) * out_stride_c + out_c_offset + o * 8) = r;
+    *reinterpret_cast<u16x8*>(out + (((size_t)b * octs_total + oct_offset + o) * voxels + v) * 8) = r;
 }
 
 }  // namespace
@@ -386,16 +393,16 @@ extern "C" int se_pointwise_chain3_bf16(const se_bf16* in, const se_bf16* wpack1
 }
 
 extern "C" int se_unproject_gather_bf16(const float* feat, const int* idx, const float* w, se_bf16* out, int batch,
-                                        int texels, int channels, int voxels, int out_stride_c, int out_c_offset,
+                                        int texels, int channels, int voxels, int octs_total, int out_c_offset,
                                         void* stream) {
     if (batch <= 0 || texels <= 0 || voxels <= 0 || channels <= 0) return SE_ERR_BAD_ARG;
-    if ((channels & 7) || (out_stride_c & 7) || (out_c_offset & 7) || out_c_offset + channels > out_stride_c)
+    if ((channels & 7) || octs_total <= 0 || (out_c_offset & 7) || out_c_offset < 0 || out_c_offset + channels > octs_total * 8)
         return SE_ERR_BAD_ARG;
     const int octs = channels / 8;
     const long long threads = (long long)voxels * octs;
     dim3 grid((unsigned)((threads + 255) / 256), batch);
     hipLaunchKernelGGL(gather_bf16_kernel, grid, dim3(256), 0, se_stream(stream), feat, reinterpret_cast<const int4*>(idx),
-                       reinterpret_cast<const f32x4*>(w), out, texels, octs, voxels, out_stride_c, out_c_offset);
+                       reinterpret_cast<const f32x4*>(w), out, texels, octs, voxels, octs_total, out_c_offset / 8);
     SE_CHECK_LAUNCH();
     return 0;
 }

@@ -90,6 +90,110 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_k3_kernel(ConvBArgs a, int t
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 7x7x7 front layer, cout = 16, dim % 8 == 0, octet-planar input [B][octs][D^3][8].
+// Workgroup = 4 waves, output tile 8x8x8; wave w owns x in {2w, 2w+1}; its 8 voxel tiles are (x, y pair): a tile's 16
+// columns are 2 y rows x 8 z.  Octet-outer: the LDS holds the 14x14x14 halo of ONE 8-channel octet (16 B / voxel, z pitch
+// 24 voxels) and, double-buffered, the 13 k steps (52 tap slots) of one dz plane of weights; the accumulators stay in
+// registers over all octets.  Tap slots are paired so that lane groups sharing a ds_read_b128 pass read addresses that
+// differ by a multiple of 256 B (bf16_common.h, tools/lds_conflicts_bf16.py: conflict-free).
+// ------------------------------------------------------------------------------------------------
+constexpr int K7_T = 8, K7_H = 14, K7_P = 24;
+constexpr int K7_HALO_BYTES = K7_H * K7_H * K7_P * 16;        // 75264
+constexpr int K7_KPD = SE_K7B_SLOTS_PER_DZ / 4;               // 13 k steps per dz plane
+constexpr int K7_WBUF_BYTES = K7_KPD * 1024;                  // 13312
+constexpr int K7_LDS_BYTES = K7_HALO_BYTES + 2 * K7_WBUF_BYTES;   // 101888
+constexpr int K7_WPIECES = K7_WBUF_BYTES / 16;                // 832
+
+__global__ __launch_bounds__(256) void conv_bf16_k7_kernel(ConvBArgs a, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* halo = lds;
+    unsigned char* wbuf = lds + K7_HALO_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int v = lane & 15, g = lane >> 4;
+    const int D = a.dim;
+    const int octs = a.nchunk;
+    int t = blockIdx.x;
+    const int tz = t % tiles; t /= tiles;
+    const int ty = t % tiles; t /= tiles;
+    const int tx = t % tiles;
+    const int b = t / tiles;
+    const int x0 = tx * K7_T, y0 = ty * K7_T, z0 = tz * K7_T;
+    const long long N = (long long)D * D * D;
+    const unsigned short* inb = a.in + (long long)b * octs * N * 8;
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const unsigned char* lbase = halo + (((2 * w) * K7_H + (v >> 3)) * K7_P + (v & 7)) * 16;
+
+    // weights of phase 0
+    for (int i = tid; i < K7_WPIECES; i += 256)
+        *reinterpret_cast<u16x8*>(wbuf + i * 16) = *reinterpret_cast<const u16x8*>(a.wpack + (size_t)i * 8);
+    int cur = 0;
+    const int phases = octs * 7;
+    for (int c = 0; c < octs; ++c) {
+        __syncthreads();
+        const unsigned short* inc = inb + (long long)c * N * 8;
+        for (int i = tid; i < K7_H * K7_H * K7_H; i += 256) {
+            const int hz = i % K7_H, hy = (i / K7_H) % K7_H, hx = i / (K7_H * K7_H);
+            const int gx = x0 + hx - 3, gy = y0 + hy - 3, gz = z0 + hz - 3;
+            u16x8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+            if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D)
+                val = *reinterpret_cast<const u16x8*>(inc + (((long long)gx * D + gy) * D + gz) * 8);
+            *reinterpret_cast<u16x8*>(halo + ((hx * K7_H + hy) * K7_P + hz) * 16) = val;
+        }
+        __syncthreads();
+        for (int dz = 0; dz < 7; ++dz) {
+            const int ph = c * 7 + dz + 1;
+            const bool has_next = ph < phases;
+            u16x8 pre[4];
+            if (has_next) {
+                const unsigned short* src = a.wpack + (size_t)ph * K7_KPD * 512;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = tid + 256 * j;
+                    if (i < K7_WPIECES) pre[j] = *reinterpret_cast<const u16x8*>(src + (size_t)i * 8);
+                }
+            }
+            const unsigned char* wb = wbuf + cur * K7_WBUF_BYTES + lane * 16;
+            const unsigned char* lz = lbase + dz * 16;
+#pragma unroll 1
+            for (int sl = 0; sl < K7_KPD; ++sl) {
+                int r = 4 * sl + g;
+                r = r > 48 ? 48 : r;                       // padding slots alias the last tap (zero weights)
+                const int r2 = r < 28 ? r : r - 28;
+                const int q7 = r2 / 7;
+                const int dx = r2 - 7 * q7, dy = 2 * q7 + (r < 28 ? 0 : 1);
+                const unsigned char* bp = lz + ((dx * K7_H + dy) * K7_P) * 16;
+                const u16x8 A = lds_read16(wb + sl * 1024);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const u16x8 Bf = lds_read16(bp + (((n >> 2) * K7_H + 2 * (n & 3)) * K7_P) * 16);
+                    acc[n] = mfma_bf16(A, Bf, acc[n]);
+                }
+            }
+            if (has_next) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = tid + 256 * j;
+                    if (i < K7_WPIECES) *reinterpret_cast<u16x8*>(wbuf + (cur ^ 1) * K7_WBUF_BYTES + i * 16) = pre[j];
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int x = x0 + 2 * w + (n >> 2), y = y0 + 2 * (n & 3) + (v >> 3), z = z0 + (v & 7);
+        const long long ovox = (((long long)b * D + x) * D + y) * D + z;
+        epilogue_single_bf16(a, acc[n], ovox, g);
+    }
+}
+
 }  // namespace
 
 int se_conv3d_bf16_tiled_try(const ConvBArgs& a, int batch, int ksize, hipStream_t s) {
@@ -104,6 +208,19 @@ int se_conv3d_bf16_tiled_try(const ConvBArgs& a, int batch, int ksize, hipStream
         const int tx = a.dim / K3_TX, ty = a.dim / K3_TY, tz = a.dim / K3_TZ;
         hipLaunchKernelGGL(conv_bf16_k3_kernel, dim3((unsigned)(batch * tx * ty * tz), a.cout / 32), dim3(256), K3_LDS_BYTES, s,
                            a, tx, ty, tz);
+        SE_CHECK_LAUNCH();
+        return 0;
+    }
+    if (ksize == 7 && a.dim % 8 == 0 && a.cout == 16 && a.kpc == SE_K7B_KPC) {
+        static bool attr_set7 = false;
+        if (!attr_set7) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_k7_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, K7_LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+            attr_set7 = true;
+        }
+        const int tiles = a.dim / K7_T;
+        hipLaunchKernelGGL(conv_bf16_k7_kernel, dim3((unsigned)(batch * tiles * tiles * tiles)), dim3(256), K7_LDS_BYTES, s, a, tiles);
         SE_CHECK_LAUNCH();
         return 0;
     }

@@ -39,10 +39,10 @@ __global__ __launch_bounds__(256) void voxelize_kernel(const float* __restrict__
                                                        const double* __restrict__ ray_tab,
                                                        T* __restrict__ occ, int depth_h, int depth_w,
                                                        int up_h, int up_w, int has_pad, int G, double side,
-                                                       int stride, int offset) {
+                                                       int stride, long long offset, long long batch_stride) {
     const int b = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
-    T* occ_b = occ + (size_t)b * G * G * G * stride + offset;
+    T* occ_b = occ + (size_t)b * batch_stride + offset;
     const double half_side = side / 2.0;
     const double dG = (double)G;
     if (has_pad && pix == 0) {
@@ -70,9 +70,11 @@ __global__ __launch_bounds__(256) void zero_kernel(f32x4* __restrict__ p, size_t
 
 // strided form: zero 16 bytes (4 float32 / 8 bfloat16 channels) at [offset, ...) of every voxel record
 template <typename T>
-__global__ __launch_bounds__(256) void zero_strided_kernel(T* __restrict__ p, size_t voxels, int stride, int offset) {
+__global__ __launch_bounds__(256) void zero_strided_kernel(T* __restrict__ p, size_t voxels, int stride, long long offset,
+                                                           long long batch_stride) {
+    p += (size_t)blockIdx.y * batch_stride + offset;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < voxels; i += (size_t)gridDim.x * 256)
-        *reinterpret_cast<f32x4*>(p + i * stride + offset) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(p + i * stride) = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
 int clear_occupancy(float* occ, size_t elems, hipStream_t s) {
@@ -95,7 +97,7 @@ extern "C" int se_voxelize_f64(const float* depth, const double* ray_tab, float*
     if (rc != 0) return rc;
     dim3 grid((up * up + 255) / 256, batch);
     hipLaunchKernelGGL(voxelize_kernel<float>, grid, dim3(256), 0, s, depth, ray_tab, occ, depth_h, depth_w, up, up,
-                       pad_x > 0 ? 1 : 0, volume_size, cuboid_side, 1, 0);
+                       pad_x > 0 ? 1 : 0, volume_size, cuboid_side, 1, 0LL, (long long)volume_size * volume_size * volume_size);
     SE_CHECK_LAUNCH();
     return 0;
 }
@@ -108,28 +110,31 @@ extern "C" int se_voxelize_strided_f64(const float* depth, const double* ray_tab
     hipStream_t s = se_stream(stream);
     const size_t voxels = (size_t)batch * volume_size * volume_size * volume_size;
     const unsigned zgrid = (unsigned)((voxels + 255) / 256 < 4096 ? (voxels + 255) / 256 : 4096);
-    hipLaunchKernelGGL(zero_strided_kernel<float>, dim3(zgrid), dim3(256), 0, s, buf, voxels, stride_c, c_offset);
+    hipLaunchKernelGGL(zero_strided_kernel<float>, dim3(zgrid), dim3(256), 0, s, buf, voxels, stride_c, (long long)c_offset, 0LL);
     SE_CHECK_LAUNCH();
     dim3 grid((up * up + 255) / 256, batch);
     hipLaunchKernelGGL(voxelize_kernel<float>, grid, dim3(256), 0, s, depth, ray_tab, buf, depth_h, depth_w, up, up,
-                       pad_x > 0 ? 1 : 0, volume_size, cuboid_side, stride_c, c_offset);
+                       pad_x > 0 ? 1 : 0, volume_size, cuboid_side, stride_c, (long long)c_offset,
+                       (long long)volume_size * volume_size * volume_size * stride_c);
     SE_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int se_voxelize_strided_bf16(const float* depth, const double* ray_tab, se_bf16* buf, int batch, int depth_h,
                                         int depth_w, int up, int pad_x, int volume_size, double cuboid_side,
-                                        int stride_c, int c_offset, void* stream) {
+                                        int octs_total, int c_offset, void* stream) {
     if (batch <= 0 || depth_h <= 0 || depth_w <= 0 || up <= 0 || volume_size <= 0 || pad_x < 0) return SE_ERR_BAD_ARG;
-    if ((stride_c & 7) || (c_offset & 7) || c_offset + 8 > stride_c) return SE_ERR_BAD_ARG;
+    if (octs_total <= 0 || (c_offset & 7) || c_offset < 0 || c_offset / 8 >= octs_total) return SE_ERR_BAD_ARG;
     hipStream_t s = se_stream(stream);
-    const size_t voxels = (size_t)batch * volume_size * volume_size * volume_size;
-    const unsigned zgrid = (unsigned)((voxels + 255) / 256 < 4096 ? (voxels + 255) / 256 : 4096);
-    hipLaunchKernelGGL(zero_strided_kernel<unsigned short>, dim3(zgrid), dim3(256), 0, s, buf, voxels, stride_c, c_offset);
+    // octet-planar [B][octs_total][N][8]: the occupancy plane is octet c_offset / 8, lane 0 of every 16-byte record
+    const long long N = (long long)volume_size * volume_size * volume_size;
+    const long long plane = (long long)(c_offset / 8) * N * 8, bstride = (long long)octs_total * N * 8;
+    const unsigned zgrid = (unsigned)((N + 255) / 256 < 4096 ? (N + 255) / 256 : 4096);
+    hipLaunchKernelGGL(zero_strided_kernel<unsigned short>, dim3(zgrid, batch), dim3(256), 0, s, buf, (size_t)N, 8, plane, bstride);
     SE_CHECK_LAUNCH();
     dim3 grid((up * up + 255) / 256, batch);
     hipLaunchKernelGGL(voxelize_kernel<unsigned short>, grid, dim3(256), 0, s, depth, ray_tab, buf, depth_h, depth_w, up, up,
-                       pad_x > 0 ? 1 : 0, volume_size, cuboid_side, stride_c, c_offset);
+                       pad_x > 0 ? 1 : 0, volume_size, cuboid_side, 8, plane, bstride);
     SE_CHECK_LAUNCH();
     return 0;
 }
@@ -144,7 +149,7 @@ extern "C" int se_voxelize_full_f64(const float* depth, const double* ray_tab, f
     dim3 grid((depth_h * depth_w + 255) / 256, batch);
     // no resize (up == depth size => sy = y, sx = x) and no padding
     hipLaunchKernelGGL(voxelize_kernel<float>, grid, dim3(256), 0, s, depth, ray_tab, occ, depth_h, depth_w, depth_h,
-                       depth_w, 0, volume_size, cuboid_side, 1, 0);
+                       depth_w, 0, volume_size, cuboid_side, 1, 0LL, (long long)volume_size * volume_size * volume_size);
     SE_CHECK_LAUNCH();
     return 0;
 }

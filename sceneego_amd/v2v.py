@@ -138,8 +138,16 @@ class V2VModel(nn.Module):
         prog = self.program
         buf = torch.zeros((B, G, G, G, prog.cin_pad), device=x.device, dtype=prog.dtype)
         buf[..., :C] = x.permute(0, 2, 3, 4, 1)
+        if prog.dtype == torch.bfloat16:
+            buf = channels_last_to_octet_planar(buf)
         logits = prog.run(buf, B, G)
         return logits.view(B, self.output_channels, G, G, G)
+
+
+def channels_last_to_octet_planar(x):
+    """[B,G,G,G,C] -> [B,C/8,G,G,G,8]: the input layout of the bf16 7^3 front layer (include/sceneego_hip.h)."""
+    B, G, C = x.shape[0], x.shape[1], x.shape[-1]
+    return x.view(B, G, G, G, C // 8, 8).permute(0, 4, 1, 2, 3, 5).contiguous()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -238,8 +246,10 @@ class V2VProgram:
 
     # -- the network -------------------------------------------------------------------------
     def run(self, x, B, G, out=None):
-        """x: [B,G,G,G,cin_pad] channels-last (channels >= cin zero) -> planar logits [B,cout,G^3]."""
-        assert x.shape[-1] == self.cin_pad and x.is_contiguous() and x.dtype == self.dtype
+        """x: [B,G,G,G,cin_pad] channels-last (channels >= cin zero; bf16: octet-planar [B,cin_pad/8,G,G,G,8])
+        -> planar logits [B,cout,G^3]."""
+        assert x.is_contiguous() and x.dtype == self.dtype
+        assert tuple(x.shape) == ((B, self.cin_pad // 8, G, G, G, 8) if self.dtype == torch.bfloat16 else (B, G, G, G, self.cin_pad))
         if G % 32:
             raise ValueError("volume_size must be a multiple of 32 (five 2x max-pools), got %d" % G)
         x = self._conv(x, self.front0, B, G, _lib.EPI_RELU)

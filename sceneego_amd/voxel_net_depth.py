@@ -266,7 +266,8 @@ class VoxelNetwork_depth(nn.Module):
         x = self._xbuf.get(xkey)
         if x is None:
             self._xbuf.clear()
-            x = torch.zeros((B, G, G, G, prog.cin_pad), device=dev, dtype=prog.dtype)
+            shape = (B, prog.cin_pad // 8, G, G, G, 8) if bf16 else (B, G, G, G, prog.cin_pad)   # bf16: octet-planar
+            x = torch.zeros(shape, device=dev, dtype=prog.dtype)
             self._xbuf[xkey] = x
         xb = None
         if bf16 and not fast_occ and self.with_scene is True:
@@ -295,7 +296,7 @@ class VoxelNetwork_depth(nn.Module):
                 x[..., C] = occ
 
         if xb is not None:
-            xb.copy_(x)
+            xb.copy_(x.view(B, G, G, G, prog.cin_pad // 8, 8).permute(0, 4, 1, 2, 3, 5))
             x = xb
         logits = prog.run(x, B, G)                                               # [B,J,N] planar
         if self.volume_multiplier != 1.0:

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from sceneego_amd import _lib, load_config, op, synth
-from sceneego_amd.v2v import V2VModel, _PackedConv
+from sceneego_amd.v2v import V2VModel, _PackedConv, channels_last_to_octet_planar
 from sceneego_amd.voxel_net_depth import VoxelNetwork_depth
 
 from conftest import case_inputs, synthetic_state_dict
@@ -88,6 +88,8 @@ def test_conv3d_bf16_vs_torch(B, dim, cin, cin_pad, cout, k, relu, residual, bn)
     pc = _PackedConv(conv.to(DEV), bnm.to(DEV) if bnm is not None else None, cin_pad, BF)
     xin = torch.full((B, dim, dim, dim, cin_pad), 3.0, device=DEV, dtype=BF)     # finite garbage in the pad channels
     xin[..., :cin] = _ndhwc(x).to(DEV).to(BF)
+    if k == 7:
+        xin = channels_last_to_octet_planar(xin)
     out = torch.full((B, dim, dim, dim, cout), -77.0, device=DEV, dtype=BF)
     flags = (_lib.EPI_RELU if relu else 0) | (_lib.EPI_RES_PRE_RELU if residual else 0)
     _lib.conv3d(xin, pc.w, pc.b, _ndhwc(res).to(DEV).to(BF) if residual else None, out, B, dim, cin, cin_pad, cout, k, flags)
@@ -154,19 +156,21 @@ def test_gather_and_voxelize_bf16(oracle_constants):
     f_nhwc = feat.permute(0, 2, 3, 1).contiguous().to(DEV)
     ref = torch.zeros((2, 64 ** 3, 48), device=DEV)
     _lib.unproject_gather(f_nhwc, idx.to(DEV), w.to(DEV), ref, 2, 4096, 32, 64 ** 3, 48, 0)
-    out = torch.full((2, 64 ** 3, 40), -5.0, device=DEV, dtype=BF)
-    _lib.unproject_gather(f_nhwc, idx.to(DEV), w.to(DEV), out, 2, 4096, 32, 64 ** 3, 40, 0)
-    assert torch.equal(out[..., :32], ref[..., :32].to(BF))                 # float32 gather rounded once
-    assert float(out[..., 32:].float().min()) == -5.0
+    N = 64 ** 3
+    out = torch.full((2, 5, N, 8), -5.0, device=DEV, dtype=BF)              # octet-planar [B][5][N][8]
+    _lib.unproject_gather(f_nhwc, idx.to(DEV), w.to(DEV), out, 2, 4096, 32, N, 40, 0)
+    want = ref[..., :32].to(BF).view(2, N, 4, 8).permute(0, 2, 1, 3)
+    assert torch.equal(out[:, :4], want)                                    # float32 gather rounded once
+    assert float(out[:, 4].float().min()) == -5.0
     # occupancy channel: identical voxel set to the float32 voxeliser
     tab = torch.from_numpy(op.build_voxelizer_ray_table(c.ray, 1280, 1024)).to(DEV)
     _, depth = synth.make_inputs(5, 2, "floor")
     occ = torch.empty((2, 64, 64, 64), device=DEV)
     _lib.voxelize(depth.to(DEV), tab, occ, 2, 1024, 1280, op.UPSAMPLED, op.PAD_X, 64, 2.0)
     _lib.voxelize_strided(depth.to(DEV), tab, out, 2, 1024, 1280, op.UPSAMPLED, op.PAD_X, 64, 2.0, 40, 32)
-    assert torch.equal(out[..., 32].float().view(2, 64, 64, 64), occ)
-    assert float(out[..., 33:].float().abs().max()) == 0.0
-    assert torch.equal(out[..., :32], ref[..., :32].to(BF))                 # feature channels untouched
+    assert torch.equal(out[:, 4, :, 0].float().view(2, 64, 64, 64), occ)
+    assert float(out[:, 4, :, 1:].float().abs().max()) == 0.0
+    assert torch.equal(out[:, :4], want)                                    # feature octets untouched
 
 
 def test_bad_arguments_bf16():

@@ -46,6 +46,8 @@ def main():
         conv = torch.nn.Conv3d(cin, cout, k, padding=(k - 1) // 2).to(dev)
         pc = _PackedConv(conv, None, cin_pad, dt)
         x = torch.randn(B, dim, dim, dim, cin_pad, device=dev).to(dt)
+        if args.bf16 and k == 7:
+            x = x.view(B, cin_pad // 8, dim, dim, dim, 8)        # octet-planar input of the bf16 front layer
         res = torch.randn(B, dim, dim, dim, cout, device=dev).to(dt)
         out = torch.empty(B, dim, dim, dim, cout, device=dev, dtype=dt)
         flop = 2.0 * B * dim ** 3 * k ** 3 * cin * cout
