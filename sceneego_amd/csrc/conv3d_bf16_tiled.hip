@@ -1,4 +1,8 @@
 // LDS-tiled bf16 convolutions for the large V2V levels (see conv3d_bf16.hip for the packer and the direct form).
+//
+// Both kernels stage (halo tile + weight chunk) global -> registers -> LDS with ALL loads of a stage issued before the first
+// LDS store (a load/store-per-iteration loop exposes one global latency per piece), prefetch the NEXT stage into registers
+// while the MFMAs of the current one run, and double-buffer the MFMA operand fragments across k steps.
 #include "bf16_common.h"
 
 #define SE_TILED_NOT_TAKEN_B (-1000)
@@ -6,6 +10,7 @@
 namespace {
 
 __device__ __forceinline__ u16x8 lds_read16(const unsigned char* p) { return *reinterpret_cast<const u16x8*>(p); }
+__device__ __forceinline__ u16x8 zero8() { return (u16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
 
 // ------------------------------------------------------------------------------------------------
 // 3x3x3, dim % 16 == 0, cin % 16 == 0, cout % 32 == 0.
@@ -13,15 +18,41 @@ __device__ __forceinline__ u16x8 lds_read16(const unsigned char* p) { return *re
 // y rows (16 z each), so a lane's B address is   halo[(w+dx)][(n+dy)][(v+dz)]   and advances by one row per tile.
 // Per 16-channel chunk the LDS holds the 6x10x18 halo (32 B / voxel) and the 14 k steps x 2 cout tiles of weights.
 // A k step = 2 taps x 2 octets: lane group g reads tap 2s + (g >> 1), octet g & 1.  The two lane groups that share a
-// ds_read_b128 cycle (g = 0,1 and g = 2,3) read the same tap, so the 16 lanes cover 16 distinct 16-byte slots.
+// ds_read_b128 pass (g = 0,1 and g = 2,3) read the same tap, so the 16 lanes cover 16 distinct 16-byte slots
+// (tools/lds_conflicts_bf16.py).
 // ------------------------------------------------------------------------------------------------
 constexpr int K3_TX = 4, K3_TY = 8, K3_TZ = 16;
 constexpr int K3_HX = K3_TX + 2, K3_HY = K3_TY + 2, K3_HZ = K3_TZ + 2;
 constexpr int K3_HALO_VOX = K3_HX * K3_HY * K3_HZ;            // 1080
-constexpr int K3_HALO_BYTES = K3_HALO_VOX * 32;               // 34560
+constexpr int K3_HALO_PIECES = K3_HALO_VOX * 2;               // 2160 x 16 B
+constexpr int K3_HALO_BYTES = K3_HALO_PIECES * 16;            // 34560
 constexpr int K3_KPC = 14;
-constexpr int K3_W_BYTES = K3_KPC * 2 * 1024;                 // 28672
+constexpr int K3_W_PIECES = K3_KPC * 2 * 64;                  // 1792 x 16 B
+constexpr int K3_W_BYTES = K3_W_PIECES * 16;                  // 28672
 constexpr int K3_LDS_BYTES = K3_HALO_BYTES + K3_W_BYTES;      // 63232 -> two workgroups per CU
+constexpr int K3_HP = (K3_HALO_PIECES + 255) / 256;           // 9 halo pieces per thread
+constexpr int K3_WP = K3_W_PIECES / 256;                      // 7 weight pieces per thread
+
+struct K3Stage {
+    u16x8 h[K3_HP];
+    u16x8 w[K3_WP];
+};
+
+__device__ __forceinline__ void k3_load_stage(K3Stage& st, const ConvBArgs& a, const int* hvox, unsigned hmask,
+                                              const unsigned short* wsrc, int c, int tid) {
+    const int coff = c * 16 + (tid & 1) * 8;      // piece i = tid + 256 j: octet i & 1 = tid & 1
+#pragma unroll
+    for (int j = 0; j < K3_HP; ++j) {
+        st.h[j] = zero8();
+        if ((hmask >> j) & 1) st.h[j] = *reinterpret_cast<const u16x8*>(a.in + (long long)hvox[j] * a.cin_pad + coff);
+    }
+#pragma unroll
+    for (int j = 0; j < K3_WP; ++j) {
+        const int i = tid + 256 * j;
+        const int m = i / (K3_KPC * 64), r = i - m * (K3_KPC * 64);
+        st.w[j] = *reinterpret_cast<const u16x8*>(wsrc + ((size_t)m * a.ksteps + c * K3_KPC) * 512 + r * 8);
+    }
+}
 
 __global__ __launch_bounds__(256, 2) void conv_bf16_k3_kernel(ConvBArgs a, int tiles_x, int tiles_y, int tiles_z) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -39,6 +70,21 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_k3_kernel(ConvBArgs a, int t
     const int b = t / tiles_x;
     const int x0 = tx * K3_TX, y0 = ty * K3_TY, z0 = tz * K3_TZ;
 
+    // this thread's halo pieces: global voxel index and in-volume mask, fixed for the whole tile
+    int hoff[K3_HP];
+    unsigned hmask = 0;
+#pragma unroll
+    for (int j = 0; j < K3_HP; ++j) {
+        const int i = tid + 256 * j;
+        const int hv = i >> 1;
+        const int hz = hv % K3_HZ, hy = (hv / K3_HZ) % K3_HY, hx = hv / (K3_HZ * K3_HY);
+        const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+        const bool ok = i < K3_HALO_PIECES && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D;
+        hoff[j] = ok ? ((b * D + gx) * D + gy) * D + gz : 0;
+        hmask |= (ok ? 1u : 0u) << j;
+    }
+    const unsigned short* wsrc = a.wpack + ((size_t)mb * 2 * a.ksteps) * 512;
+
     f32x4 acc[2][K3_TY];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -46,40 +92,65 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_k3_kernel(ConvBArgs a, int t
         for (int n = 0; n < K3_TY; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const unsigned char* brow = halo + ((w * K3_HY) * K3_HZ + v) * 32 + (g & 1) * 16;
-    const unsigned short* wsrc = a.wpack + ((size_t)mb * 2 * a.ksteps) * 512;
+    const unsigned char* arow = wts + lane * 16;
 
+    K3Stage st;
+    k3_load_stage(st, a, hoff, hmask, wsrc, 0, tid);
     for (int c = 0; c < a.nchunk; ++c) {
-        __syncthreads();
-        // halo: 2160 16-byte pieces (voxel, octet); zero outside the volume
-        for (int i = tid; i < K3_HALO_VOX * 2; i += 256) {
-            const int hv = i >> 1, o = i & 1;
-            const int hz = hv % K3_HZ, hy = (hv / K3_HZ) % K3_HY, hx = hv / (K3_HZ * K3_HY);
-            const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
-            u16x8 val = {0, 0, 0, 0, 0, 0, 0, 0};
-            if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D)
-                val = *reinterpret_cast<const u16x8*>(a.in + ((((long long)b * D + gx) * D + gy) * D + gz) * a.cin_pad + c * 16 + o * 8);
-            *reinterpret_cast<u16x8*>(halo + i * 16) = val;
+        __syncthreads();                       // every wave is done reading the previous chunk
+#pragma unroll
+        for (int j = 0; j < K3_HP; ++j) {
+            const int i = tid + 256 * j;
+            if (i < K3_HALO_PIECES) *reinterpret_cast<u16x8*>(halo + i * 16) = st.h[j];
         }
-        // weights of this chunk: [m][14][lane][16 B]
-        for (int i = tid; i < K3_W_BYTES / 16; i += 256) {
-            const int m = i / (K3_KPC * 64), r = i - m * (K3_KPC * 64);
-            *reinterpret_cast<u16x8*>(wts + i * 16) =
-                *reinterpret_cast<const u16x8*>(wsrc + ((size_t)m * a.ksteps + c * K3_KPC) * 512 + r * 8);
-        }
+#pragma unroll
+        for (int j = 0; j < K3_WP; ++j) *reinterpret_cast<u16x8*>(wts + (tid + 256 * j) * 16) = st.w[j];
         __syncthreads();
-#pragma unroll 2
+        if (c + 1 < a.nchunk) k3_load_stage(st, a, hoff, hmask, wsrc, c + 1, tid);   // in flight under the MFMAs below
+
+        // k steps, operand fragments double-buffered
+        u16x8 A0, A1, Bf[K3_TY];
+        {
+            const int tap = g >> 1;
+            const unsigned char* bp = brow + (((tap / 9) * K3_HY + (tap / 3) % 3) * K3_HZ + tap % 3) * 32;
+            A0 = lds_read16(arow);
+            A1 = lds_read16(arow + K3_KPC * 1024);
+#pragma unroll
+            for (int n = 0; n < K3_TY; ++n) Bf[n] = lds_read16(bp + n * (K3_HZ * 32));
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 + K3_TY, 0);
+        }
+#pragma unroll
         for (int sl = 0; sl < K3_KPC; ++sl) {
-            int tap = 2 * sl + (g >> 1);
-            tap = tap > 26 ? 26 : tap;                 // padding group: zero weights, any valid address
-            const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-            const unsigned char* bp = brow + ((dx * K3_HY + dy) * K3_HZ + dz) * 32;
-            const u16x8 A0 = lds_read16(wts + sl * 1024 + lane * 16);
-            const u16x8 A1 = lds_read16(wts + (K3_KPC + sl) * 1024 + lane * 16);
+            u16x8 nA0 = A0, nA1 = A1, nB[K3_TY];
+#pragma unroll
+            for (int n = 0; n < K3_TY; ++n) nB[n] = Bf[n];
+            if (sl + 1 < K3_KPC) {
+                int tap = 2 * (sl + 1) + (g >> 1);
+                tap = tap > 26 ? 26 : tap;             // padding group: zero weights, any valid address
+                const unsigned char* bp = brow + (((tap / 9) * K3_HY + (tap / 3) % 3) * K3_HZ + tap % 3) * 32;
+                nA0 = lds_read16(arow + (sl + 1) * 1024);
+                nA1 = lds_read16(arow + (K3_KPC + sl + 1) * 1024);
+#pragma unroll
+                for (int n = 0; n < K3_TY; ++n) nB[n] = lds_read16(bp + n * (K3_HZ * 32));
+            }
 #pragma unroll
             for (int n = 0; n < K3_TY; ++n) {
-                const u16x8 Bf = lds_read16(bp + n * (K3_HZ * 32));
-                acc[0][n] = mfma_bf16(A0, Bf, acc[0][n]);
-                acc[1][n] = mfma_bf16(A1, Bf, acc[1][n]);
+                acc[0][n] = mfma_bf16(A0, Bf[n], acc[0][n]);
+                acc[1][n] = mfma_bf16(A1, Bf[n], acc[1][n]);
+            }
+            A0 = nA0; A1 = nA1;
+#pragma unroll
+            for (int n = 0; n < K3_TY; ++n) Bf[n] = nB[n];
+            // issue order: the next k step's fragment reads are spread between this k step's MFMAs
+            if (sl + 1 < K3_KPC) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int n = 0; n < K3_TY; ++n) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * K3_TY, 0);
             }
         }
     }
@@ -99,11 +170,23 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_k3_kernel(ConvBArgs a, int t
 // differ by a multiple of 256 B (bf16_common.h, tools/lds_conflicts_bf16.py: conflict-free).
 // ------------------------------------------------------------------------------------------------
 constexpr int K7_T = 8, K7_H = 14, K7_P = 24;
-constexpr int K7_HALO_BYTES = K7_H * K7_H * K7_P * 16;        // 75264
+constexpr int K7_HALO_PIECES = K7_H * K7_H * K7_H;            // 2744 x 16 B
+constexpr int K7_HALO_BYTES = K7_H * K7_H * K7_P * 16;        // 75264 (z pitch padded to 24)
 constexpr int K7_KPD = SE_K7B_SLOTS_PER_DZ / 4;               // 13 k steps per dz plane
 constexpr int K7_WBUF_BYTES = K7_KPD * 1024;                  // 13312
 constexpr int K7_LDS_BYTES = K7_HALO_BYTES + 2 * K7_WBUF_BYTES;   // 101888
 constexpr int K7_WPIECES = K7_WBUF_BYTES / 16;                // 832
+constexpr int K7_HP = (K7_HALO_PIECES + 255) / 256;           // 11
+constexpr int K7_WP = (K7_WPIECES + 255) / 256;               // 4
+
+__device__ __forceinline__ int k7_tap_offset(int sl, int g) {
+    int r = 4 * sl + g;
+    r = r > 48 ? 48 : r;                       // padding slots alias the last tap (zero weights)
+    const int r2 = r < 28 ? r : r - 28;
+    const int q7 = r2 / 7;
+    const int dx = r2 - 7 * q7, dy = 2 * q7 + (r < 28 ? 0 : 1);
+    return ((dx * K7_H + dy) * K7_P) * 16;
+}
 
 __global__ __launch_bounds__(256) void conv_bf16_k7_kernel(ConvBArgs a, int tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -123,63 +206,116 @@ __global__ __launch_bounds__(256) void conv_bf16_k7_kernel(ConvBArgs a, int tile
     const long long N = (long long)D * D * D;
     const unsigned short* inb = a.in + (long long)b * octs * N * 8;
 
+    // this thread's halo pieces: element offset inside an octet plane, LDS byte offset, in-volume mask
+    int hoff[K7_HP], hlds[K7_HP];
+    unsigned hmask = 0;
+#pragma unroll
+    for (int j = 0; j < K7_HP; ++j) {
+        const int i = tid + 256 * j;
+        const int hz = i % K7_H, hy = (i / K7_H) % K7_H, hx = i / (K7_H * K7_H);
+        const int gx = x0 + hx - 3, gy = y0 + hy - 3, gz = z0 + hz - 3;
+        const bool inside = i < K7_HALO_PIECES;
+        const bool ok = inside && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D;
+        hoff[j] = ok ? ((gx * D + gy) * D + gz) * 8 : 0;
+        hlds[j] = inside ? ((hx * K7_H + hy) * K7_P + hz) * 16 : -1;
+        hmask |= (ok ? 1u : 0u) << j;
+    }
+
     f32x4 acc[8];
 #pragma unroll
     for (int n = 0; n < 8; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const unsigned char* lbase = halo + (((2 * w) * K7_H + (v >> 3)) * K7_P + (v & 7)) * 16;
 
-    // weights of phase 0
-    for (int i = tid; i < K7_WPIECES; i += 256)
-        *reinterpret_cast<u16x8*>(wbuf + i * 16) = *reinterpret_cast<const u16x8*>(a.wpack + (size_t)i * 8);
+    u16x8 hreg[K7_HP], wreg[K7_WP];
+#pragma unroll
+    for (int j = 0; j < K7_HP; ++j) {
+        hreg[j] = zero8();
+        if ((hmask >> j) & 1) hreg[j] = *reinterpret_cast<const u16x8*>(inb + hoff[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < K7_WP; ++j) {
+        const int i = tid + 256 * j;
+        wreg[j] = zero8();
+        if (i < K7_WPIECES) wreg[j] = *reinterpret_cast<const u16x8*>(a.wpack + (size_t)i * 8);
+    }
     int cur = 0;
     const int phases = octs * 7;
     for (int c = 0; c < octs; ++c) {
-        __syncthreads();
-        const unsigned short* inc = inb + (long long)c * N * 8;
-        for (int i = tid; i < K7_H * K7_H * K7_H; i += 256) {
-            const int hz = i % K7_H, hy = (i / K7_H) % K7_H, hx = i / (K7_H * K7_H);
-            const int gx = x0 + hx - 3, gy = y0 + hy - 3, gz = z0 + hz - 3;
-            u16x8 val = {0, 0, 0, 0, 0, 0, 0, 0};
-            if ((unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D)
-                val = *reinterpret_cast<const u16x8*>(inc + (((long long)gx * D + gy) * D + gz) * 8);
-            *reinterpret_cast<u16x8*>(halo + ((hx * K7_H + hy) * K7_P + hz) * 16) = val;
+        __syncthreads();                      // previous octet fully consumed
+#pragma unroll
+        for (int j = 0; j < K7_HP; ++j)
+            if (hlds[j] >= 0) *reinterpret_cast<u16x8*>(halo + hlds[j]) = hreg[j];
+        if (c == 0) {
+#pragma unroll
+            for (int j = 0; j < K7_WP; ++j) {
+                const int i = tid + 256 * j;
+                if (i < K7_WPIECES) *reinterpret_cast<u16x8*>(wbuf + i * 16) = wreg[j];
+            }
         }
         __syncthreads();
         for (int dz = 0; dz < 7; ++dz) {
             const int ph = c * 7 + dz + 1;
             const bool has_next = ph < phases;
-            u16x8 pre[4];
             if (has_next) {
                 const unsigned short* src = a.wpack + (size_t)ph * K7_KPD * 512;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < K7_WP; ++j) {
                     const int i = tid + 256 * j;
-                    if (i < K7_WPIECES) pre[j] = *reinterpret_cast<const u16x8*>(src + (size_t)i * 8);
+                    if (i < K7_WPIECES) wreg[j] = *reinterpret_cast<const u16x8*>(src + (size_t)i * 8);
+                }
+            }
+            if (dz == 6 && c + 1 < octs) {     // next octet's halo: in flight under the last dz plane
+                const unsigned short* inc = inb + (long long)(c + 1) * N * 8;
+#pragma unroll
+                for (int j = 0; j < K7_HP; ++j) {
+                    hreg[j] = zero8();
+                    if ((hmask >> j) & 1) hreg[j] = *reinterpret_cast<const u16x8*>(inc + hoff[j]);
                 }
             }
             const unsigned char* wb = wbuf + cur * K7_WBUF_BYTES + lane * 16;
             const unsigned char* lz = lbase + dz * 16;
-#pragma unroll 1
-            for (int sl = 0; sl < K7_KPD; ++sl) {
-                int r = 4 * sl + g;
-                r = r > 48 ? 48 : r;                       // padding slots alias the last tap (zero weights)
-                const int r2 = r < 28 ? r : r - 28;
-                const int q7 = r2 / 7;
-                const int dx = r2 - 7 * q7, dy = 2 * q7 + (r < 28 ? 0 : 1);
-                const unsigned char* bp = lz + ((dx * K7_H + dy) * K7_P) * 16;
-                const u16x8 A = lds_read16(wb + sl * 1024);
+            u16x8 A, Bf[8];
+            {
+                const unsigned char* bp = lz + k7_tap_offset(0, g);
+                A = lds_read16(wb);
 #pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    const u16x8 Bf = lds_read16(bp + (((n >> 2) * K7_H + 2 * (n & 3)) * K7_P) * 16);
-                    acc[n] = mfma_bf16(A, Bf, acc[n]);
+                for (int n = 0; n < 8; ++n) Bf[n] = lds_read16(bp + (((n >> 2) * K7_H + 2 * (n & 3)) * K7_P) * 16);
+                __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+            }
+#pragma unroll
+            for (int sl = 0; sl < K7_KPD; ++sl) {
+                u16x8 nA = A, nB[8];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) nB[n] = Bf[n];
+                if (sl + 1 < K7_KPD) {
+                    const unsigned char* bp = lz + k7_tap_offset(sl + 1, g);
+                    nA = lds_read16(wb + (sl + 1) * 1024);
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) nB[n] = lds_read16(bp + (((n >> 2) * K7_H + 2 * (n & 3)) * K7_P) * 16);
+                }
+#pragma unroll
+                for (int n = 0; n < 8; ++n) acc[n] = mfma_bf16(A, Bf[n], acc[n]);
+                A = nA;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) Bf[n] = nB[n];
+                if (sl + 1 < K7_KPD) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                    for (int n = 0; n < 7; ++n) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
                 }
             }
             if (has_next) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < K7_WP; ++j) {
                     const int i = tid + 256 * j;
-                    if (i < K7_WPIECES) *reinterpret_cast<u16x8*>(wbuf + (cur ^ 1) * K7_WBUF_BYTES + i * 16) = pre[j];
+                    if (i < K7_WPIECES) *reinterpret_cast<u16x8*>(wbuf + (cur ^ 1) * K7_WBUF_BYTES + i * 16) = wreg[j];
                 }
             }
             __syncthreads();
@@ -197,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_bf16_k7_kernel(ConvBArgs a, int tile
 }  // namespace
 
 int se_conv3d_bf16_tiled_try(const ConvBArgs& a, int batch, int ksize, hipStream_t s) {
-    if (ksize == 3 && a.dim % 16 == 0 && a.cin_pad % 16 == 0 && a.cout % 32 == 0 && a.kpc == K3_KPC) {
+    if (ksize == 3 && a.dim % 16 == 0 && a.cin_pad % 16 == 0 && a.cout % 32 == 0 && a.kpc == K3_KPC && a.total_vox < (1LL << 31)) {
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_k3_kernel),
@@ -211,7 +347,7 @@ int se_conv3d_bf16_tiled_try(const ConvBArgs& a, int batch, int ksize, hipStream
         SE_CHECK_LAUNCH();
         return 0;
     }
-    if (ksize == 7 && a.dim % 8 == 0 && a.cout == 16 && a.kpc == SE_K7B_KPC) {
+    if (ksize == 7 && a.dim % 8 == 0 && a.cout == 16 && a.kpc == SE_K7B_KPC && (long long)a.dim * a.dim * a.dim * 8 < (1LL << 31)) {
         static bool attr_set7 = false;
         if (!attr_set7) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_k7_kernel),
