@@ -142,6 +142,83 @@ int launch_direct_b(const ConvBArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3x3 on the deep pyramid levels (8^3, 4^3, 2^3; 128 -> 128): a handful of voxels against 885 KB of weights, so the launch is
+// bound by the serial chain of dependent global loads.  The four waves of a workgroup split the k steps (wave w takes
+// s = w, w+4, ...), every wave issues the loads of U k steps before their MFMAs, and the partial sums meet in LDS in a fixed
+// order (deterministic).  Workgroup = N_T voxel tiles x 32 couts.
+// ------------------------------------------------------------------------------------------------
+template <int N_T, int U>
+__global__ __launch_bounds__(256) void conv_bf16_k3_splitk_kernel(ConvBArgs a) {
+    __shared__ f32x4 red[4][2 * N_T][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = lane & 15, g = lane >> 4;
+    const int mb = blockIdx.y;
+    const int D = a.dim;
+    long long vox[N_T];
+    int vx[N_T], vy[N_T], vz[N_T];
+#pragma unroll
+    for (int n = 0; n < N_T; ++n) {
+        vox[n] = ((long long)blockIdx.x * N_T + n) * 16 + v;
+        const long long q = vox[n] < a.total_vox ? vox[n] : 0;
+        vz[n] = (int)(q % D);
+        vy[n] = (int)((q / D) % D);
+        vx[n] = (int)((q / ((long long)D * D)) % D);
+    }
+    f32x4 acc[2][N_T];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < N_T; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned short* wp = a.wpack + ((size_t)mb * 2 * a.ksteps) * 512 + lane * 8;
+    const int o = g & 1;
+    for (int s0 = wave; s0 < a.ksteps; s0 += 4 * U) {
+        u16x8 A[U][2], Bf[U][N_T];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = s0 + 4 * u;
+            const bool live = s < a.ksteps;
+            const int ss = live ? s : 0;
+            const int c = ss / 14, sl = ss - c * 14;         // kpc == 14 (3^3, 16-channel chunks)
+            int tap = 2 * sl + (g >> 1);
+            const bool valid = live && tap < 27;
+            tap = tap > 26 ? 26 : tap;
+            const int dx = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dz = tap % 3 - 1;
+            A[u][0] = *reinterpret_cast<const u16x8*>(wp + (size_t)ss * 512);
+            A[u][1] = *reinterpret_cast<const u16x8*>(wp + ((size_t)a.ksteps + ss) * 512);
+            if (!live) { A[u][0] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0}; A[u][1] = A[u][0]; }
+#pragma unroll
+            for (int n = 0; n < N_T; ++n) {
+                const int xx = vx[n] + dx, yy = vy[n] + dy, zz = vz[n] + dz;
+                const bool ok = valid && vox[n] < a.total_vox && (unsigned)xx < (unsigned)D && (unsigned)yy < (unsigned)D &&
+                                (unsigned)zz < (unsigned)D;
+                Bf[u][n] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) Bf[u][n] = *reinterpret_cast<const u16x8*>(a.in + (vox[n] + ((long long)dx * D + dy) * D + dz) * a.cin_pad + c * 16 + o * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int n = 0; n < N_T; ++n) {
+                acc[0][n] = mfma_bf16(A[u][0], Bf[u][n], acc[0][n]);
+                acc[1][n] = mfma_bf16(A[u][1], Bf[u][n], acc[1][n]);
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < N_T; ++n) red[wave][m * N_T + n][lane] = acc[m][n];
+    __syncthreads();
+    if (wave < N_T) {
+        const int n = wave;
+        f32x4 lo = red[0][n][lane], hi = red[0][N_T + n][lane];
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) { lo += red[w2][n][lane]; hi += red[w2][N_T + n][lane]; }
+        const long long ov = ((long long)blockIdx.x * N_T + n) * 16 + v;
+        if (ov < a.total_vox) epilogue_pair_bf16(a, lo, hi, ov, mb, g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // ConvTranspose3d k2s2: per output parity p a [cout x cin] GEMM on the input voxels; the 8 parities reuse the B fragments.
 // ------------------------------------------------------------------------------------------------
 template <int NCHUNK>
@@ -333,6 +410,16 @@ extern "C" int se_conv3d_bf16(const se_bf16* in, const se_bf16* wpack, const flo
     const int took = se_conv3d_bf16_tiled_try(a, batch, ksize, s);
     if (took != SE_TILED_NOT_TAKEN_B) return took;
     const bool pair = cout % 32 == 0;
+    if (ksize == 3 && pair && p.oc == 2 && a.total_vox <= 8 * 8 * 8 * 64) {
+        const long long tiles = (a.total_vox + 15) / 16;
+        if (tiles >= 128) {
+            hipLaunchKernelGGL((conv_bf16_k3_splitk_kernel<2, 4>), dim3((unsigned)((tiles + 1) / 2), cout / 32), dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL((conv_bf16_k3_splitk_kernel<1, 4>), dim3((unsigned)tiles, cout / 32), dim3(256), 0, s, a);
+        }
+        SE_CHECK_LAUNCH();
+        return 0;
+    }
     // few voxels (deep pyramid levels): one voxel tile per wave so that the launch still spreads over the chip
     const bool small = a.total_vox * (cout / 16) < 256 * 4 * 32;
     if (ksize == 7) return pair ? launch_direct_b<7, 1, 2, 2>(a, s) : launch_direct_b<7, 1, 1, 2>(a, s);

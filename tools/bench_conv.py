@@ -22,6 +22,9 @@ SHAPES = [  # (dim, cin, cin_pad, cout, k)
     (16, 128, 128, 128, 3),
     (128, 32, 32, 32, 3),      # BASELINE config 5: 128^3 grid
     (128, 33, 48, 16, 7),
+    (8, 128, 128, 128, 3),     # deep pyramid levels
+    (4, 128, 128, 128, 3),
+    (2, 128, 128, 128, 3),
 ]
 
 
