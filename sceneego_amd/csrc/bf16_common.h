@@ -77,22 +77,26 @@ __host__ __device__ inline int se_bf16_cout_of(int cout, int m, int r) {
 }
 
 // Epilogue of a tile pair: lane (v, g) holds channels cb*32 + 8g .. +7 of one voxel (record index `ovox`).
-__device__ __forceinline__ void epilogue_pair_bf16(const ConvBArgs& a, f32x4 lo, f32x4 hi, long long ovox, int cb, int g) {
-    const int co0 = cb * 32 + 8 * g;
-    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bpack + co0);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bpack + co0 + 4);
-    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-    const long long off = ovox * a.cout + co0;
+// Split into load and apply/store halves so that a kernel can issue the bias and ALL residual loads of its tiles before the
+// first use (one exposed latency per workgroup instead of two per tile).
+struct EpiBias8 { f32x4 b0, b1; };
+__device__ __forceinline__ EpiBias8 epi_load_bias8(const ConvBArgs& a, int cb, int g) {
+    EpiBias8 e;
+    e.b0 = *reinterpret_cast<const f32x4*>(a.bpack + cb * 32 + 8 * g);
+    e.b1 = *reinterpret_cast<const f32x4*>(a.bpack + cb * 32 + 8 * g + 4);
+    return e;
+}
+__device__ __forceinline__ bool epi_has_res(const ConvBArgs& a) {
+    return a.res && (a.flags & (SE_EPI_RES_PRE_RELU | SE_EPI_RES_POST_RELU));
+}
+__device__ __forceinline__ void epi_store_pair(const ConvBArgs& a, f32x4 lo, f32x4 hi, const EpiBias8& e, bool has_res, u16x8 rv,
+                                               long long off) {
+    float v[8] = {lo.x + e.b0.x, lo.y + e.b0.y, lo.z + e.b0.z, lo.w + e.b0.w,
+                  hi.x + e.b1.x, hi.y + e.b1.y, hi.z + e.b1.z, hi.w + e.b1.w};
     float r[8];
-    const bool has_res = a.res && (a.flags & (SE_EPI_RES_PRE_RELU | SE_EPI_RES_POST_RELU));
-    if (has_res) {
-        const u16x8 rv = *reinterpret_cast<const u16x8*>(a.res + off);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = bf2f(rv[i]);
-    }
-    if (has_res && (a.flags & SE_EPI_RES_PRE_RELU)) {
+    for (int i = 0; i < 8; ++i) r[i] = has_res ? bf2f(rv[i]) : 0.f;
+    if (a.flags & SE_EPI_RES_PRE_RELU) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += r[i];
     }
@@ -100,7 +104,7 @@ __device__ __forceinline__ void epilogue_pair_bf16(const ConvBArgs& a, f32x4 lo,
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
     }
-    if (has_res && (a.flags & SE_EPI_RES_POST_RELU)) {
+    if (a.flags & SE_EPI_RES_POST_RELU) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += r[i];
     }
@@ -108,6 +112,13 @@ __device__ __forceinline__ void epilogue_pair_bf16(const ConvBArgs& a, f32x4 lo,
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
     *reinterpret_cast<u16x8*>(a.out + off) = o;
+}
+__device__ __forceinline__ void epilogue_pair_bf16(const ConvBArgs& a, f32x4 lo, f32x4 hi, long long ovox, int cb, int g) {
+    const long long off = ovox * a.cout + cb * 32 + 8 * g;
+    const bool has_res = epi_has_res(a);
+    u16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (has_res) rv = *reinterpret_cast<const u16x8*>(a.res + off);
+    epi_store_pair(a, lo, hi, epi_load_bias8(a, cb, g), has_res, rv, off);
 }
 
 // Single 16-cout tile (cout <= 16, e.g. the front layer): lane (v, g) holds channels 4g .. 4g+3.

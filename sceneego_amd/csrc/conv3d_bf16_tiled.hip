@@ -42,9 +42,9 @@ __device__ __forceinline__ void k3_load_stage(K3Stage& st, const ConvBArgs& a, c
                                               const unsigned short* wsrc, int c, int tid) {
     const int coff = c * 16 + (tid & 1) * 8;      // piece i = tid + 256 j: octet i & 1 = tid & 1
 #pragma unroll
-    for (int j = 0; j < K3_HP; ++j) {
-        st.h[j] = zero8();
-        if ((hmask >> j) & 1) st.h[j] = *reinterpret_cast<const u16x8*>(a.in + (long long)hvox[j] * a.cin_pad + coff);
+    for (int j = 0; j < K3_HP; ++j) {      // branch-free: out-of-volume pieces read voxel 0 and are zeroed by a select
+        const u16x8 val = *reinterpret_cast<const u16x8*>(a.in + (long long)hvox[j] * a.cin_pad + coff);
+        st.h[j] = ((hmask >> j) & 1) ? val : zero8();
     }
 #pragma unroll
     for (int j = 0; j < K3_WP; ++j) {
@@ -54,7 +54,72 @@ __device__ __forceinline__ void k3_load_stage(K3Stage& st, const ConvBArgs& a, c
     }
 }
 
-__global__ __launch_bounds__(256, 2) void conv_bf16_k3_kernel(ConvBArgs a, int tiles_x, int tiles_y, int tiles_z) {
+__device__ __forceinline__ void k3_commit_stage(const K3Stage& st, unsigned char* halo, unsigned char* wts, int tid) {
+#pragma unroll
+    for (int j = 0; j < K3_HP; ++j) {
+        const int i = tid + 256 * j;
+        if (i < K3_HALO_PIECES) *reinterpret_cast<u16x8*>(halo + i * 16) = st.h[j];
+    }
+#pragma unroll
+    for (int j = 0; j < K3_WP; ++j) *reinterpret_cast<u16x8*>(wts + (tid + 256 * j) * 16) = st.w[j];
+}
+
+// the 14 k steps of one chunk; operand fragments double-buffered, next k step's reads spread between this one's MFMAs
+__device__ __forceinline__ void k3_compute(f32x4 (&acc)[2][K3_TY], const unsigned char* brow, const unsigned char* arow, int g) {
+    u16x8 A0, A1, Bf[K3_TY];
+    {
+        const int tap = g >> 1;
+        const unsigned char* bp = brow + (((tap / 9) * K3_HY + (tap / 3) % 3) * K3_HZ + tap % 3) * 32;
+        A0 = lds_read16(arow);
+        A1 = lds_read16(arow + K3_KPC * 1024);
+#pragma unroll
+        for (int n = 0; n < K3_TY; ++n) Bf[n] = lds_read16(bp + n * (K3_HZ * 32));
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + K3_TY, 0);
+    }
+#pragma unroll
+    for (int sl = 0; sl < K3_KPC; ++sl) {
+        u16x8 nA0 = A0, nA1 = A1, nB[K3_TY];
+#pragma unroll
+        for (int n = 0; n < K3_TY; ++n) nB[n] = Bf[n];
+        if (sl + 1 < K3_KPC) {
+            int tap = 2 * (sl + 1) + (g >> 1);
+            tap = tap > 26 ? 26 : tap;             // padding group: zero weights, any valid address
+            const unsigned char* bp = brow + (((tap / 9) * K3_HY + (tap / 3) % 3) * K3_HZ + tap % 3) * 32;
+            nA0 = lds_read16(arow + (sl + 1) * 1024);
+            nA1 = lds_read16(arow + (K3_KPC + sl + 1) * 1024);
+#pragma unroll
+            for (int n = 0; n < K3_TY; ++n) nB[n] = lds_read16(bp + n * (K3_HZ * 32));
+        }
+#pragma unroll
+        for (int n = 0; n < K3_TY; ++n) {
+            acc[0][n] = mfma_bf16(A0, Bf[n], acc[0][n]);
+            acc[1][n] = mfma_bf16(A1, Bf[n], acc[1][n]);
+        }
+        A0 = nA0; A1 = nA1;
+#pragma unroll
+        for (int n = 0; n < K3_TY; ++n) Bf[n] = nB[n];
+        if (sl + 1 < K3_KPC) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int n = 0; n < K3_TY; ++n) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * K3_TY, 0);
+        }
+    }
+}
+
+#ifdef SE_STAMPB
+#define K3_STAMP(i) do { if (stamps && lane == 0) stamps[((size_t)blockIdx.x * 4 + w) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define K3_STAMP_ARG , unsigned long long* stamps
+#else
+#define K3_STAMP(i) do {} while (0)
+#define K3_STAMP_ARG
+#endif
+
+__global__ __launch_bounds__(256, 2) void conv_bf16_k3_kernel(ConvBArgs a, int tiles_x, int tiles_y, int tiles_z K3_STAMP_ARG) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* halo = lds;
     unsigned char* wts = lds + K3_HALO_BYTES;
@@ -94,71 +159,40 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_k3_kernel(ConvBArgs a, int t
     const unsigned char* brow = halo + ((w * K3_HY) * K3_HZ + v) * 32 + (g & 1) * 16;
     const unsigned char* arow = wts + lane * 16;
 
-    K3Stage st;
-    k3_load_stage(st, a, hoff, hmask, wsrc, 0, tid);
-    for (int c = 0; c < a.nchunk; ++c) {
-        __syncthreads();                       // every wave is done reading the previous chunk
-#pragma unroll
-        for (int j = 0; j < K3_HP; ++j) {
-            const int i = tid + 256 * j;
-            if (i < K3_HALO_PIECES) *reinterpret_cast<u16x8*>(halo + i * 16) = st.h[j];
-        }
-#pragma unroll
-        for (int j = 0; j < K3_WP; ++j) *reinterpret_cast<u16x8*>(wts + (tid + 256 * j) * 16) = st.w[j];
-        __syncthreads();
-        if (c + 1 < a.nchunk) k3_load_stage(st, a, hoff, hmask, wsrc, c + 1, tid);   // in flight under the MFMAs below
+    const long long obase = (((long long)b * D + (x0 + w)) * D + y0) * D + (z0 + v);   // output voxel of tile n: + n * D
+    const bool has_res = epi_has_res(a);
 
-        // k steps, operand fragments double-buffered
-        u16x8 A0, A1, Bf[K3_TY];
-        {
-            const int tap = g >> 1;
-            const unsigned char* bp = brow + (((tap / 9) * K3_HY + (tap / 3) % 3) * K3_HZ + tap % 3) * 32;
-            A0 = lds_read16(arow);
-            A1 = lds_read16(arow + K3_KPC * 1024);
-#pragma unroll
-            for (int n = 0; n < K3_TY; ++n) Bf[n] = lds_read16(bp + n * (K3_HZ * 32));
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 + K3_TY, 0);
-        }
-#pragma unroll
-        for (int sl = 0; sl < K3_KPC; ++sl) {
-            u16x8 nA0 = A0, nA1 = A1, nB[K3_TY];
-#pragma unroll
-            for (int n = 0; n < K3_TY; ++n) nB[n] = Bf[n];
-            if (sl + 1 < K3_KPC) {
-                int tap = 2 * (sl + 1) + (g >> 1);
-                tap = tap > 26 ? 26 : tap;             // padding group: zero weights, any valid address
-                const unsigned char* bp = brow + (((tap / 9) * K3_HY + (tap / 3) % 3) * K3_HZ + tap % 3) * 32;
-                nA0 = lds_read16(arow + (sl + 1) * 1024);
-                nA1 = lds_read16(arow + (K3_KPC + sl + 1) * 1024);
-#pragma unroll
-                for (int n = 0; n < K3_TY; ++n) nB[n] = lds_read16(bp + n * (K3_HZ * 32));
-            }
-#pragma unroll
-            for (int n = 0; n < K3_TY; ++n) {
-                acc[0][n] = mfma_bf16(A0, Bf[n], acc[0][n]);
-                acc[1][n] = mfma_bf16(A1, Bf[n], acc[1][n]);
-            }
-            A0 = nA0; A1 = nA1;
-#pragma unroll
-            for (int n = 0; n < K3_TY; ++n) Bf[n] = nB[n];
-            // issue order: the next k step's fragment reads are spread between this k step's MFMAs
-            if (sl + 1 < K3_KPC) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-                for (int n = 0; n < K3_TY; ++n) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * K3_TY, 0);
-            }
-        }
+    K3Stage st;
+    K3_STAMP(0);
+    k3_load_stage(st, a, hoff, hmask, wsrc, 0, tid);
+    K3_STAMP(1);
+    for (int c = 0; c + 1 < a.nchunk; ++c) {
+        __syncthreads();                       // every wave is done reading the previous chunk
+        k3_commit_stage(st, halo, wts, tid);
+        __syncthreads();
+        K3_STAMP(2);
+        k3_load_stage(st, a, hoff, hmask, wsrc, c + 1, tid);   // in flight under the MFMAs below
+        k3_compute(acc, brow, arow, g);
+        K3_STAMP(3);
     }
+    // last chunk: the staging registers are free; fetch bias and the skip tensor under the MFMAs instead
+    __syncthreads();
+    k3_commit_stage(st, halo, wts, tid);
+    __syncthreads();
+    K3_STAMP(4);
+    const EpiBias8 ebias = epi_load_bias8(a, mb, g);
+    u16x8 rv[K3_TY];
 #pragma unroll
     for (int n = 0; n < K3_TY; ++n) {
-        const long long ovox = (((long long)b * D + (x0 + w)) * D + (y0 + n)) * D + (z0 + v);
-        epilogue_pair_bf16(a, acc[0][n], acc[1][n], ovox, mb, g);
+        rv[n] = zero8();
+        if (has_res) rv[n] = *reinterpret_cast<const u16x8*>(a.res + (obase + (long long)n * D) * a.cout + mb * 32 + 8 * g);
     }
+    k3_compute(acc, brow, arow, g);
+    K3_STAMP(5);
+#pragma unroll
+    for (int n = 0; n < K3_TY; ++n)
+        epi_store_pair(a, acc[0][n], acc[1][n], ebias, has_res, rv[n], (obase + (long long)n * D) * a.cout + mb * 32 + 8 * g);
+    K3_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -322,15 +356,28 @@ __global__ __launch_bounds__(256) void conv_bf16_k7_kernel(ConvBArgs a, int tile
             cur ^= 1;
         }
     }
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.bpack + 4 * g);
+    const bool relu = a.flags & SE_EPI_RELU;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
         const int x = x0 + 2 * w + (n >> 2), y = y0 + 2 * (n & 3) + (v >> 3), z = z0 + (v & 7);
         const long long ovox = (((long long)b * D + x) * D + y) * D + z;
-        epilogue_single_bf16(a, acc[n], ovox, g);
+        f32x4 r = acc[n] + bias4;
+        if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        u16x4 o;
+        o[0] = f2bf(r.x); o[1] = f2bf(r.y); o[2] = f2bf(r.z); o[3] = f2bf(r.w);
+        *reinterpret_cast<u16x4*>(a.out + ovox * 16 + 4 * g) = o;
     }
 }
 
 }  // namespace
+
+#ifdef SE_STAMPB
+static unsigned long long* g_stampb = nullptr;
+extern "C" void se_debug_set_stamp_buffer_b(void* p) { g_stampb = reinterpret_cast<unsigned long long*>(p); }
+#endif
+
+static bool epi_has_res_host(const ConvBArgs& a) { return a.res && (a.flags & (SE_EPI_RES_PRE_RELU | SE_EPI_RES_POST_RELU)); }
 
 int se_conv3d_bf16_tiled_try(const ConvBArgs& a, int batch, int ksize, hipStream_t s) {
     if (ksize == 3 && a.dim % 16 == 0 && a.cin_pad % 16 == 0 && a.cout % 32 == 0 && a.kpc == K3_KPC && a.total_vox < (1LL << 31)) {
@@ -342,12 +389,17 @@ int se_conv3d_bf16_tiled_try(const ConvBArgs& a, int batch, int ksize, hipStream
             attr_set = true;
         }
         const int tx = a.dim / K3_TX, ty = a.dim / K3_TY, tz = a.dim / K3_TZ;
+#ifdef SE_STAMPB
+        hipLaunchKernelGGL(conv_bf16_k3_kernel, dim3((unsigned)(batch * tx * ty * tz), a.cout / 32), dim3(256), K3_LDS_BYTES, s,
+                           a, tx, ty, tz, g_stampb);
+#else
         hipLaunchKernelGGL(conv_bf16_k3_kernel, dim3((unsigned)(batch * tx * ty * tz), a.cout / 32), dim3(256), K3_LDS_BYTES, s,
                            a, tx, ty, tz);
+#endif
         SE_CHECK_LAUNCH();
         return 0;
     }
-    if (ksize == 7 && a.dim % 8 == 0 && a.cout == 16 && a.kpc == SE_K7B_KPC && (long long)a.dim * a.dim * a.dim * 8 < (1LL << 31)) {
+    if (ksize == 7 && a.dim % 8 == 0 && a.cout == 16 && a.kpc == SE_K7B_KPC && !epi_has_res_host(a) && (long long)a.dim * a.dim * a.dim * 8 < (1LL << 31)) {
         static bool attr_set7 = false;
         if (!attr_set7) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_k7_kernel),
