@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--v2v-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="fp32: BASELINE configs[1] (default, the headline); bf16: configs[2] (bf16 storage, f32 accumulate)")
+    ap.add_argument("--backbone-dtype", default="fp32", choices=["fp32", "bf16"], help="MIOpen backbone precision (config 3: bf16)")
     ap.add_argument("--dump-kernel-events", action="store_true", help="per-shape conv launch times to stderr")
     ap.add_argument("--graphs", action="store_true", help="replay the forward as a captured hipGraph (implies --no-kernel-events)")
     return ap.parse_args()
@@ -135,6 +136,8 @@ def main():
     bf16 = args.v2v_dtype == "bf16"
     if bf16:
         net.set_v2v_dtype("bf16")
+    if args.backbone_dtype == "bf16":
+        net.set_backbone_dtype("bf16")
     if args.graphs:
         args.no_kernel_events = True
         net.enable_graphs(True)
@@ -171,7 +174,8 @@ def main():
                   f"frames/sec VoxelNetDepth forward (256x256 img+depth, {G}^3 grid)",
         "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 storage + f32 accumulate (V2V), f32 backbone" if bf16 else "f32", "data": "synthetic",
+        "dtype": ("bf16 storage + f32 accumulate (V2V), " + args.backbone_dtype + " backbone") if bf16 else
+                 ("f32" if args.backbone_dtype == "fp32" else "f32 V2V, bf16 backbone"), "data": "synthetic",
         "config": {"workload": f"batch={args.batch}/GPU synthetic 256x256 image N(0,1) + {args.depth_kind} depth 1024x1280, "
                                f"{G}^3 grid, 15 joints, " + ("bf16 V2V (BASELINE configs[2])" if bf16 else "fp32 (BASELINE configs[1])"),
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "volume_size": G,

@@ -188,6 +188,10 @@ int se_voxelize_strided_bf16(const float* depth, const double* ray_tab, se_bf16*
                              int depth_w, int up, int pad_x, int volume_size, double cuboid_side,
                              int octs_total, int c_offset, void* stream);
 
+/* se_bias_act_nchw_f32 for a bfloat16 backbone (x, bias, residual, out bfloat16; float32 arithmetic; hw % 8 == 0). */
+int se_bias_act_nchw_bf16(const se_bf16* x, const se_bf16* bias, const se_bf16* residual, se_bf16* out,
+                          int batch, int channels, int hw, int relu, void* stream);
+
 /* Debug / benchmarking only: selects alternative kernel variants for A/B timing (0 = production dispatch). */
 void se_debug_set_variant(int variant);
 /* Debug only: u64 device buffer [workgroups][8 waves][4]; non-NULL switches the Winograd conv to its cycle-stamp build. */

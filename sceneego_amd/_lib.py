@@ -47,6 +47,7 @@ SIGNATURES = {
     "se_maxpool3d_2_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "se_unproject_gather_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "se_voxelize_strided_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _i, _i, _vp]),
+    "se_bias_act_nchw_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_debug_set_variant": (None, [_i]),
     "se_debug_set_stamp_buffer": (None, [_vp]),
 }
@@ -160,8 +161,13 @@ def intersection(buf, occ, batch, voxels, channels, stride_c):
 def bias_act_nchw(x, bias, residual, relu):
     """In place on ``x`` [N,C,H,W] (contiguous): x = relu?(x + bias[c] (+ residual))."""
     require_hip(x, bias)
-    _chk_f32(x, bias, residual)
     n, c, hh, ww = x.shape
+    if x.dtype == torch.bfloat16:
+        assert bias.dtype == torch.bfloat16 and x.is_contiguous() and (residual is None or (residual.dtype == x.dtype and residual.is_contiguous()))
+        _check(load().se_bias_act_nchw_bf16(_ptr(x), _ptr(bias), _ptr(residual), _ptr(x), n, c, hh * ww, 1 if relu else 0,
+                                            _stream()), "se_bias_act_nchw_bf16")
+        return x
+    _chk_f32(x, bias, residual)
     _check(load().se_bias_act_nchw_f32(_ptr(x), _ptr(bias), _ptr(residual), _ptr(x), n, c, hh * ww, 1 if relu else 0,
                                        _stream()), "se_bias_act_nchw_f32")
     return x

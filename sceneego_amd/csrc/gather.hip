@@ -106,3 +106,41 @@ extern "C" int se_bias_act_nchw_f32(const float* x, const float* bias, const flo
     SE_CHECK_LAUNCH();
     return 0;
 }
+
+// bfloat16 form (BASELINE config 3 backbone): 8 elements per lane, float32 arithmetic, one rounding
+namespace {
+typedef unsigned short u16x8g __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float bf2f_g(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f2bf_g(float f) { const __bf16 b = (__bf16)f; return __builtin_bit_cast(unsigned short, b); }
+__global__ __launch_bounds__(256) void bias_act_bf16_kernel(const u16x8g* __restrict__ x, const unsigned short* __restrict__ bias,
+                                                            const u16x8g* __restrict__ res, u16x8g* __restrict__ out,
+                                                            long long total8, int hw8, int channels, int relu) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+        const int c = (int)((i / hw8) % channels);
+        const float b = bf2f_g(bias[c]);
+        const u16x8g xv = x[i];
+        u16x8g rv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (res) rv = res[i];
+        u16x8g o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = bf2f_g(xv[k]) + b;
+            if (res) v += bf2f_g(rv[k]);
+            if (relu) v = fmaxf(v, 0.f);
+            o[k] = f2bf_g(v);
+        }
+        out[i] = o;
+    }
+}
+}  // namespace
+
+extern "C" int se_bias_act_nchw_bf16(const se_bf16* x, const se_bf16* bias, const se_bf16* residual, se_bf16* out, int batch,
+                                     int channels, int hw, int relu, void* stream) {
+    if (batch <= 0 || channels <= 0 || hw <= 0 || (hw & 7)) return SE_ERR_BAD_ARG;
+    const long long total8 = (long long)batch * channels * (hw / 8);
+    const unsigned grid = (unsigned)((total8 + 255) / 256 < 4096 ? (total8 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bias_act_bf16_kernel, dim3(grid), dim3(256), 0, se_stream(stream), reinterpret_cast<const u16x8g*>(x), bias,
+                       reinterpret_cast<const u16x8g*>(residual), reinterpret_cast<u16x8g*>(out), total8, hw / 8, channels, relu);
+    SE_CHECK_LAUNCH();
+    return 0;
+}

@@ -168,8 +168,8 @@ class FoldedBackbone:
 
     @torch.no_grad()
     def __call__(self, images):
-        if self.dtype == torch.float32 and self.memory_format == torch.contiguous_format and images.is_cuda:
-            return self._call_fused(images)
+        if self.memory_format == torch.contiguous_format and images.is_cuda:
+            return self._call_fused(images.to(self.dtype))
         x = images.to(self.dtype).contiguous(memory_format=self.memory_format)
         x = F.relu_(F.conv2d(x, self.stem[0], self.stem[1], stride=2, padding=3))
         x = F.max_pool2d(x, 3, stride=2, padding=1)
@@ -184,8 +184,8 @@ class FoldedBackbone:
         return x
 
     def _call_fused(self, images):
-        """fp32 NCHW on a HIP device: MIOpen convolutions WITHOUT bias + one fused HIP epilogue
-        (``se_bias_act_nchw_f32``: bias, residual add, ReLU in a single pass)."""
+        """NCHW on a HIP device (float32, or bfloat16 for config 3): MIOpen convolutions WITHOUT bias + one fused HIP
+        epilogue (``se_bias_act_nchw_f32`` / ``_bf16``: bias, residual add, ReLU in a single pass)."""
         from . import _lib
         ba = _lib.bias_act_nchw
         x = ba(F.conv2d(images.contiguous(), self.stem[0], None, stride=2, padding=3), self.stem[1], None, True)

@@ -115,6 +115,18 @@ class VoxelNetwork_depth(nn.Module):
         # float32 accumulation; joints differ from the float32 reference by more than 1e-3)
         self.v2v_dtype = torch.bfloat16 if str(config.model.get("v2v_dtype", "fp32")).lower() in ("bf16", "bfloat16") \
             else torch.float32
+        self.backbone_dtype = torch.bfloat16 if str(config.model.get("backbone_dtype", "fp32")).lower() in ("bf16", "bfloat16") \
+            else torch.float32
+
+    def set_backbone_dtype(self, dtype):
+        """'fp32' (default) / 'bf16': MIOpen 2-D backbone precision (bf16 only pays off at batch >= 16 or under hipGraph
+        replay: it issues the same number of launches)."""
+        if isinstance(dtype, str):
+            dtype = torch.bfloat16 if dtype.lower() in ("bf16", "bfloat16") else torch.float32
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.backbone_dtype = dtype
+        self._invalidate()
+        return self
 
     def set_v2v_dtype(self, dtype):
         """'fp32' / 'bf16' (or the torch dtypes); takes effect at the next forward."""
@@ -146,8 +158,9 @@ class VoxelNetwork_depth(nn.Module):
                 setattr(self, name, fn(t))
         return out
 
-    def compile(self, dtype=torch.float32):
+    def compile(self, dtype=None):
         """Fold/pack all weights for inference (done lazily by forward; call after changing weights in place)."""
+        dtype = dtype or self.backbone_dtype
         if self.training:
             raise RuntimeError("VoxelNetwork_depth runs inference only: call .eval() before forward()")
         dev = next(self.volume_net.parameters()).device

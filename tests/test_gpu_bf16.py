@@ -173,6 +173,26 @@ def test_gather_and_voxelize_bf16(oracle_constants):
     assert torch.equal(out[:, :4], want)                                    # feature octets untouched
 
 
+def test_bias_act_bf16_and_backbone():
+    x = _r(torch.from_numpy(synth.normal(4, "x", (2, 24, 8, 8))))
+    b = _r(torch.from_numpy(synth.normal(4, "b", (24,))))
+    r = _r(torch.from_numpy(synth.normal(4, "r", (2, 24, 8, 8))))
+    want = F.relu(x + b.view(1, -1, 1, 1) + r).to(BF)
+    got = _lib.bias_act_nchw(x.to(DEV).to(BF), b.to(DEV).to(BF), r.to(DEV).to(BF), True)
+    assert torch.equal(got.cpu(), want)
+    from sceneego_amd import pose_resnet
+    net = pose_resnet.get_pose_net(None).eval()
+    net.load_state_dict({k[len("backbone."):]: v for k, v in synthetic_state_dict().items() if k.startswith("backbone.")})
+    net = net.to(DEV)
+    img = torch.from_numpy(synth.normal(9, "img", (2, 3, 256, 256))).to(DEV)
+    with torch.no_grad():
+        ref = pose_resnet.FoldedBackbone(net)(img)
+        got = pose_resnet.FoldedBackbone(net, dtype=BF)(img).float()
+    rel = float((got - ref).abs().max() / ref.abs().max())
+    print(f"bf16 backbone feature error vs float32: {rel:.2e} of max")
+    assert rel < 5e-2
+
+
 def test_bad_arguments_bf16():
     lib = _lib.load()
     assert lib.se_conv3d_packed_elems_bf16(48, 32, 3, 0) == -1               # cout neither <= 16 nor a multiple of 32
