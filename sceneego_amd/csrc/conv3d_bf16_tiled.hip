@@ -203,70 +203,90 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_k3_kernel(ConvBArgs a, int t
 // registers over all octets.  Tap slots are paired so that lane groups sharing a ds_read_b128 pass read addresses that
 // differ by a multiple of 256 B (bf16_common.h, tools/lds_conflicts_bf16.py: conflict-free).
 // ------------------------------------------------------------------------------------------------
-constexpr int K7_T = 8, K7_H = 14, K7_P = 24;
-constexpr int K7_HALO_PIECES = K7_H * K7_H * K7_H;            // 2744 x 16 B
-constexpr int K7_HALO_BYTES = K7_H * K7_H * K7_P * 16;        // 75264 (z pitch padded to 24)
+// Two tile geometries: ROW16 = true: tile 8(x) x 4(y) x 16(z), a voxel tile = one row of 16 z (halo 14x10x22, 80 KB of LDS with
+// the weight buffers -> 2 workgroups per CU; needs dim % 16 == 0); ROW16 = false: tile 8x8x8, a voxel tile = 2 y rows x 8 z
+// (halo 14^3, 100 KB -> 1 workgroup per CU; dim % 8 == 0).  z pitch 24 voxels in both.
+constexpr int K7_P = 24;
 constexpr int K7_KPD = SE_K7B_SLOTS_PER_DZ / 4;               // 13 k steps per dz plane
 constexpr int K7_WBUF_BYTES = K7_KPD * 1024;                  // 13312
-constexpr int K7_LDS_BYTES = K7_HALO_BYTES + 2 * K7_WBUF_BYTES;   // 101888
 constexpr int K7_WPIECES = K7_WBUF_BYTES / 16;                // 832
-constexpr int K7_HP = (K7_HALO_PIECES + 255) / 256;           // 11
 constexpr int K7_WP = (K7_WPIECES + 255) / 256;               // 4
 
+template <bool ROW16>
+struct K7Geo {
+    static constexpr int TX = 8, TY = ROW16 ? 4 : 8, TZ = ROW16 ? 16 : 8;
+    static constexpr int HX = TX + 6, HY = TY + 6, HZ = TZ + 6;
+    static constexpr int PIECES = HX * HY * HZ;                       // 16-byte records
+    static constexpr int HALO_BYTES = HX * HY * K7_P * 16;
+    static constexpr int LDS_BYTES = HALO_BYTES + 2 * K7_WBUF_BYTES;  // 80384 / 101888
+    static constexpr int HP = (PIECES + 255) / 256;                   // 13 / 11 pieces per thread
+    // voxel tile n of wave w, lane column v -> (x, y, z) inside the output tile
+    __device__ static __forceinline__ int tx(int w, int n) { return 2 * w + (n >> 2); }
+    __device__ static __forceinline__ int ty(int n, int v) { return ROW16 ? (n & 3) : 2 * (n & 3) + (v >> 3); }
+    __device__ static __forceinline__ int tz(int v) { return ROW16 ? v : (v & 7); }
+    // LDS byte offset of tile n relative to tile 0 of the same wave (compile-time per n)
+    __device__ static __forceinline__ int tile_off(int n) { return (((n >> 2) * HY + (ROW16 ? 1 : 2) * (n & 3)) * K7_P) * 16; }
+};
+
+template <bool ROW16>
 __device__ __forceinline__ int k7_tap_offset(int sl, int g) {
     int r = 4 * sl + g;
     r = r > 48 ? 48 : r;                       // padding slots alias the last tap (zero weights)
     const int r2 = r < 28 ? r : r - 28;
     const int q7 = r2 / 7;
     const int dx = r2 - 7 * q7, dy = 2 * q7 + (r < 28 ? 0 : 1);
-    return ((dx * K7_H + dy) * K7_P) * 16;
+    return ((dx * K7Geo<ROW16>::HY + dy) * K7_P) * 16;
 }
 
-__global__ __launch_bounds__(256) void conv_bf16_k7_kernel(ConvBArgs a, int tiles) {
+template <bool ROW16>
+__global__ __launch_bounds__(256, ROW16 ? 2 : 1) void conv_bf16_k7_kernel(ConvBArgs a, int tiles_x, int tiles_y, int tiles_z) {
+    using G = K7Geo<ROW16>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* halo = lds;
-    unsigned char* wbuf = lds + K7_HALO_BYTES;
+    unsigned char* wbuf = lds + G::HALO_BYTES;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int v = lane & 15, g = lane >> 4;
     const int D = a.dim;
     const int octs = a.nchunk;
     int t = blockIdx.x;
-    const int tz = t % tiles; t /= tiles;
-    const int ty = t % tiles; t /= tiles;
-    const int tx = t % tiles;
-    const int b = t / tiles;
-    const int x0 = tx * K7_T, y0 = ty * K7_T, z0 = tz * K7_T;
+    const int tz = t % tiles_z; t /= tiles_z;
+    const int ty = t % tiles_y; t /= tiles_y;
+    const int tx = t % tiles_x;
+    const int b = t / tiles_x;
+    const int x0 = tx * G::TX, y0 = ty * G::TY, z0 = tz * G::TZ;
     const long long N = (long long)D * D * D;
     const unsigned short* inb = a.in + (long long)b * octs * N * 8;
-
-    // this thread's halo pieces: element offset inside an octet plane, LDS byte offset, in-volume mask
-    int hoff[K7_HP], hlds[K7_HP];
-    unsigned hmask = 0;
-#pragma unroll
-    for (int j = 0; j < K7_HP; ++j) {
-        const int i = tid + 256 * j;
-        const int hz = i % K7_H, hy = (i / K7_H) % K7_H, hx = i / (K7_H * K7_H);
-        const int gx = x0 + hx - 3, gy = y0 + hy - 3, gz = z0 + hz - 3;
-        const bool inside = i < K7_HALO_PIECES;
-        const bool ok = inside && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D;
-        hoff[j] = ok ? ((gx * D + gy) * D + gz) * 8 : 0;
-        hlds[j] = inside ? ((hx * K7_H + hy) * K7_P + hz) * 16 : -1;
-        hmask |= (ok ? 1u : 0u) << j;
-    }
 
     f32x4 acc[8];
 #pragma unroll
     for (int n = 0; n < 8; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const unsigned char* lbase = halo + (((2 * w) * K7_H + (v >> 3)) * K7_P + (v & 7)) * 16;
+    const unsigned char* lbase = halo + (((2 * w) * G::HY + G::ty(0, v)) * K7_P + G::tz(v)) * 16;
 
-    u16x8 hreg[K7_HP], wreg[K7_WP];
+    // halo staging: piece i = tid + 256 j -> (hx, hy, hz); addresses are recomputed per use (cheap) to save registers
+    auto halo_load = [&](u16x8 (&hreg)[G::HP], const unsigned short* plane) {
 #pragma unroll
-    for (int j = 0; j < K7_HP; ++j) {
-        hreg[j] = zero8();
-        if ((hmask >> j) & 1) hreg[j] = *reinterpret_cast<const u16x8*>(inb + hoff[j]);
-    }
+        for (int j = 0; j < G::HP; ++j) {
+            const int i = tid + 256 * j;
+            const int hz = i % G::HZ, hy = (i / G::HZ) % G::HY, hx = i / (G::HZ * G::HY);
+            const int gx = x0 + hx - 3, gy = y0 + hy - 3, gz = z0 + hz - 3;
+            const bool ok = i < G::PIECES && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D;
+            const u16x8 val = *reinterpret_cast<const u16x8*>(plane + (ok ? ((gx * D + gy) * D + gz) * 8 : 0));
+            hreg[j] = ok ? val : zero8();
+        }
+    };
+    auto halo_commit = [&](const u16x8 (&hreg)[G::HP]) {
+#pragma unroll
+        for (int j = 0; j < G::HP; ++j) {
+            const int i = tid + 256 * j;
+            const int hz = i % G::HZ, hy = (i / G::HZ) % G::HY, hx = i / (G::HZ * G::HY);
+            if (i < G::PIECES) *reinterpret_cast<u16x8*>(halo + ((hx * G::HY + hy) * K7_P + hz) * 16) = hreg[j];
+        }
+    };
+
+    u16x8 hreg[G::HP], wreg[K7_WP];
+    halo_load(hreg, inb);
 #pragma unroll
     for (int j = 0; j < K7_WP; ++j) {
         const int i = tid + 256 * j;
@@ -277,9 +297,7 @@ __global__ __launch_bounds__(256) void conv_bf16_k7_kernel(ConvBArgs a, int tile
     const int phases = octs * 7;
     for (int c = 0; c < octs; ++c) {
         __syncthreads();                      // previous octet fully consumed
-#pragma unroll
-        for (int j = 0; j < K7_HP; ++j)
-            if (hlds[j] >= 0) *reinterpret_cast<u16x8*>(halo + hlds[j]) = hreg[j];
+        halo_commit(hreg);
         if (c == 0) {
 #pragma unroll
             for (int j = 0; j < K7_WP; ++j) {
@@ -299,22 +317,15 @@ __global__ __launch_bounds__(256) void conv_bf16_k7_kernel(ConvBArgs a, int tile
                     if (i < K7_WPIECES) wreg[j] = *reinterpret_cast<const u16x8*>(src + (size_t)i * 8);
                 }
             }
-            if (dz == 6 && c + 1 < octs) {     // next octet's halo: in flight under the last dz plane
-                const unsigned short* inc = inb + (long long)(c + 1) * N * 8;
-#pragma unroll
-                for (int j = 0; j < K7_HP; ++j) {
-                    hreg[j] = zero8();
-                    if ((hmask >> j) & 1) hreg[j] = *reinterpret_cast<const u16x8*>(inc + hoff[j]);
-                }
-            }
+            if (dz == 6 && c + 1 < octs) halo_load(hreg, inb + (long long)(c + 1) * N * 8);   // in flight under the last dz plane
             const unsigned char* wb = wbuf + cur * K7_WBUF_BYTES + lane * 16;
             const unsigned char* lz = lbase + dz * 16;
             u16x8 A, Bf[8];
             {
-                const unsigned char* bp = lz + k7_tap_offset(0, g);
+                const unsigned char* bp = lz + k7_tap_offset<ROW16>(0, g);
                 A = lds_read16(wb);
 #pragma unroll
-                for (int n = 0; n < 8; ++n) Bf[n] = lds_read16(bp + (((n >> 2) * K7_H + 2 * (n & 3)) * K7_P) * 16);
+                for (int n = 0; n < 8; ++n) Bf[n] = lds_read16(bp + G::tile_off(n));
                 __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
             }
 #pragma unroll
@@ -323,10 +334,10 @@ __global__ __launch_bounds__(256) void conv_bf16_k7_kernel(ConvBArgs a, int tile
 #pragma unroll
                 for (int n = 0; n < 8; ++n) nB[n] = Bf[n];
                 if (sl + 1 < K7_KPD) {
-                    const unsigned char* bp = lz + k7_tap_offset(sl + 1, g);
+                    const unsigned char* bp = lz + k7_tap_offset<ROW16>(sl + 1, g);
                     nA = lds_read16(wb + (sl + 1) * 1024);
 #pragma unroll
-                    for (int n = 0; n < 8; ++n) nB[n] = lds_read16(bp + (((n >> 2) * K7_H + 2 * (n & 3)) * K7_P) * 16);
+                    for (int n = 0; n < 8; ++n) nB[n] = lds_read16(bp + G::tile_off(n));
                 }
 #pragma unroll
                 for (int n = 0; n < 8; ++n) acc[n] = mfma_bf16(A, Bf[n], acc[n]);
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(256) void conv_bf16_k7_kernel(ConvBArgs a, int tile
     const bool relu = a.flags & SE_EPI_RELU;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
-        const int x = x0 + 2 * w + (n >> 2), y = y0 + 2 * (n & 3) + (v >> 3), z = z0 + (v & 7);
+        const int x = x0 + G::tx(w, n), y = y0 + G::ty(n, v), z = z0 + G::tz(v);
         const long long ovox = (((long long)b * D + x) * D + y) * D + z;
         f32x4 r = acc[n] + bias4;
         if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
@@ -370,12 +381,30 @@ __global__ __launch_bounds__(256) void conv_bf16_k7_kernel(ConvBArgs a, int tile
     }
 }
 
+template <bool ROW16>
+int launch_k7(const ConvBArgs& a, int batch, hipStream_t s) {
+    using G = K7Geo<ROW16>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_k7_kernel<ROW16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tx = a.dim / G::TX, ty = a.dim / G::TY, tz = a.dim / G::TZ;
+    hipLaunchKernelGGL(conv_bf16_k7_kernel<ROW16>, dim3((unsigned)(batch * tx * ty * tz)), dim3(256), G::LDS_BYTES, s, a, tx, ty, tz);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 #ifdef SE_STAMPB
 static unsigned long long* g_stampb = nullptr;
 extern "C" void se_debug_set_stamp_buffer_b(void* p) { g_stampb = reinterpret_cast<unsigned long long*>(p); }
 #endif
+
+extern int g_variant;   // A/B switch for tools/bench_conv.py (se_debug_set_variant, conv3d_tiled.hip)
 
 static bool epi_has_res_host(const ConvBArgs& a) { return a.res && (a.flags & (SE_EPI_RES_PRE_RELU | SE_EPI_RES_POST_RELU)); }
 
@@ -399,18 +428,9 @@ int se_conv3d_bf16_tiled_try(const ConvBArgs& a, int batch, int ksize, hipStream
         SE_CHECK_LAUNCH();
         return 0;
     }
-    if (ksize == 7 && a.dim % 8 == 0 && a.cout == 16 && a.kpc == SE_K7B_KPC && !epi_has_res_host(a) && (long long)a.dim * a.dim * a.dim * 8 < (1LL << 31)) {
-        static bool attr_set7 = false;
-        if (!attr_set7) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_k7_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, K7_LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-            attr_set7 = true;
-        }
-        const int tiles = a.dim / K7_T;
-        hipLaunchKernelGGL(conv_bf16_k7_kernel, dim3((unsigned)(batch * tiles * tiles * tiles)), dim3(256), K7_LDS_BYTES, s, a, tiles);
-        SE_CHECK_LAUNCH();
-        return 0;
+    if (ksize == 7 && a.dim % 8 == 0 && a.cout == 16 && a.kpc == SE_K7B_KPC && !epi_has_res_host(a) &&
+        (long long)a.dim * a.dim * a.dim * 8 < (1LL << 31)) {
+        return (a.dim % 16 == 0 && g_variant != 1) ? launch_k7<true>(a, batch, s) : launch_k7<false>(a, batch, s);
     }
     return SE_TILED_NOT_TAKEN_B;
 }

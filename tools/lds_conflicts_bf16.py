@@ -46,7 +46,9 @@ def k7_slot(r):
     return 6, 5, False
 
 
-def k7(P=24):
+def k7(P=24, row16=False):
+    """row16: tile 8x4x16 (a voxel tile = one row of 16 z, halo 14x10x22); else tile 8x8x8 (2 y rows x 8 z, halo 14^3)."""
+    HY = 10 if row16 else 14
     res = 1
     for dz in range(7):
         for sl in range(13):
@@ -56,9 +58,9 @@ def k7(P=24):
                         v, g = l & 15, l >> 4
                         dx, dy, ok = k7_slot(4 * sl + g)
                         x = 2 * wv + (n >> 2) + dx
-                        y = 2 * (n & 3) + (v >> 3) + dy
-                        z = (v & 7) + dz
-                        return ((x * 14 + y) * P + z) * 16
+                        y = ((n & 3) if row16 else 2 * (n & 3) + (v >> 3)) + dy
+                        z = (v if row16 else (v & 7)) + dz
+                        return ((x * HY + y) * P + z) * 16
                     res = max(res, worst(addr))
     return res
 
@@ -66,4 +68,6 @@ def k7(P=24):
 if __name__ == "__main__":
     print("conv_bf16_k3_kernel  B reads, worst pass multiplicity:", k3())
     for P in (14, 16, 20, 24):
-        print(f"conv_bf16_k7_kernel  z pitch {P}: worst pass multiplicity:", k7(P))
+        print(f"conv_bf16_k7_kernel<false> (8x8x8 tile)   z pitch {P}: worst pass multiplicity:", k7(P))
+    for P in (22, 24):
+        print(f"conv_bf16_k7_kernel<true>  (8x4x16 tile)  z pitch {P}: worst pass multiplicity:", k7(P, True))
