@@ -269,17 +269,27 @@ __global__ __launch_bounds__(256) void conv3d_k3_splitk_kernel(ConvArgs a, float
         const int zz = vz + tap / 9 - 1, yy = vy + (tap / 3) % 3 - 1, xx = vx + tap % 3 - 1;
         const bool ok = vok && (unsigned)zz < (unsigned)dim && (unsigned)yy < (unsigned)dim && (unsigned)xx < (unsigned)dim;
         const float* src = a.in + (ok ? ((((long long)vb * dim + zz) * dim + yy) * dim + xx) * a.cin_pad + 4 * h : 0);
-        for (int cg = 0; cg < cgs; ++cg) {
-            f32x4 xf = {0.f, 0.f, 0.f, 0.f};
-            if (ok) xf = *reinterpret_cast<const f32x4*>(src + cg * 16);
-            const f32x4* wrow = wp + ((size_t)(cg * 27 + tap) * a.nts + nt0) * 64 + lane;
+        // the launch is latency-bound: issue the loads of 4 channel groups (4 x (1 + N_T) x 16 B per lane) before their MFMAs
+        for (int cg0 = 0; cg0 < cgs; cg0 += 4) {
+            f32x4 xf[4], wf[4][N_T];
 #pragma unroll
-            for (int n = 0; n < N_T; ++n) {
-                const f32x4 wf = wrow[n * 64];
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, xf.x, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, xf.y, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, xf.z, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, xf.w, acc[n], 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                const int cg = cg0 + u < cgs ? cg0 + u : cgs - 1;
+                xf[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ok && cg0 + u < cgs) xf[u] = *reinterpret_cast<const f32x4*>(src + cg * 16);
+                const f32x4* wrow = wp + ((size_t)(cg * 27 + tap) * a.nts + nt0) * 64 + lane;
+#pragma unroll
+                for (int n = 0; n < N_T; ++n) wf[u][n] = wrow[n * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int n = 0; n < N_T; ++n) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][n].x, xf[u].x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][n].y, xf[u].y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][n].z, xf[u].z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][n].w, xf[u].w, acc[n], 0, 0, 0);
+                }
             }
         }
     }

@@ -342,10 +342,10 @@ __global__ __launch_bounds__(256) void pointwise_chain3_bf16_kernel(
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_bf16_kernel(const float* __restrict__ feat, const int4* __restrict__ idx,
                                                           const f32x4* __restrict__ w, unsigned short* __restrict__ out,
-                                                          int texels, int octs, int voxels, int octs_total,
+                                                          int batch, int texels, int octs, int voxels, int octs_total,
                                                           int oct_offset) {
-    const int b = blockIdx.y;
-    // octet-major thread order: the 16-byte records of one octet plane are written contiguously
+    // octet-major thread order: the 16-byte records of one octet plane are written contiguously.  The table entry of a voxel
+    // (32 B) is read once and reused for the whole batch (grid.y covers batch slices of 8).
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int o = (int)(t / voxels);
     const int v = (int)(t - (long long)o * voxels);
@@ -353,17 +353,20 @@ __global__ __launch_bounds__(256) void gather_bf16_kernel(const float* __restric
     const int4 id = idx[v];
     const f32x4 wt = w[v];
     const int C = octs * 8;
-    const float* fb = feat + (size_t)b * texels * C + o * 8;
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-    // same tap order (nw, ne, sw, se) and float32 arithmetic as gather_kernel; only the store rounds to bf16
-    if (id.x >= 0) { const float* p = fb + (size_t)id.x * C; a0 += *reinterpret_cast<const f32x4*>(p) * wt.x; a1 += *reinterpret_cast<const f32x4*>(p + 4) * wt.x; }
-    if (id.y >= 0) { const float* p = fb + (size_t)id.y * C; a0 += *reinterpret_cast<const f32x4*>(p) * wt.y; a1 += *reinterpret_cast<const f32x4*>(p + 4) * wt.y; }
-    if (id.z >= 0) { const float* p = fb + (size_t)id.z * C; a0 += *reinterpret_cast<const f32x4*>(p) * wt.z; a1 += *reinterpret_cast<const f32x4*>(p + 4) * wt.z; }
-    if (id.w >= 0) { const float* p = fb + (size_t)id.w * C; a0 += *reinterpret_cast<const f32x4*>(p) * wt.w; a1 += *reinterpret_cast<const f32x4*>(p + 4) * wt.w; }
-    u16x8 r;
-    r[0] = f2bf(a0.x); r[1] = f2bf(a0.y); r[2] = f2bf(a0.z); r[3] = f2bf(a0.w);
-    r[4] = f2bf(a1.x); r[5] = f2bf(a1.y); r[6] = f2bf(a1.z); r[7] = f2bf(a1.w);
-    *reinterpret_cast<u16x8*>(out + (((size_t)b * octs_total + oct_offset + o) * voxels + v) * 8) = r;
+    const int b1 = min(batch, (int)(blockIdx.y + 1) * 8);
+    for (int b = blockIdx.y * 8; b < b1; ++b) {
+        const float* fb = feat + (size_t)b * texels * C + o * 8;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        // same tap order (nw, ne, sw, se) and float32 arithmetic as gather_kernel; only the store rounds to bf16
+        if (id.x >= 0) { const float* p = fb + (size_t)id.x * C; a0 += *reinterpret_cast<const f32x4*>(p) * wt.x; a1 += *reinterpret_cast<const f32x4*>(p + 4) * wt.x; }
+        if (id.y >= 0) { const float* p = fb + (size_t)id.y * C; a0 += *reinterpret_cast<const f32x4*>(p) * wt.y; a1 += *reinterpret_cast<const f32x4*>(p + 4) * wt.y; }
+        if (id.z >= 0) { const float* p = fb + (size_t)id.z * C; a0 += *reinterpret_cast<const f32x4*>(p) * wt.z; a1 += *reinterpret_cast<const f32x4*>(p + 4) * wt.z; }
+        if (id.w >= 0) { const float* p = fb + (size_t)id.w * C; a0 += *reinterpret_cast<const f32x4*>(p) * wt.w; a1 += *reinterpret_cast<const f32x4*>(p + 4) * wt.w; }
+        u16x8 r;
+        r[0] = f2bf(a0.x); r[1] = f2bf(a0.y); r[2] = f2bf(a0.z); r[3] = f2bf(a0.w);
+        r[4] = f2bf(a1.x); r[5] = f2bf(a1.y); r[6] = f2bf(a1.z); r[7] = f2bf(a1.w);
+        *reinterpret_cast<u16x8*>(out + (((size_t)b * octs_total + oct_offset + o) * voxels + v) * 8) = r;
+    }
 }
 
 }  // namespace
@@ -487,9 +490,9 @@ extern "C" int se_unproject_gather_bf16(const float* feat, const int* idx, const
         return SE_ERR_BAD_ARG;
     const int octs = channels / 8;
     const long long threads = (long long)voxels * octs;
-    dim3 grid((unsigned)((threads + 255) / 256), batch);
+    dim3 grid((unsigned)((threads + 255) / 256), (batch + 7) / 8);
     hipLaunchKernelGGL(gather_bf16_kernel, grid, dim3(256), 0, se_stream(stream), feat, reinterpret_cast<const int4*>(idx),
-                       reinterpret_cast<const f32x4*>(w), out, texels, octs, voxels, octs_total, out_c_offset / 8);
+                       reinterpret_cast<const f32x4*>(w), out, batch, texels, octs, voxels, octs_total, out_c_offset / 8);
     SE_CHECK_LAUNCH();
     return 0;
 }
