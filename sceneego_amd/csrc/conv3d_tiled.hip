@@ -674,7 +674,7 @@ int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) 
 
 static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s) {
     const int dim = a.dim;
-    if (ksize == 3 && (g_variant == 0 || g_variant == 4 || g_variant >= 10)) {   // production: 1-D Winograd persistent kernels
+    if (ksize == 3 && (g_variant == 0 || g_variant == 4 || (g_variant >= 10 && g_variant < 20))) {   // production: 1-D Winograd persistent kernels
         const int rc = se_conv3d_wino_try(a, batch, s);
         if (rc != SE_TILED_NOT_TAKEN) return rc;
     }
@@ -682,6 +682,13 @@ static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s)
     if (a.cout & 15) return SE_TILED_NOT_TAKEN;               // planar 15-channel output layer: direct kernel
     const int nts = a.nts;
     if (ksize == 3) {
+        // BASELINE config 5 (LDS tile-size sweep, tools/bench_conv.py --variants 21,22,23): non-persistent LDS-tiled direct
+        // kernel with 8x8x{4,8,16} output tiles = 38 / 64 / 115 KB of halo per 16-channel chunk
+        if (g_variant >= 21 && g_variant <= 23 && nts % 2 == 0 && dim % 16 == 0) {
+            if (g_variant == 21) return launch_tiled<3, 16, 4, 2>(a, batch, s);
+            if (g_variant == 22) return launch_tiled<3, 16, 8, 2>(a, batch, s);
+            return launch_tiled<3, 16, 16, 2>(a, batch, s);
+        }
         if (g_variant != 1 && g_variant != 3 && a.cout == 32 && dim >= 32 && (a.cin == 16 || a.cin == 32) && a.cin_pad == a.cin &&
             !(a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR))) {
             ensure_device_info();
