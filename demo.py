@@ -16,7 +16,8 @@ import pickle
 import torch
 
 from sceneego_amd import load_config, synth
-from sceneego_amd.preprocess import load_depth, load_image_bgr, prepare_depth, preprocess_image
+from sceneego_amd.preprocess import (DEPTH_CLAMP, load_depth, load_image_bgr, prepare_depth, preprocess_image,
+                                     preprocess_image_device)
 from sceneego_amd.voxel_net_depth import VoxelNetwork_depth
 
 JOINT_NAMES = ["Neck", "Right_shoulder", "Right_elbow", "Right_wrist", "Left_shoulder", "Left_elbow", "Left_wrist",
@@ -51,9 +52,20 @@ class Demo:
         results = []
         with torch.no_grad():
             for img_path, depth_path in self.items:
-                img = preprocess_image(load_image_bgr(img_path), self.config.image_shape)[None].to(self.device)
-                depth = prepare_depth(load_depth(depth_path), self.config.dataset.image_width,
-                                      self.config.dataset.image_height)[None].to(self.device)
+                frame = load_image_bgr(img_path)
+                W, H = self.config.dataset.image_width, self.config.dataset.image_height
+                if frame.shape[:2] == (4 * self.config.image_shape[0], 4 * self.config.image_shape[1] + 256):
+                    # raw uint8 frame to the device; crop / quarter-resize / normalise there (se_preprocess_image_u8)
+                    img = preprocess_image_device(torch.from_numpy(frame).to(self.device), self.config.image_shape)
+                else:
+                    img = preprocess_image(frame, self.config.image_shape)[None].to(self.device)
+                d = load_depth(depth_path)
+                if d.shape == (H // 2, W // 2):
+                    # half-size depth map (the demo EXRs): upload as is, clamp on the device; the voxeliser's nearest
+                    # lookup floor(x * 640 / 1024) equals the reference's two nearest resizes floor(floor(1.25 x) / 2)
+                    depth = torch.from_numpy(d).to(self.device).clamp_(max=DEPTH_CLAMP)[None]
+                else:
+                    depth = prepare_depth(d, W, H)[None].to(self.device)
                 kp, _, _, _ = self.network(img, self.network.grid_coord_proj_batch, self.network.coord_volumes,
                                            depth_map_batch=depth)
                 assert len(kp) == 1

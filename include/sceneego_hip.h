@@ -188,6 +188,13 @@ int se_voxelize_strided_bf16(const float* depth, const double* ray_tab, se_bf16*
                              int depth_w, int up, int pad_x, int volume_size, double cuboid_side,
                              int octs_total, int c_offset, void* stream);
 
+/* Image pre-processing of the demo path on the device (dataset/demo_dataset.py:72-82, utils/data_transforms.py:38-72):
+ * img BGR uint8 [B][height][width][3] -> crop crop_x columns each side -> exact 1/4 bilinear resize (= rounded mean of the
+ * central 2x2 of every 4x4 block, cv2.resize INTER_LINEAR at scale 1/4) -> /255, -mean3[c], /std3[c] in float64 ->
+ * out float32 [B][3][height/4][(width-2*crop_x)/4].  mean3 / std3: HOST pointers to 3 doubles (read at launch).   */
+int se_preprocess_image_u8(const unsigned char* img, float* out, int batch, int height, int width, int crop_x,
+                           const double* mean3, const double* std3, void* stream);
+
 /* se_bias_act_nchw_f32 for a bfloat16 backbone (x, bias, residual, out bfloat16; float32 arithmetic; hw % 8 == 0). */
 int se_bias_act_nchw_bf16(const se_bf16* x, const se_bf16* bias, const se_bf16* residual, se_bf16* out,
                           int batch, int channels, int hw, int relu, void* stream);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "se_maxpool3d_2_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "se_unproject_gather_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "se_voxelize_strided_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _i, _i, _vp]),
+    "se_preprocess_image_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "se_bias_act_nchw_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_debug_set_variant": (None, [_i]),
     "se_debug_set_stamp_buffer": (None, [_vp]),
@@ -136,6 +137,18 @@ def voxelize_full(depth, ray_tab, occ, batch, depth_h, depth_w, volume_size, cub
     assert ray_tab.dtype == torch.float64 and ray_tab.is_contiguous()
     _check(load().se_voxelize_full_f64(_ptr(depth), _ptr(ray_tab), _ptr(occ), batch, depth_h, depth_w,
                                        volume_size, float(cuboid_side), _stream()), "se_voxelize_full_f64")
+
+
+def preprocess_image_u8(img_u8, out, crop_x, mean3, std3):
+    """img_u8 [B,H,W,3] uint8 BGR on the device -> out [B,3,H/4,(W-2*crop_x)/4] float32 (normalised, reference arithmetic)."""
+    require_hip(img_u8, out)
+    assert img_u8.dtype == torch.uint8 and img_u8.is_contiguous() and img_u8.shape[-1] == 3
+    _chk_f32(out)
+    B, H, W, _ = img_u8.shape
+    m = (ctypes.c_double * 3)(*[float(x) for x in mean3])
+    sd = (ctypes.c_double * 3)(*[float(x) for x in std3])
+    _check(load().se_preprocess_image_u8(_ptr(img_u8), _ptr(out), B, H, W, crop_x, m, sd, _stream()), "se_preprocess_image_u8")
+    return out
 
 
 def unproject_gather(feat, idx, w, out, batch, texels, channels, voxels, out_stride_c, out_c_offset):

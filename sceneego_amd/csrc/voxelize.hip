@@ -153,3 +153,45 @@ extern "C" int se_voxelize_full_f64(const float* depth, const double* ray_tab, f
     SE_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Image pre-processing of the demo path (dataset/demo_dataset.py:72-82 + utils/data_transforms.py:38-72) on the device:
+// BGR uint8 [B][H][W][3] -> crop `crop_x` columns left and right -> exact 1/4 bilinear resize (cv2.resize INTER_LINEAR maps
+// dst d to src 4d + 1.5: the rounded mean of the central 2x2 of each 4x4 block) -> /255 -> (x - mean[c]) / std[c] in float64
+// like numpy (the reference applies the RGB statistics to the BGR channels as they come) -> float32 CHW.
+// mean3 / std3 are HOST pointers (3 doubles each).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
+                                                            int H, int W, int crop_x, int oh, int ow, double m0, double m1,
+                                                            double m2, double s0, double s1, double s2) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= oh * ow) return;
+    const int oy = t / ow, ox = t - oy * ow;
+    const unsigned char* p = img + ((size_t)b * H + (4 * oy + 1)) * W * 3 + (size_t)(crop_x + 4 * ox + 1) * 3;
+    const double mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int sum = p[c] + p[3 + c] + p[(size_t)W * 3 + c] + p[(size_t)W * 3 + 3 + c];
+        const int q = (sum + 2) >> 2;
+        double v = (double)q / 255.0;
+        v -= mean[c];
+        v /= sd[c];
+        out[((size_t)b * 3 + c) * oh * ow + t] = (float)v;
+    }
+}
+}  // namespace
+
+extern "C" int se_preprocess_image_u8(const unsigned char* img, float* out, int batch, int height, int width, int crop_x,
+                                      const double* mean3, const double* std3, void* stream) {
+    if (batch <= 0 || height <= 0 || width <= 0 || crop_x < 0 || !mean3 || !std3) return SE_ERR_BAD_ARG;
+    const int cw = width - 2 * crop_x;
+    if (cw <= 0 || (cw & 3) || (height & 3)) return SE_ERR_BAD_ARG;
+    const int oh = height / 4, ow = cw / 4;
+    dim3 grid((oh * ow + 255) / 256, batch);
+    hipLaunchKernelGGL(preprocess_u8_kernel, grid, dim3(256), 0, se_stream(stream), img, out, height, width, crop_x, oh, ow,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    SE_CHECK_LAUNCH();
+    return 0;
+}

@@ -54,6 +54,18 @@ def preprocess_image(img_bgr: np.ndarray, image_shape=(256, 256)) -> torch.Tenso
     return normalize_u8(small)
 
 
+def preprocess_image_device(img_bgr_u8: torch.Tensor, image_shape=(256, 256)) -> torch.Tensor:
+    """Device form of :func:`preprocess_image` for full frames: uint8 BGR [H,W,3] or [B,H,W,3] on a HIP device ->
+    [B,3,256,256] float32, same arithmetic (``se_preprocess_image_u8``).  Only the exact 1/4 scale is supported."""
+    from . import _lib
+    x = img_bgr_u8 if img_bgr_u8.dim() == 4 else img_bgr_u8[None]
+    B, H, W, _ = x.shape
+    if H != 4 * image_shape[0] or W - 256 != 4 * image_shape[1]:
+        raise ValueError(f"device pre-processing needs a {4 * image_shape[0]}x{4 * image_shape[1] + 256} frame, got {H}x{W}")
+    out = torch.empty((B, 3, image_shape[0], image_shape[1]), device=x.device, dtype=torch.float32)
+    return _lib.preprocess_image_u8(x.contiguous(), out, 128, IMG_MEAN, IMG_STD)
+
+
 def normalize_u8(small_bgr_u8: np.ndarray) -> torch.Tensor:
     """[256,256,3] uint8 (BGR) -> normalised CHW float32 (reference ``demo_dataset.py:76-82``: /255, -mean, /std, ToTensor)."""
     img = small_bgr_u8.astype(np.float64) / 255.0

@@ -205,3 +205,19 @@ def test_demo_cli_exr_depth(tmp_path, golden):
     res = d.run()
     err = float(np.abs(res[0]["predicted_keypoints"] - g["joints"][0]).max())
     assert err <= JOINT_TOL, err
+
+
+def test_scene_volumes_from_dataset_side_voxeliser(net64, oracle_constants):
+    """f3 (voxel_output=True): dataset/real_depth_utils.py:29-60 restated on the GPU feeds forward(scene_volumes=...);
+    the voxel set is bit-identical to the oracle's and the joints equal the oracle's for the same scene volume."""
+    from sceneego_amd import real_depth_utils as rdu
+    c = oracle_constants(64)
+    img, depth = synth.make_inputs(77, 2, "floor")
+    occ = rdu.depth_map_to_voxel(c.ray, depth, 2, 64, device=DEV)
+    want = torch.stack([O.depth_to_voxel_full(depth[b].numpy(), c.ray, 64, 2) for b in range(2)])
+    assert torch.equal(occ.cpu(), want)
+    assert torch.equal(rdu.depth_map_to_voxel(c.ray, depth[0].numpy(), 2, 64, device=DEV).cpu(), want[0])
+    kp, _, _, _ = net64(img.to(DEV), net64.grid_coord_proj_batch, net64.coord_volumes, scene_volumes=occ)
+    sd = synthetic_state_dict()
+    oj, _, _ = O.forward(sd, c, img, None, scene_volumes=want)
+    assert float((kp.cpu() - oj).abs().max()) <= JOINT_TOL

@@ -3,6 +3,8 @@
 Integer / index work (voxeliser) must be bit-exact; float32 kernels use the tolerances written next to
 each assertion (the f32 MFMA is an exact fmaf chain, so differences are summation-order only).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -359,3 +361,23 @@ def test_voxelize_strided_into_v2v_buffer(voxel_setup):
         assert torch.equal(got[b, :, 32], want)
     assert float(got[..., 33:36].abs().max()) == 0.0
     assert float(got[..., :32].min()) == 5.0 and float(got[..., 36:].min()) == 5.0
+
+
+def test_preprocess_image_device_matches_host():
+    """f1: crop 128 / exact quarter resize / BGR normalisation on the device == the host restatement, bit for bit."""
+    from sceneego_amd import preprocess as pp
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, size=(2, 1024, 1280, 3), dtype=np.uint8)
+    got = pp.preprocess_image_device(torch.from_numpy(frames).to(DEV)).cpu()
+    want = torch.stack([pp.preprocess_image(f) for f in frames])
+    assert got.shape == (2, 3, 256, 256) and torch.equal(got, want)
+    with pytest.raises(ValueError):
+        pp.preprocess_image_device(torch.zeros((1, 512, 640, 3), dtype=torch.uint8, device=DEV))
+    # half-size depth map: the voxeliser's own nearest lookup == the reference's two nearest resizes (host prepare_depth)
+    c = O.Constants(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sceneego_amd", "calibration",
+                                 "fisheye.calibration_05_08.json"), G=64)
+    tab = torch.from_numpy(op.build_voxelizer_ray_table(c.ray, 1280, 1024)).to(DEV)
+    d = (rng.random((1, 512, 640), dtype=np.float32) * 12).astype(np.float32)
+    a = _hip_voxelize(torch.from_numpy(d).to(DEV).clamp_(max=10.0), tab)
+    b = _hip_voxelize(pp.prepare_depth(d[0])[None].to(DEV), tab)
+    assert torch.equal(a, b)
