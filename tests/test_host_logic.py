@@ -235,3 +235,29 @@ def test_exr_piz_demo_depth_map():
     assert digest == EXR_DEMO_SHA256, digest
     out = pp.prepare_depth(d)
     assert tuple(out.shape) == (1024, 1280) and float(out.max()) == 10.0
+
+
+def test_metrics_against_reference_umeyama(golden):
+    """f4: MPJPE / PA-MPJPE on the reference's Umeyama alignment (goldens from tools/make_golden_metrics.py) + properties."""
+    import importlib.util
+    from conftest import ROOT
+    from sceneego_amd import metrics
+    spec = importlib.util.spec_from_file_location("mgm", os.path.join(ROOT, "tools", "make_golden_metrics.py"))
+    mgm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mgm)
+    est, gt = mgm.inputs()
+    g = golden("metrics")
+    c, R, t = metrics.umeyama(est, gt)
+    np.testing.assert_allclose(c, g["c"], rtol=1e-12)
+    np.testing.assert_allclose(R, g["R"], atol=1e-12)
+    np.testing.assert_allclose(t, g["t"], atol=1e-12)
+    assert abs(metrics.pa_mpjpe(est, gt) - float(g["pa_mpjpe"])) < 1e-12
+    assert abs(metrics.mpjpe(est, gt) - float(g["mpjpe"])) < 1e-12
+    np.testing.assert_allclose(metrics.global_align_sequence(est, gt), g["global_aligned"], atol=1e-12)
+    # an exact similarity transform is removed completely; a reflection is not
+    rot = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    assert metrics.pa_mpjpe(est, 2.5 * est @ rot + 1.0) < 1e-12
+    assert metrics.pa_mpjpe(est, est * np.array([1.0, 1.0, -1.0])) > 0.1
+    assert metrics.pa_mpjpe(est, est @ rot + 3.0, scale=False) < 1e-12
+    assert metrics.per_joint_error(est, gt).shape == (15,)
+    assert metrics.root_trajectory_error(est, est) == 0.0 and metrics.root_trajectory_error(est, gt, align=True) < metrics.root_trajectory_error(est, gt)
