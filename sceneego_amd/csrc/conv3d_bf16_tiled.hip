@@ -33,16 +33,28 @@ constexpr int K3_LDS_BYTES = K3_HALO_BYTES + K3_W_BYTES;      // 63232 -> two wo
 constexpr int K3_HP = (K3_HALO_PIECES + 255) / 256;           // 9 halo pieces per thread
 constexpr int K3_WP = K3_W_PIECES / 256;                      // 7 weight pieces per thread
 
+template <int TY>
+struct K3G {
+    static constexpr int HY = TY + 2;
+    static constexpr int HALO_VOX = K3_HX * HY * K3_HZ;
+    static constexpr int HALO_PIECES = HALO_VOX * 2;
+    static constexpr int HALO_BYTES = HALO_PIECES * 16;
+    static constexpr int LDS_BYTES = HALO_BYTES + K3_W_BYTES;      // TY = 8: 63232 (2 WG/CU); TY = 4: 49408 (3 WG/CU)
+    static constexpr int HP = (HALO_PIECES + 255) / 256;
+};
+
+template <int TY>
 struct K3Stage {
-    u16x8 h[K3_HP];
+    u16x8 h[K3G<TY>::HP];
     u16x8 w[K3_WP];
 };
 
-__device__ __forceinline__ void k3_load_stage(K3Stage& st, const ConvBArgs& a, const int* hvox, unsigned hmask,
+template <int TY>
+__device__ __forceinline__ void k3_load_stage(K3Stage<TY>& st, const ConvBArgs& a, const int* hvox, unsigned hmask,
                                               const unsigned short* wsrc, int c, int tid) {
     const int coff = c * 16 + (tid & 1) * 8;      // piece i = tid + 256 j: octet i & 1 = tid & 1
 #pragma unroll
-    for (int j = 0; j < K3_HP; ++j) {      // branch-free: out-of-volume pieces read voxel 0 and are zeroed by a select
+    for (int j = 0; j < K3G<TY>::HP; ++j) {      // branch-free: out-of-volume pieces read voxel 0 and are zeroed by a select
         const u16x8 val = *reinterpret_cast<const u16x8*>(a.in + (long long)hvox[j] * a.cin_pad + coff);
         st.h[j] = ((hmask >> j) & 1) ? val : zero8();
     }
@@ -54,59 +66,61 @@ __device__ __forceinline__ void k3_load_stage(K3Stage& st, const ConvBArgs& a, c
     }
 }
 
-__device__ __forceinline__ void k3_commit_stage(const K3Stage& st, unsigned char* halo, unsigned char* wts, int tid) {
+template <int TY>
+__device__ __forceinline__ void k3_commit_stage(const K3Stage<TY>& st, unsigned char* halo, unsigned char* wts, int tid) {
 #pragma unroll
-    for (int j = 0; j < K3_HP; ++j) {
+    for (int j = 0; j < K3G<TY>::HP; ++j) {
         const int i = tid + 256 * j;
-        if (i < K3_HALO_PIECES) *reinterpret_cast<u16x8*>(halo + i * 16) = st.h[j];
+        if (i < K3G<TY>::HALO_PIECES) *reinterpret_cast<u16x8*>(halo + i * 16) = st.h[j];
     }
 #pragma unroll
     for (int j = 0; j < K3_WP; ++j) *reinterpret_cast<u16x8*>(wts + (tid + 256 * j) * 16) = st.w[j];
 }
 
 // the 14 k steps of one chunk; operand fragments double-buffered, next k step's reads spread between this one's MFMAs
-__device__ __forceinline__ void k3_compute(f32x4 (&acc)[2][K3_TY], const unsigned char* brow, const unsigned char* arow, int g) {
-    u16x8 A0, A1, Bf[K3_TY];
+template <int TY>
+__device__ __forceinline__ void k3_compute(f32x4 (&acc)[2][TY], const unsigned char* brow, const unsigned char* arow, int g) {
+    u16x8 A0, A1, Bf[TY];
     {
         const int tap = g >> 1;
-        const unsigned char* bp = brow + (((tap / 9) * K3_HY + (tap / 3) % 3) * K3_HZ + tap % 3) * 32;
+        const unsigned char* bp = brow + (((tap / 9) * K3G<TY>::HY + (tap / 3) % 3) * K3_HZ + tap % 3) * 32;
         A0 = lds_read16(arow);
         A1 = lds_read16(arow + K3_KPC * 1024);
 #pragma unroll
-        for (int n = 0; n < K3_TY; ++n) Bf[n] = lds_read16(bp + n * (K3_HZ * 32));
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 + K3_TY, 0);
+        for (int n = 0; n < TY; ++n) Bf[n] = lds_read16(bp + n * (K3_HZ * 32));
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + TY, 0);
     }
 #pragma unroll
     for (int sl = 0; sl < K3_KPC; ++sl) {
-        u16x8 nA0 = A0, nA1 = A1, nB[K3_TY];
+        u16x8 nA0 = A0, nA1 = A1, nB[TY];
 #pragma unroll
-        for (int n = 0; n < K3_TY; ++n) nB[n] = Bf[n];
+        for (int n = 0; n < TY; ++n) nB[n] = Bf[n];
         if (sl + 1 < K3_KPC) {
             int tap = 2 * (sl + 1) + (g >> 1);
             tap = tap > 26 ? 26 : tap;             // padding group: zero weights, any valid address
-            const unsigned char* bp = brow + (((tap / 9) * K3_HY + (tap / 3) % 3) * K3_HZ + tap % 3) * 32;
+            const unsigned char* bp = brow + (((tap / 9) * K3G<TY>::HY + (tap / 3) % 3) * K3_HZ + tap % 3) * 32;
             nA0 = lds_read16(arow + (sl + 1) * 1024);
             nA1 = lds_read16(arow + (K3_KPC + sl + 1) * 1024);
 #pragma unroll
-            for (int n = 0; n < K3_TY; ++n) nB[n] = lds_read16(bp + n * (K3_HZ * 32));
+            for (int n = 0; n < TY; ++n) nB[n] = lds_read16(bp + n * (K3_HZ * 32));
         }
 #pragma unroll
-        for (int n = 0; n < K3_TY; ++n) {
+        for (int n = 0; n < TY; ++n) {
             acc[0][n] = mfma_bf16(A0, Bf[n], acc[0][n]);
             acc[1][n] = mfma_bf16(A1, Bf[n], acc[1][n]);
         }
         A0 = nA0; A1 = nA1;
 #pragma unroll
-        for (int n = 0; n < K3_TY; ++n) Bf[n] = nB[n];
+        for (int n = 0; n < TY; ++n) Bf[n] = nB[n];
         if (sl + 1 < K3_KPC) {
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-            for (int n = 0; n < K3_TY; ++n) {
+            for (int n = 0; n < TY; ++n) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * K3_TY, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TY, 0);
         }
     }
 }
@@ -119,10 +133,11 @@ __device__ __forceinline__ void k3_compute(f32x4 (&acc)[2][K3_TY], const unsigne
 #define K3_STAMP_ARG
 #endif
 
-__global__ __launch_bounds__(256, 2) void conv_bf16_k3_kernel(ConvBArgs a, int tiles_x, int tiles_y, int tiles_z K3_STAMP_ARG) {
+template <int TY>
+__global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void conv_bf16_k3_kernel(ConvBArgs a, int tiles_x, int tiles_y, int tiles_z K3_STAMP_ARG) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* halo = lds;
-    unsigned char* wts = lds + K3_HALO_BYTES;
+    unsigned char* wts = lds + K3G<TY>::HALO_BYTES;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int v = lane & 15, g = lane >> 4;
@@ -133,64 +148,64 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_k3_kernel(ConvBArgs a, int t
     const int ty = t % tiles_y; t /= tiles_y;
     const int tx = t % tiles_x;
     const int b = t / tiles_x;
-    const int x0 = tx * K3_TX, y0 = ty * K3_TY, z0 = tz * K3_TZ;
+    const int x0 = tx * K3_TX, y0 = ty * TY, z0 = tz * K3_TZ;
 
     // this thread's halo pieces: global voxel index and in-volume mask, fixed for the whole tile
-    int hoff[K3_HP];
+    int hoff[K3G<TY>::HP];
     unsigned hmask = 0;
 #pragma unroll
-    for (int j = 0; j < K3_HP; ++j) {
+    for (int j = 0; j < K3G<TY>::HP; ++j) {
         const int i = tid + 256 * j;
         const int hv = i >> 1;
-        const int hz = hv % K3_HZ, hy = (hv / K3_HZ) % K3_HY, hx = hv / (K3_HZ * K3_HY);
+        const int hz = hv % K3_HZ, hy = (hv / K3_HZ) % K3G<TY>::HY, hx = hv / (K3_HZ * K3G<TY>::HY);
         const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
-        const bool ok = i < K3_HALO_PIECES && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D;
+        const bool ok = i < K3G<TY>::HALO_PIECES && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D;
         hoff[j] = ok ? ((b * D + gx) * D + gy) * D + gz : 0;
         hmask |= (ok ? 1u : 0u) << j;
     }
     const unsigned short* wsrc = a.wpack + ((size_t)mb * 2 * a.ksteps) * 512;
 
-    f32x4 acc[2][K3_TY];
+    f32x4 acc[2][TY];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < K3_TY; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < TY; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const unsigned char* brow = halo + ((w * K3_HY) * K3_HZ + v) * 32 + (g & 1) * 16;
+    const unsigned char* brow = halo + ((w * K3G<TY>::HY) * K3_HZ + v) * 32 + (g & 1) * 16;
     const unsigned char* arow = wts + lane * 16;
 
     const long long obase = (((long long)b * D + (x0 + w)) * D + y0) * D + (z0 + v);   // output voxel of tile n: + n * D
     const bool has_res = epi_has_res(a);
 
-    K3Stage st;
+    K3Stage<TY> st;
     K3_STAMP(0);
-    k3_load_stage(st, a, hoff, hmask, wsrc, 0, tid);
+    k3_load_stage<TY>(st, a, hoff, hmask, wsrc, 0, tid);
     K3_STAMP(1);
     for (int c = 0; c + 1 < a.nchunk; ++c) {
         __syncthreads();                       // every wave is done reading the previous chunk
-        k3_commit_stage(st, halo, wts, tid);
+        k3_commit_stage<TY>(st, halo, wts, tid);
         __syncthreads();
         K3_STAMP(2);
-        k3_load_stage(st, a, hoff, hmask, wsrc, c + 1, tid);   // in flight under the MFMAs below
-        k3_compute(acc, brow, arow, g);
+        k3_load_stage<TY>(st, a, hoff, hmask, wsrc, c + 1, tid);   // in flight under the MFMAs below
+        k3_compute<TY>(acc, brow, arow, g);
         K3_STAMP(3);
     }
     // last chunk: the staging registers are free; fetch bias and the skip tensor under the MFMAs instead
     __syncthreads();
-    k3_commit_stage(st, halo, wts, tid);
+    k3_commit_stage<TY>(st, halo, wts, tid);
     __syncthreads();
     K3_STAMP(4);
     const EpiBias8 ebias = epi_load_bias8(a, mb, g);
-    u16x8 rv[K3_TY];
+    u16x8 rv[TY];
 #pragma unroll
-    for (int n = 0; n < K3_TY; ++n) {
+    for (int n = 0; n < TY; ++n) {
         rv[n] = zero8();
         if (has_res) rv[n] = *reinterpret_cast<const u16x8*>(a.res + (obase + (long long)n * D) * a.cout + mb * 32 + 8 * g);
     }
-    k3_compute(acc, brow, arow, g);
+    k3_compute<TY>(acc, brow, arow, g);
     K3_STAMP(5);
 #pragma unroll
-    for (int n = 0; n < K3_TY; ++n)
+    for (int n = 0; n < TY; ++n)
         epi_store_pair(a, acc[0][n], acc[1][n], ebias, has_res, rv[n], (obase + (long long)n * D) * a.cout + mb * 32 + 8 * g);
     K3_STAMP(6);
 }
@@ -602,6 +617,27 @@ static unsigned long long* g_stampb = nullptr;
 extern "C" void se_debug_set_stamp_buffer_b(void* p) { g_stampb = reinterpret_cast<unsigned long long*>(p); }
 #endif
 
+template <int TY>
+static int launch_k3(const ConvBArgs& a, int batch, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_k3_kernel<TY>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, K3G<TY>::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tx = a.dim / K3_TX, ty = a.dim / TY, tz = a.dim / K3_TZ;
+#ifdef SE_STAMPB
+    hipLaunchKernelGGL(conv_bf16_k3_kernel<TY>, dim3((unsigned)(batch * tx * ty * tz), a.cout / 32), dim3(256), K3G<TY>::LDS_BYTES, s,
+                       a, tx, ty, tz, g_stampb);
+#else
+    hipLaunchKernelGGL(conv_bf16_k3_kernel<TY>, dim3((unsigned)(batch * tx * ty * tz), a.cout / 32), dim3(256), K3G<TY>::LDS_BYTES, s,
+                       a, tx, ty, tz);
+#endif
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern int g_variant;   // A/B switch for tools/bench_conv.py (se_debug_set_variant, conv3d_tiled.hip)
 
 static bool epi_has_res_host(const ConvBArgs& a) { return a.res && (a.flags & (SE_EPI_RES_PRE_RELU | SE_EPI_RES_POST_RELU)); }
@@ -630,25 +666,8 @@ int se_conv3d_bf16_tiled_try(const ConvBArgs& a, int batch, int ksize, hipStream
             return 0;
         }
     }
-    if (ksize == 3 && a.dim % 16 == 0 && a.cin_pad % 16 == 0 && a.cout % 32 == 0 && a.kpc == K3_KPC && a.total_vox < (1LL << 31)) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_k3_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
-        const int tx = a.dim / K3_TX, ty = a.dim / K3_TY, tz = a.dim / K3_TZ;
-#ifdef SE_STAMPB
-        hipLaunchKernelGGL(conv_bf16_k3_kernel, dim3((unsigned)(batch * tx * ty * tz), a.cout / 32), dim3(256), K3_LDS_BYTES, s,
-                           a, tx, ty, tz, g_stampb);
-#else
-        hipLaunchKernelGGL(conv_bf16_k3_kernel, dim3((unsigned)(batch * tx * ty * tz), a.cout / 32), dim3(256), K3_LDS_BYTES, s,
-                           a, tx, ty, tz);
-#endif
-        SE_CHECK_LAUNCH();
-        return 0;
-    }
+    if (ksize == 3 && a.dim % 16 == 0 && a.cin_pad % 16 == 0 && a.cout % 32 == 0 && a.kpc == K3_KPC && a.total_vox < (1LL << 31))
+        return g_variant == 4 ? launch_k3<4>(a, batch, s) : launch_k3<8>(a, batch, s);   // 4: tile 4x4x16, 3 workgroups per CU (A/B)
     if (ksize == 7 && a.dim % 8 == 0 && a.cout == 16 && a.kpc == SE_K7B_KPC && !epi_has_res_host(a) &&
         (long long)a.dim * a.dim * a.dim * 8 < (1LL << 31)) {
         return (a.dim % 16 == 0 && g_variant != 1) ? launch_k7<true>(a, batch, s) : launch_k7<false>(a, batch, s);
