@@ -262,14 +262,21 @@ def v2v(sd, x, prefix="volume_net", taps=None):
 # ------------------------------------------------------------------------------------------------
 # soft-argmax  (utils/op.py:83-96)
 # ------------------------------------------------------------------------------------------------
-def integrate(volumes, coord, softmax=True):
+def integrate(volumes, coord, softmax=True, accumulate64=False):
+    """utils/op.py:83-96.  ``accumulate64``: evaluate the same formula with float64 softmax / sums from the float32 logits.
+    The float32 einsum over 64^3 = 262 144 terms is reduction-order dependent: on the same logits (equal to 5e-6) two x86 hosts
+    gave joints 6e-4 m apart (tools/diag/oracle_host_noise.py), so checks that run the oracle on an arbitrary host use the
+    float64 evaluation as the platform-stable value of the reference's formula; the goldens keep the reference's own float32."""
     B, J = volumes.shape[:2]
     shp = volumes.shape
     v = volumes.reshape(B, J, -1)
+    if accumulate64:
+        v = v.double()
     v = F.softmax(v, dim=2) if softmax else F.relu(v)
     v = v.reshape(shp)
-    cv = coord.unsqueeze(0).expand(B, -1, -1, -1, -1)
-    return torch.einsum("bnxyz, bxyzc -> bnc", v, cv), v
+    cv = coord.unsqueeze(0).expand(B, -1, -1, -1, -1).to(v.dtype)
+    kp = torch.einsum("bnxyz, bxyzc -> bnc", v, cv)
+    return (kp.float(), v.float()) if accumulate64 else (kp, v)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -277,7 +284,7 @@ def integrate(volumes, coord, softmax=True):
 # ------------------------------------------------------------------------------------------------
 @torch.no_grad()
 def forward(sd, const, images, depth=None, scene_volumes=None, with_scene=True, with_intersection=False,
-            volume_multiplier=1.0, volume_softmax=True, taps=None, times=None):
+            volume_multiplier=1.0, volume_softmax=True, taps=None, times=None, accumulate64=False):
     import time
     G = const.G
     tm = (lambda k, t0: times.__setitem__(k, times.get(k, 0.0) + time.perf_counter() - t0)) if times is not None else (lambda k, t0: None)
@@ -309,5 +316,6 @@ def forward(sd, const, images, depth=None, scene_volumes=None, with_scene=True, 
     t0 = time.perf_counter()
     logits = v2v(sd, vol, taps=taps); tm("v2v", t0)
     t0 = time.perf_counter()
-    joints, volumes = integrate(logits * volume_multiplier, const.coord, softmax=volume_softmax); tm("softargmax", t0)
+    joints, volumes = integrate(logits * volume_multiplier, const.coord, softmax=volume_softmax, accumulate64=accumulate64)
+    tm("softargmax", t0)
     return joints, big, volumes

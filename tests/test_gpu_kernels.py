@@ -305,7 +305,7 @@ def test_softargmax_kat_and_random(oracle_constants, golden):
     assert torch.equal(v2.cpu(), F.relu(vol))
     # random peaked logits
     lg = torch.from_numpy(synth.normal(4, "lg", (2, 15, 64, 64, 64), 6.0))
-    want_kp, want_v = O.integrate(lg, c.coord, softmax=True)
+    want_kp, want_v = O.integrate(lg, c.coord, softmax=True, accumulate64=True)   # float64 value of the reference formula
     kp3, v3 = op.integrate_tensor_3d_with_coordinates(lg.to(DEV), cv[:2], softmax=True)
     assert float((kp3.cpu() - want_kp).abs().max()) < 3e-4   # fp32 noise floor of a 262 144-term expectation (KAT: 1.3e-4)
     assert float((v3.cpu() - want_v).abs().max()) < 1e-6 + 1e-4 * float(want_v.max())
