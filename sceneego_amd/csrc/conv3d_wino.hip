@@ -556,7 +556,7 @@ constexpr int V43_FLOATS = 6 * HY * HX * 16;
 #endif
 
 __global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int tiles_per_dim, int ztiles, int total_tiles,
-                                                               int n_cb, int units_per_wg, unsigned long long* dbg) {
+                                                               int n_cb, int units_per_wg, int variant, unsigned long long* dbg) {
 #ifdef SE_STAMP43
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0;
 #endif
@@ -668,9 +668,21 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int t
     load_weights(cur.cb, 0);
     __syncthreads();
 
-    f32x4 part[4], resv[4];
+    // Per-item epilogue operands (running partial sums of earlier chunks, skip tensor, bias) are fetched one item AHEAD, in
+    // the middle of the previous item's MFMA block: issued at item start they sat behind the just-issued output stores and
+    // the address arithmetic ran with the matrix pipe idle (2.2 k cycles of "setup" per item in the stamp build).
+    f32x4 part[4], resv[4], part_n[4], resv_n[4];
 #pragma unroll
-    for (int z = 0; z < 4; ++z) part[z] = resv[z] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < 4; ++z) part[z] = resv[z] = part_n[z] = resv_n[z] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    long long o0 = out_offset(cur.u_lo + cur.k, cur.cb), o0_n = 0;
+    f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + cur.cb * 32 + nt * 16 + 4 * h), bias_n = bias;
+    if (chunks == 1 && use_res) {
+#pragma unroll
+        for (int z = 0; z < 4; ++z) resv[z] = *reinterpret_cast<const f32x4*>(a.res + o0 + z * zstride);
+    }
+    bool part_ready = true;     // false: the partial sums of the current item could not be prefetched (run of one unit)
+    bool res_ready = true;
+    const bool prefetch_epi = variant != 7;    // se_debug_set_variant(17): A/B, epilogue operands loaded at item start
 
 #ifdef SE_STAMP43
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
@@ -679,21 +691,21 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int t
         const WinoIter nxt = next_item(cur);
         const int u = cur.u_lo + cur.k;
         const bool last_chunk = cur.c == chunks - 1;
-        const bool lone = cur.n == 1;
         const int fetch_u = nxt.valid ? nxt.u_lo + nxt.k : u;
         const int fetch_c = nxt.valid ? nxt.c : cur.c;
-        const long long o0 = out_offset(u, cur.cb);
-        if (cur.c > 0) {
+        if (cur.c > 0 && !part_ready) {
             // a run of one unit meets the same tile again in the very next item: its stores must have landed first
-            if (lone) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (cur.n == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int z = 0; z < 4; ++z) part[z] = *reinterpret_cast<const f32x4*>(a.out + o0 + z * zstride);
         }
-        if (last_chunk && use_res) {
+        if (last_chunk && use_res && !res_ready) {
 #pragma unroll
             for (int z = 0; z < 4; ++z) resv[z] = *reinterpret_cast<const f32x4*>(a.res + o0 + z * zstride);
         }
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + cur.cb * 32 + nt * 16 + 4 * h);   // consumed in the epilogue
+        // what the NEXT item needs: decided here, loaded inside the MFMA block below
+        const bool n_part = prefetch_epi && nxt.valid && nxt.c > 0 && nxt.n > 1;
+        const bool n_res = prefetch_epi && nxt.valid && use_res && nxt.c == chunks - 1;
 
         f32x4 acc[6];
 #pragma unroll
@@ -706,6 +718,20 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int t
             constexpr int S = decltype(s_tag)::value;
             constexpr int x = S % 6;
             if constexpr (S == 3) fetch(fetch_u, fetch_c);   // next item's raw columns: global loads under the MFMAs
+            if constexpr (S == 9) {                          // ... and its epilogue operands
+                if (nxt.valid) {
+                    o0_n = out_offset(fetch_u, nxt.cb);
+                    bias_n = *reinterpret_cast<const f32x4*>(a.bpack + nxt.cb * 32 + nt * 16 + 4 * h);
+                    if (n_part) {
+#pragma unroll
+                        for (int z = 0; z < 4; ++z) part_n[z] = *reinterpret_cast<const f32x4*>(a.out + o0_n + z * zstride);
+                    }
+                    if (n_res) {
+#pragma unroll
+                        for (int z = 0; z < 4; ++z) resv_n[z] = *reinterpret_cast<const f32x4*>(a.res + o0_n + z * zstride);
+                    }
+                }
+            }
             if constexpr (S + 1 < 54) {
                 constexpr int t1 = (S + 1) / 6, x1 = (S + 1) % 6;
                 wn = wrow[(S + 1) * 128];
@@ -764,7 +790,13 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int t
         SE_ST43(4)   // epilogue
         __syncthreads();
         SE_ST43(5)   // barrier 2
+        part_ready = !(nxt.c > 0) || n_part;
+        res_ready = n_res;
         cur = nxt;
+        o0 = o0_n;
+        bias = bias_n;
+#pragma unroll
+        for (int z = 0; z < 4; ++z) { part[z] = part_n[z]; resv[z] = resv_n[z]; }
     }
 #ifdef SE_STAMP43
     if (lane == 0 && dbg) {
@@ -823,7 +855,7 @@ int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
         }
         if (per <= MAX43) {
             hipLaunchKernelGGL(conv3d_k3_wino43_kernel, dim3((n_units + per - 1) / per), dim3(512), LDS43, s, a, tiles, ztiles,
-                               total_tiles, n_cb, per, g_wino_dbg43);
+                               total_tiles, n_cb, per, g_variant >= 10 ? g_variant - 10 : 0, g_wino_dbg43);
             SE_CHECK_LAUNCH();
             return 0;
         }
