@@ -449,8 +449,10 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino_kernel(ConvArgs a, int til
     load_weights(0);
     __syncthreads();
 
-    f32x4 part[2];
-    part[0] = part[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the running partial sums of the NEXT item are fetched inside the current MFMA block (see the 3x3x3 kernel below)
+    f32x4 part[2], part_n[2];
+    part[0] = part[1] = part_n[0] = part_n[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    long long o0 = out_offset(0), o0_n = 0;
     const int n_items = chunks * n;
     for (int item = 0; item < n_items; ++item) {
         const int c = item / n, k = item - c * n;
@@ -458,12 +460,12 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino_kernel(ConvArgs a, int til
         const int c_next = has_next ? (item + 1) / n : c;
         const int k_next = has_next ? (item + 1) - c_next * n : k;
         const bool last_chunk = c == chunks - 1;
-        const long long o0 = out_offset(k);
-        if (c > 0) {
-            if (lone) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // same tile as the previous item: stores first
+        if (c > 0 && lone) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // same tile as the previous item: stores first
             part[0] = *reinterpret_cast<const f32x4*>(a.out + o0);
             part[1] = *reinterpret_cast<const f32x4*>(a.out + o0 + zstride);
         }
+        const bool n_part = has_next && c_next > 0 && !lone;
 
         f32x4 acc[8];
 #pragma unroll
@@ -479,6 +481,13 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino_kernel(ConvArgs a, int til
                 constexpr int S = decltype(s_tag)::value;
                 constexpr int g = S / 8, x = S % 8;
                 if constexpr (S == 3) fetch(k_next, c_next);   // next item's raw columns: global loads under the MFMAs
+                if constexpr (S == 11) {
+                    o0_n = out_offset(k_next);
+                    if (n_part) {
+                        part_n[0] = *reinterpret_cast<const f32x4*>(a.out + o0_n);
+                        part_n[1] = *reinterpret_cast<const f32x4*>(a.out + o0_n + zstride);
+                    }
+                }
                 if constexpr (S + 1 < 104) {
                     constexpr int g1 = (S + 1) / 8, x1 = (S + 1) % 8;
                     wn = wrow[(S + 1) * 64];
@@ -524,6 +533,9 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino_kernel(ConvArgs a, int til
         *reinterpret_cast<f32x4*>(a.out + o0 + zstride) = y1;
         if (!has_next) break;
         __syncthreads();
+        o0 = o0_n;
+        part[0] = part_n[0];
+        part[1] = part_n[1];
     }
 }
 
