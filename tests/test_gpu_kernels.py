@@ -153,6 +153,8 @@ CONV_CASES = [
     (8, 2, 128, 128, 3, True, True, True),      # split-K shapes of the real pyramid at B = 8
     (8, 4, 128, 128, 3, True, False, True),
     (2, 8, 128, 128, 3, True, True, True),
+    (4, 8, 128, 128, 3, True, True, True),      # 2048..8192 voxels: in-workgroup split-K (conv3d_k3_wavesplit_kernel)
+    (8, 8, 64, 64, 3, False, False, True),
     (1, 8, 128, 64, 3, True, False, False),
     (2, 8, 16, 32, 1, False, False, True),
     (1, 16, 32, 32, 1, True, False, True),
