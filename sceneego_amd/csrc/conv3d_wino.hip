@@ -540,6 +540,218 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino_kernel(ConvArgs a, int til
 }
 
 // ------------------------------------------------------------------------------------------------
+// F(2,7) kernel in ping-pong form (A/B only — measured 5 % SLOWER than the single-phase form, whose 416-MFMA blocks already
+// keep the matrix pipe 79 % busy; kept as a documented negative result): same arithmetic, weights, LDS layout and work units as conv3d_k7_wino_kernel,
+// but the two z pairs of a 4x8x8 tile belong to two groups of 4 waves (one wave per SIMD each) that run HALF A PHASE
+// APART: while one group issues the 416 MFMAs of its z pair, the other does A^T, the partial-sum add, the epilogue, the
+// output stores and the B^T transform + LDS commit of its next z pair (see conv3d_k3_wino43pp_kernel below).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void conv3d_k7_winopp_kernel(ConvArgs a, int tiles_per_dim, int ztiles, int total_tiles,
+                                                               int units_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;
+    float* vt = lds + K7_W_FLOATS;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4* utab = reinterpret_cast<i32x4*>(lds + K7_W_FLOATS + K7_VT_FLOATS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int G = wave >> 2;                       // group = z pair
+    const int wg = wave & 3;
+    const int vl = lane & 15;
+    const int h = lane >> 4;
+    const int dim = a.dim;
+    const int chunks = (a.cin + 3) >> 2;
+    const int rem = a.cin & 3;
+    const int u_begin = (int)blockIdx.x * units_per_wg;
+    const int u_end = min(u_begin + units_per_wg, total_tiles);
+    if (u_begin >= u_end) return;
+    const int n = u_end - u_begin;
+
+    for (int i = tid; i < n; i += 512) {
+        int t = u_begin + i;
+        i32x4 e;
+        e.w = t % tiles_per_dim; t /= tiles_per_dim;
+        e.z = t % tiles_per_dim; t /= tiles_per_dim;
+        e.y = t % ztiles; t /= ztiles;
+        e.x = t;
+        utab[i] = e;
+    }
+
+    const int ry = wg * 2 + (vl >> 3);
+    const int rx = vl & 7;
+    int toff[SE_K7W_GROUPS];
+#pragma unroll
+    for (int g = 0; g < SE_K7W_GROUPS; ++g) {
+        int tap = 4 * g + h;
+        tap = tap < 49 ? tap : 0;   // zero-weight padding
+        toff[g] = (G * 8 * K7_COLS + (ry + tap / 7) * K7_HX + rx + tap % 7) * 4;
+    }
+
+    // staging role inside the group: thread tg < 196 owns halo column tg of this group's z pair
+    const int tg = tid & 255;
+    const bool s_on = tg < K7_COLS;
+    const int s_col = s_on ? tg : 0;
+    const int s_cy = s_col / K7_HX, s_cx = s_col % K7_HX;
+    f32x4 raw[8];
+    auto fetch = [&](int k, int c) {
+        const i32x4 e = utab[k];
+        const int gy = e.z * 8 - 3 + s_cy, gx = e.w * 8 - 3 + s_cx;
+        const int gz0 = e.y * 4 + 2 * G - 3;
+        const bool okc = s_on && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim;
+        const long long base = ((((long long)e.x * dim) * dim + gy) * dim + gx) * a.cin_pad + c * 4;
+        const long long zs = (long long)dim * dim * a.cin_pad;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool ok = okc && (unsigned)(gz0 + q) < (unsigned)dim;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(a.in + (ok ? base + (gz0 + q) * zs : 0));
+            raw[q] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&]() {   // V = B^T d, rows as printed by tools/wino27_matrices.py
+        if (!s_on) return;
+        const f32x4 d0 = raw[0], d1 = raw[1], d2 = raw[2], d3 = raw[3], d4 = raw[4], d5 = raw[5], d6 = raw[6], d7 = raw[7];
+        f32x4 v[8];
+        v[0] = (d6 - d0) + 5.25f * (d2 - d4);
+        v[7] = (d7 - d1) + 5.25f * (d3 - d5);
+        const f32x4 e1 = d2 + d6 - 4.25f * d4, o1 = d1 + d5 - 4.25f * d3;
+        v[1] = e1 + o1;
+        v[2] = e1 - o1;
+        const f32x4 e2 = 0.25f * d2 - 1.25f * d4 + d6, o2 = 0.5f * d1 - 2.5f * d3 + 2.f * d5;
+        v[3] = e2 + o2;
+        v[4] = e2 - o2;
+        const f32x4 e3 = 4.f * d2 - 5.f * d4 + d6, o3 = 2.f * d1 - 2.5f * d3 + 0.5f * d5;
+        v[5] = e3 + o3;
+        v[6] = e3 - o3;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) *reinterpret_cast<f32x4*>(vt + ((G * 8 + x) * K7_COLS + s_col) * 4) = v[x];
+    };
+    auto load_weights = [&](int c) {
+        fill_lds<512>(wl, reinterpret_cast<const f32x4*>(a.wpack_d) + (size_t)c * (K7_W_FLOATS / 4), K7_W_FLOATS / 4, tid);
+    };
+    auto out_offset = [&](int k) -> long long {
+        const i32x4 e = utab[k];
+        const int oz = e.y * 4 + 2 * G, oy = e.z * 8 + ry, ox = e.w * 8 + rx;
+        return ((((long long)e.x * dim + oz) * dim + oy) * dim + ox) * 16 + 4 * h;
+    };
+    const long long zstride = (long long)dim * dim * 16;
+    const bool relu = a.flags & SE_EPI_RELU;
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + 4 * h);
+
+    __syncthreads();   // utab
+    fetch(0, 0);
+    commit();
+    load_weights(0);
+    __syncthreads();
+
+    f32x4 acc[8], part[2];
+    part[0] = part[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < 8; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    long long o0 = 0;
+    const f32x4* wrow = reinterpret_cast<const f32x4*>(wl) + lane;
+
+    for (int c = 0; c < chunks; ++c) {
+        const bool last_chunk = c == chunks - 1;
+        const bool seg_next = c + 1 < chunks;
+        const int nj = (last_chunk && rem != 0) ? rem : 4;   // uniform: real channels in this chunk
+        for (int t = 0; t <= 2 * n; ++t) {
+            const int r = t - G;
+            if (r >= 0 && !(r & 1) && (r >> 1) < n) {
+                // ------------------------------ MFMA phase of item (c, k) ------------------------------
+                __builtin_amdgcn_s_setprio(3);
+                const int k = r >> 1;
+                const bool has_next = k + 1 < n || seg_next;
+                const int k_next = k + 1 < n ? k + 1 : 0;
+                const int c_next = k + 1 < n ? c : c + 1;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                auto body = [&](auto nj_tag) {
+                    constexpr int NJ = decltype(nj_tag)::value;
+                    f32x4 w0 = wrow[0], v0 = *reinterpret_cast<const f32x4*>(vt + toff[0]);
+                    f32x4 w1 = wrow[64], v1 = *reinterpret_cast<const f32x4*>(vt + toff[0] + K7_COLS * 4);
+                    f32x4 w2 = w0, v2 = v0, w3 = w1, v3 = v1;
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    auto pairstep = [&](auto p_tag) {
+                        constexpr int P = decltype(p_tag)::value;
+                        constexpr int S0 = 2 * P, S1 = 2 * P + 1;
+                        constexpr int x0 = S0 % 8, x1 = S1 % 8;
+                        if constexpr (P == 1) { if (has_next) fetch(k_next, c_next); }   // next z pair's raw columns
+                        if constexpr (P == 3) {                                           // this item's partial sums
+                            o0 = out_offset(k);
+                            if (c > 0) {
+                                part[0] = *reinterpret_cast<const f32x4*>(a.out + o0);
+                                part[1] = *reinterpret_cast<const f32x4*>(a.out + o0 + zstride);
+                            }
+                        }
+                        if constexpr (P + 1 < 52) {
+                            constexpr int g2 = (S0 + 2) / 8, X2 = (S0 + 2) % 8, g3 = (S1 + 2) / 8, X3 = (S1 + 2) % 8;
+                            w2 = wrow[(S0 + 2) * 64];
+                            v2 = *reinterpret_cast<const f32x4*>(vt + toff[g2] + X2 * K7_COLS * 4);
+                            w3 = wrow[(S1 + 2) * 64];
+                            v3 = *reinterpret_cast<const f32x4*>(vt + toff[g3] + X3 * K7_COLS * 4);
+                        }
+                        acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, v0.x, acc[x0], 0, 0, 0);
+                        acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, v1.x, acc[x1], 0, 0, 0);
+                        if constexpr (NJ > 1) {
+                            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, v0.y, acc[x0], 0, 0, 0);
+                            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, v1.y, acc[x1], 0, 0, 0);
+                        }
+                        if constexpr (NJ > 2) {
+                            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, v0.z, acc[x0], 0, 0, 0);
+                            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, v1.z, acc[x1], 0, 0, 0);
+                        }
+                        if constexpr (NJ > 3) {
+                            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, v0.w, acc[x0], 0, 0, 0);
+                            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, v1.w, acc[x1], 0, 0, 0);
+                        }
+                        if constexpr (P + 1 < 52) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
+                        } else {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+                        }
+                        w0 = w2; v0 = v2; w1 = w3; v1 = v3;
+                    };
+                    for_each_index(pairstep, std::make_integer_sequence<int, 52>{});
+                };
+                if (nj == 4) body(std::integral_constant<int, 4>{});
+                else if (nj == 1) body(std::integral_constant<int, 1>{});
+                else if (nj == 2) body(std::integral_constant<int, 2>{});
+                else body(std::integral_constant<int, 3>{});
+                __builtin_amdgcn_s_setprio(0);
+            } else if (r >= 1 && (r & 1) && ((r - 1) >> 1) < n) {
+                // ------------------------------ finish item (c, k), stage the next z pair ------------------------------
+                const int k = (r - 1) >> 1;
+                const bool has_next = k + 1 < n || seg_next;
+                // A^T: y0 = M0 + ... + M6 ; y1 = M1 - M2 + 2 M3 - 2 M4 + M5/2 - M6/2 + M7
+                f32x4 y0 = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + acc[6]);
+                f32x4 y1 = (acc[1] - acc[2]) + 2.f * (acc[3] - acc[4]) + 0.5f * (acc[5] - acc[6]) + acc[7];
+                if (c > 0) { y0 += part[0]; y1 += part[1]; }
+                if (has_next) commit();
+                if (last_chunk) {
+                    y0 += bias; y1 += bias;
+                    if (relu) {
+                        y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
+                        y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(a.out + o0) = y0;
+                *reinterpret_cast<f32x4*>(a.out + o0 + zstride) = y1;
+            }
+            __syncthreads();
+        }
+        if (seg_next) {
+            load_weights(c + 1);
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 3x3x3 convolution with 1-D Winograd F(4,3) along z: 6 multiplies per 4 z-neighbouring outputs instead of 12
 // -> HALF the MFMAs of the direct form (F(2,3) above: 2/3).  Lavin-Gray matrices, points {0, +-1, +-2, inf}:
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
@@ -1201,6 +1413,9 @@ int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k7_wino_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k7_winopp_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
@@ -1212,8 +1427,12 @@ int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
     const int grid = total_tiles < num_cus ? total_tiles : num_cus;
     const int per = (total_tiles + grid - 1) / grid;
     if (per > MAX_UNITS) return SE_TILED_NOT_TAKEN;
-    hipLaunchKernelGGL(conv3d_k7_wino_kernel, dim3((total_tiles + per - 1) / per), dim3(512), LDS_BYTES, s, a, tiles, ztiles,
-                       total_tiles, per);
+    if (g_variant != 19)   // production: single-phase form (the ping-pong form measured 4.35 vs 4.15 ms: se_debug_set_variant(19))
+        hipLaunchKernelGGL(conv3d_k7_wino_kernel, dim3((total_tiles + per - 1) / per), dim3(512), LDS_BYTES, s, a, tiles, ztiles,
+                           total_tiles, per);
+    else
+        hipLaunchKernelGGL(conv3d_k7_winopp_kernel, dim3((total_tiles + per - 1) / per), dim3(512), LDS_BYTES, s, a, tiles, ztiles,
+                           total_tiles, per);
     SE_CHECK_LAUNCH();
     return 0;
 }

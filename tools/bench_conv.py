@@ -61,7 +61,7 @@ def main():
                 lib.se_debug_set_variant(v)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                no_res = args.no_res or (args.bf16 and k == 7)     # the bf16 front-layer kernel has no skip input
+                no_res = args.no_res or k == 7     # the front-layer Winograd / bf16 kernels have no skip input
                 _lib.conv3d(x, pc.w, pc.b, None if no_res else res, out, B, dim, cin, cin_pad, cout, k,
                             _lib.EPI_RELU | (0 if no_res else _lib.EPI_RES_PRE_RELU), None if args.bf16 else ws)
                 e1.record()
