@@ -196,7 +196,7 @@ def main():
         line["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(args.batch, G),
-            "kernel": f"conv3d 3x3x3 32->32 @{G}^3 f32 (conv3d_k3_wino43_kernel: 1-D Winograd F(4,3) on v_mfma_f32_16x16x4_f32), "
+            "kernel": f"conv3d 3x3x3 32->32 @{G}^3 f32 (conv3d_k3_wino43pp_kernel: 1-D Winograd F(4,3) on v_mfma_f32_16x16x4_f32, ping-pong wave groups), "
                       f"{len(ms) // args.steps} launches/step",
             "note": "achieved = ALGORITHMIC (direct-convolution) FLOP / launch time; the kernel executes 1/2 of them on the "
                     "matrix cores (Winograd F(4,3) along z), so executed_mfma_frac = frac / 2 is the pipe utilisation",
