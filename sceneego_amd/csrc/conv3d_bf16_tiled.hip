@@ -29,8 +29,6 @@ constexpr int K3_HALO_BYTES = K3_HALO_PIECES * 16;            // 34560
 constexpr int K3_KPC = 14;
 constexpr int K3_W_PIECES = K3_KPC * 2 * 64;                  // 1792 x 16 B
 constexpr int K3_W_BYTES = K3_W_PIECES * 16;                  // 28672
-constexpr int K3_LDS_BYTES = K3_HALO_BYTES + K3_W_BYTES;      // 63232 -> two workgroups per CU
-constexpr int K3_HP = (K3_HALO_PIECES + 255) / 256;           // 9 halo pieces per thread
 constexpr int K3_WP = K3_W_PIECES / 256;                      // 7 weight pieces per thread
 
 template <int TY>
