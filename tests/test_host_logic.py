@@ -261,3 +261,17 @@ def test_metrics_against_reference_umeyama(golden):
     assert metrics.pa_mpjpe(est, est @ rot + 3.0, scale=False) < 1e-12
     assert metrics.per_joint_error(est, gt).shape == (15,)
     assert metrics.root_trajectory_error(est, est) == 0.0 and metrics.root_trajectory_error(est, gt, align=True) < metrics.root_trajectory_error(est, gt)
+
+
+def test_bf16_kernel_lds_reads_are_conflict_free():
+    """The operand-read address patterns of the bf16 LDS-tiled kernels (tap pairing, z pitch 24, octet-on-bit-0 lane groups)
+    are modelled in tools/lds_conflicts_bf16.py; the production geometries must have no ds_read_b128 bank conflict (the PMC
+    pass on the GPU reads SQ_LDS_BANK_CONFLICT = 0 for the 3^3 kernel, profiles/r01_pmc_bf16_conv.txt)."""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("ldsc", os.path.join(ROOT, "tools", "lds_conflicts_bf16.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.k3() == 1
+    assert m.k7(24, False) == 1 and m.k7(24, True) == 1
+    assert m.k7(16, False) > 1          # the naive pitch is not conflict-free: the padding is what buys it
