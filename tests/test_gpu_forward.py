@@ -103,7 +103,7 @@ def test_scene_volumes_branch_and_none(net64, oracle_constants):
     with torch.no_grad():
         kp_vox = net64(img.to(DEV), net64.grid_coord_proj_batch, net64.coord_volumes, scene_volumes=occ.to(DEV))[0]
         assert net64(img.to(DEV), net64.grid_coord_proj_batch, net64.coord_volumes) is None
-    assert float((kp_depth - kp_vox).abs().max()) < 1e-5   # same occupancy grid -> same joints (MIOpen may pick another algo)
+    assert float((kp_depth - kp_vox).abs().max()) < 5e-5   # same occupancy grid -> same joints (MIOpen may pick another algo)
 
 
 def test_full_size_properties_b8(net64):
@@ -115,9 +115,9 @@ def test_full_size_properties_b8(net64):
     assert float((kp - kp_again).abs().max()) < 5e-5   # MIOpen's split-K (atomic) igemm kernels are not bitwise reproducible
     perm = torch.tensor([3, 1, 7, 0, 2, 6, 5, 4])
     kp_perm = _forward(net64, img[perm], depth[perm])[0]
-    assert float((kp_perm - kp[perm.to(DEV)]).abs().max()) < 1e-5
+    assert float((kp_perm - kp[perm.to(DEV)]).abs().max()) < 5e-5
     kp_one = _forward(net64, img[5:6], depth[5:6])[0]
-    assert float((kp_one - kp[5:6]).abs().max()) < 1e-5
+    assert float((kp_one - kp[5:6]).abs().max()) < 5e-5
     assert bool(torch.isfinite(kp).all())
     assert float(kp[..., 2].min()) >= 0.0 and float(kp[..., 2].max()) <= 2.0 and float(kp[..., :2].abs().max()) <= 1.0
 
@@ -129,7 +129,7 @@ def test_batch_larger_than_opt_batch_size(net64):
     depth = depth.repeat(21, 1, 1)
     kp = _forward(net64, img, depth)[0]
     assert tuple(kp.shape) == (42, 15, 3)
-    assert float((kp[0] - kp[40]).abs().max()) < 1e-5
+    assert float((kp[0] - kp[40]).abs().max()) < 5e-5
 
 
 def test_hipgraph_replay_matches_eager(net64):
