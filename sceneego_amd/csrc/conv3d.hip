@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include "conv_common.h"
+#include "wino47_matrices.h"
 
 namespace {
 
@@ -140,6 +141,33 @@ __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict
         v = wv * sc;
     }
     wpack[t] = v;
+}
+
+// Section F (k = 7, cout <= 16): 1-D Winograd F(4,7) along z.  U_xi = sum_kz G[xi][kz] * W[..][kz][dy][dx] (G: wino47_matrices.h);
+// blocks [chunk3][g(13)][xi(10)][lane][j(3)]: k lane h carries the (dy,dx) tap 4g+h (taps >= 49 are zero padding), j = channel
+// inside the 3-channel chunk.
+__global__ void pack_k7f_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
+                                float eps, float* __restrict__ out, int cout, int cin, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int j = (int)(t % 3);
+    long long r = t / 3;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int xi = (int)(r % SE_K7F_XI); r /= SE_K7F_XI;
+    const int g = (int)(r % SE_K7W_GROUPS); r /= SE_K7W_GROUPS;
+    const int tap2d = 4 * g + (lane >> 4);
+    const int cc = (int)r * 3 + j;
+    const int co = lane & 15;
+    float v = 0.f;
+    if (co < cout && cc < cin && tap2d < 49) {
+        const float sc = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
+        const float* wp = w + ((size_t)co * cin + cc) * 343 + tap2d;
+        float u = 0.f;
+#pragma unroll
+        for (int kz = 0; kz < 7; ++kz) u += SE_W47_G[xi][kz] * wp[kz * 49];
+        v = u * sc;
+    }
+    out[t] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -512,6 +540,7 @@ extern "C" long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, in
     long long n = packed_elems_a(cout, cin_pad, ksize, transposed);
     if (!transposed && ksize == 7) n += (long long)(cin_pad / 4) * SE_K7_GROUPS * (round_up16(cout) / 16) * 256;
     if (!transposed && ksize == 7 && cout <= 16) n += (long long)(cin_pad / 4) * SE_K7W_CHUNK_FLOATS;
+    if (!transposed && ksize == 7 && cout <= 16) n += (long long)((cin_pad + 2) / 3) * SE_K7F_CHUNK_FLOATS;     // section F (last)
     if (!transposed && ksize == 3 && cout % 32 == 0)
         n += (long long)(cin_pad / 16) * (cout / 32) * (SE_WINO_CHUNK_FLOATS + SE_WINO43_CHUNK_FLOATS);
     return n;
@@ -529,9 +558,17 @@ extern "C" int se_conv3d_pack_f32(const float* w, const float* b, const float* g
     const long long total = se_conv3d_packed_elems(cout, cin_pad, ksize, transposed);
     const long long total_a = packed_elems_a(cout, cin_pad, ksize, transposed);
     const long long threads = total > round_up16(cout) ? total : round_up16(cout);
+    long long total_main = total;
+    if (!transposed && ksize == 7 && cout <= 16) total_main -= (long long)((cin_pad + 2) / 3) * SE_K7F_CHUNK_FLOATS;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, se_stream(stream), w, b,
-                       gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_pad, taps, transposed, total_a, total);
+                       gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_pad, taps, transposed, total_a, total_main);
     SE_CHECK_LAUNCH();
+    if (total_main != total) {
+        const long long nf = total - total_main;
+        hipLaunchKernelGGL(pack_k7f_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, se_stream(stream), w, gamma, var, eps,
+                           wpack + total_main, cout, cin, nf);
+        SE_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -559,6 +596,8 @@ extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* b
     a.wpack_d = nullptr;
     if (ksize == 7 && cout <= 16)
         a.wpack_d = a.wpack_b + (long long)(cin_pad / 4) * SE_K7_GROUPS * (round_up16(cout) / 16) * 256;
+    a.wpack_f = nullptr;
+    if (ksize == 7 && cout <= 16) a.wpack_f = a.wpack_d + (long long)(cin_pad / 4) * SE_K7W_CHUNK_FLOATS;
     a.wpack_e = nullptr;
     if (ksize == 3 && cout % 32 == 0) a.wpack_e = a.wpack_b + (long long)(cin_pad / 16) * (cout / 32) * SE_WINO_CHUNK_FLOATS;
     if (ksize == 3 && (cout % 32)) a.wpack_b = nullptr;
@@ -612,6 +651,7 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
     a.wpack_b = nullptr;
     a.wpack_d = nullptr;
     a.wpack_e = nullptr;
+    a.wpack_f = nullptr;
     const long long vox_per_wg = 4 * 4 * 16;
     const unsigned gx = (unsigned)((a.total_vox + vox_per_wg - 1) / vox_per_wg);
     if (a.nts % 2 == 0) {

@@ -13,6 +13,9 @@
 // 1-D Winograd F(2,7) section of the packed 7x7x7 weights: per 4-channel chunk 13 (dy,dx) tap groups x 8 xi x 1 KiB
 #define SE_K7W_GROUPS 13
 #define SE_K7W_CHUNK_FLOATS (SE_K7W_GROUPS * 8 * 256)
+// 1-D Winograd F(4,7) section (F) of the packed 7x7x7 weights: per 3-channel chunk 13 (dy,dx) tap groups x 10 xi x 64 lanes x 3
+#define SE_K7F_XI 10
+#define SE_K7F_CHUNK_FLOATS (SE_K7W_GROUPS * SE_K7F_XI * 64 * 3)
 
 // G matrix of F(2,7) with interpolation points {0, 1, -1, 2, -2, 1/2, -1/2, inf} (Cook-Toom; tools/wino27_matrices.py):
 // row xi, column kz.  y = A^T [(G g) .* (B^T d)].
@@ -37,6 +40,7 @@ struct ConvArgs {
     const float* wpack_b;  // k = 7: section B [chunk4][group][nt][lane][4];  k = 3: Winograd section C (NULL if cout % 32)
     const float* wpack_e;  // k = 3, cout % 32 == 0: Winograd F(4,3) section E (else NULL)
     const float* wpack_d;  // k = 7, cout <= 16: Winograd F(2,7) section D [chunk4][g13][xi8][lane][4] (else NULL)
+    const float* wpack_f;  // k = 7, cout <= 16: Winograd F(4,7) section F [chunk3][g13][xi10][lane][3] (else NULL)
     const float* bpack;
     const float* res;
     float* out;
