@@ -32,6 +32,9 @@ extern "C" {
 #define SE_EPI_RES_PRE_RELU  2   /* y += residual BEFORE the ReLU  (Res3DBlock: relu(res + skip))     */
 #define SE_EPI_RES_POST_RELU 4   /* y += residual AFTER the ReLU   (decoder: upsample(x) + skip_x)    */
 #define SE_EPI_OUT_PLANAR    8   /* write [B][Cout][voxels] (NCDHW) instead of NDHWC                  */
+#define SE_IN_PLANAR3        16  /* se_conv3d_f32, k = 7, cout = 16, dim % 8 == 0, no residual only: `in` is
+                                  * triplet-planar [B][ceil(cin/3)][D][D][D][3] (channel c at triplet c/3,
+                                  * slot c%3; slots >= cin must be finite) - see se_unproject_gather_planar3_f32 */
 
 /* ABI version; bumped on any signature change. */
 int se_abi_version(void);
@@ -138,6 +141,17 @@ int se_maxpool3d_2_f32(const float* in, float* out, int batch, int dim, int chan
 int se_softargmax3d_f32(const float* vol, const float* coord, float* out_vol, float* joints,
                         float* scratch, int rows, int voxels, int mode, void* stream);
 long long se_softargmax3d_scratch_elems(int rows);
+
+/* Producers of the triplet-planar float32 V2V input [B][triplets_total][voxels][3] (SE_IN_PLANAR3; the 7^3 front layer
+ * fetches its halo columns from ~5x fewer cache lines than from the channels-last record).  Same arithmetic, bit for bit, as
+ * se_unproject_gather_f32 / se_voxelize_strided_f64.  The gather writes channels [0, channels) (channels = 16, 32 or 64) and
+ * ZEROES the remaining slots of its last triplet; se_voxelize_planar3_f64 then only scatters 1.0 into slot `channel`
+ * (it does not clear: call it after the gather, with channel in that cleared range, e.g. 32 for 32 feature channels).  */
+int se_unproject_gather_planar3_f32(const float* feat, const int* idx, const float* w, float* out,
+                                    int batch, int texels, int channels, int voxels, int triplets_total, void* stream);
+int se_voxelize_planar3_f64(const float* depth, const double* ray_tab, float* buf, int batch, int depth_h, int depth_w,
+                            int up, int pad_x, int volume_size, double cuboid_side,
+                            int triplets_total, int channel, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16-storage V2V (BASELINE config 3): activations and weights bfloat16 in HBM, float32 accumulation on

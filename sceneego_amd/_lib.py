@@ -13,12 +13,13 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
 EPI_RES_POST_RELU = 4
 EPI_OUT_PLANAR = 8
+IN_PLANAR3 = 16     # se_conv3d_f32, k = 7: triplet-planar input [B][ceil(cin/3)][D][D][D][3]
 
 _vp, _i, _f, _d, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong
 
@@ -29,6 +30,8 @@ SIGNATURES = {
     "se_voxelize_strided_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "se_voxelize_full_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _vp]),
     "se_unproject_gather_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "se_unproject_gather_planar3_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_voxelize_planar3_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "se_intersection_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "se_bias_act_nchw_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_conv3d_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -131,6 +134,17 @@ def voxelize_strided(depth, ray_tab, buf, batch, depth_h, depth_w, up, pad_x, vo
            "se_voxelize_strided_f64")
 
 
+def voxelize_planar3(depth, ray_tab, buf, batch, depth_h, depth_w, up, pad_x, volume_size, cuboid_side, triplets_total, channel):
+    """Scatter the occupancy into slot `channel` of a triplet-planar float32 buffer (cleared by unproject_gather_planar3)."""
+    require_hip(depth, ray_tab, buf)
+    _chk_f32(depth, buf)
+    assert ray_tab.dtype == torch.float64 and ray_tab.is_contiguous()
+    assert buf.numel() == batch * triplets_total * volume_size ** 3 * 3
+    _check(load().se_voxelize_planar3_f64(_ptr(depth), _ptr(ray_tab), _ptr(buf), batch, depth_h, depth_w, up, pad_x,
+                                          volume_size, float(cuboid_side), triplets_total, channel, _stream()),
+           "se_voxelize_planar3_f64")
+
+
 def voxelize_full(depth, ray_tab, occ, batch, depth_h, depth_w, volume_size, cuboid_side):
     require_hip(depth, ray_tab, occ)
     _chk_f32(depth, occ)
@@ -162,6 +176,15 @@ def unproject_gather(feat, idx, w, out, batch, texels, channels, voxels, out_str
         return
     _check(load().se_unproject_gather_f32(_ptr(feat), _ptr(idx), _ptr(w), _ptr(out), batch, texels, channels,
                                           voxels, out_stride_c, out_c_offset, _stream()), "se_unproject_gather_f32")
+
+
+def unproject_gather_planar3(feat, idx, w, out, batch, texels, channels, voxels, triplets_total):
+    require_hip(feat, idx, w, out)
+    _chk_f32(feat, w, out)
+    assert idx.dtype == torch.int32 and idx.is_contiguous()
+    assert out.numel() == batch * triplets_total * voxels * 3
+    _check(load().se_unproject_gather_planar3_f32(_ptr(feat), _ptr(idx), _ptr(w), _ptr(out), batch, texels, channels,
+                                                  voxels, triplets_total, _stream()), "se_unproject_gather_planar3_f32")
 
 
 def intersection(buf, occ, batch, voxels, channels, stride_c):

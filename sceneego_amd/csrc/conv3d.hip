@@ -143,20 +143,34 @@ __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict
     wpack[t] = v;
 }
 
-// Section F (k = 7, cout <= 16): 1-D Winograd F(4,7) along z.  U_xi = sum_kz G[xi][kz] * W[..][kz][dy][dx] (G: wino47_matrices.h);
-// blocks [chunk3][g(13)][xi(10)][lane][j(3)]: k lane h carries the (dy,dx) tap 4g+h (taps >= 49 are zero padding), j = channel
-// inside the 3-channel chunk.
+// Section F (k = 7, cout <= 16): 1-D Winograd F(4,7) along z.  U_xi = sum_kz G[xi][kz] * W[..][kz][dy][dx] (G: wino47_matrices.h).
+// Per 3-channel chunk and (dy,dx) tap group g (k lane h carries tap 4g+h; taps >= 49 are zero padding) the 10 xi are stored as
+// two quads and a tail so that a lane reads 4 xi x 3 channels = 48 B with three ds_read_b128:
+//   [chunk3][g(13)] { Q0 [lane][xi 0..3][j] , Q1 [lane][xi 4..7][j] , T [lane][xi 8..9][j] }   (768 + 768 + 384 floats)
 __global__ void pack_k7f_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
                                 float eps, float* __restrict__ out, int cout, int cin, long long total) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
-    const int j = (int)(t % 3);
-    long long r = t / 3;
-    const int lane = (int)(r & 63); r >>= 6;
-    const int xi = (int)(r % SE_K7F_XI); r /= SE_K7F_XI;
-    const int g = (int)(r % SE_K7W_GROUPS); r /= SE_K7W_GROUPS;
+    const int chunk = (int)(t / SE_K7F_CHUNK_FLOATS);
+    int r = (int)(t - (long long)chunk * SE_K7F_CHUNK_FLOATS);
+    const int g = r / 1920;
+    r -= g * 1920;
+    int lane, xi, j;
+    if (r < 1536) {
+        const int q = r / 768, rr = r - q * 768;
+        lane = rr / 12;
+        const int e = rr - lane * 12;
+        xi = 4 * q + e / 3;
+        j = e % 3;
+    } else {
+        const int rr = r - 1536;
+        lane = rr / 6;
+        const int e = rr - lane * 6;
+        xi = 8 + e / 3;
+        j = e % 3;
+    }
     const int tap2d = 4 * g + (lane >> 4);
-    const int cc = (int)r * 3 + j;
+    const int cc = chunk * 3 + j;
     const int co = lane & 15;
     float v = 0.f;
     if (co < cout && cc < cin && tap2d < 49) {
@@ -529,7 +543,7 @@ int launch_direct(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int se_abi_version(void) { return 4; }
+extern "C" int se_abi_version(void) { return 5; }
 
 static long long packed_elems_a(int cout, int cin_pad, int ksize, int transposed) {
     const long long taps = transposed ? 8 : (long long)ksize * ksize * ksize;
@@ -602,8 +616,10 @@ extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* b
     if (ksize == 3 && cout % 32 == 0) a.wpack_e = a.wpack_b + (long long)(cin_pad / 16) * (cout / 32) * SE_WINO_CHUNK_FLOATS;
     if (ksize == 3 && (cout % 32)) a.wpack_b = nullptr;
     if (ksize == 1) a.wpack_b = nullptr;
+    if ((flags & SE_IN_PLANAR3) && ksize != 7) return SE_ERR_BAD_ARG;
     const int took = se_conv3d_tiled_try(a, batch, ksize, s);
     if (took != SE_TILED_NOT_TAKEN) return took;
+    if (flags & SE_IN_PLANAR3) return SE_ERR_BAD_ARG;
     // small volumes with wide channels: split the taps over grid.z when the plain launch would not fill the chip
     if (ksize == 3 && !planar && a.nts % 2 == 0 && a.total_vox >= 2048 && a.total_vox <= 8192 && g_variant_direct != 1) {
         // 8^3-sized levels: in-workgroup split-K, single launch (measured 0.063 vs 0.077 ms for grid split-K + reduce at B = 8;

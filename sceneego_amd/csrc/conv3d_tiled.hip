@@ -662,7 +662,8 @@ int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) 
     for (int b0 = 0; b0 < batch; b0 += SLICE) {
         const int nb = batch - b0 < SLICE ? batch - b0 : SLICE;
         ConvArgs sl = a;
-        sl.in = a.in + (long long)b0 * vox * a.cin_pad;
+        // floats per voxel of the input: channels-last record, or 3 x ceil(cin/3) planes for the triplet-planar 7^3 input
+        sl.in = a.in + (long long)b0 * vox * ((a.flags & SE_IN_PLANAR3) ? (a.cin + 2) / 3 * 3 : a.cin_pad);
         sl.out = a.out + (long long)b0 * vox * a.cout;
         if (a.res) sl.res = a.res + (long long)b0 * vox * a.cout;
         sl.total_vox = (long long)nb * vox;
@@ -705,6 +706,7 @@ static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s)
             const int rc = se_conv3d_k7_wino_try(a, batch, s);
             if (rc != SE_TILED_NOT_TAKEN) return rc;
         }
+        if (a.flags & SE_IN_PLANAR3) return SE_ERR_BAD_ARG;
         if (g_variant != 1 && dim >= 32 && a.cout == 16 && !a.res && !(a.flags & SE_EPI_OUT_PLANAR)) {
             ensure_device_info();
             return launch_k7_persistent(a, batch, s);

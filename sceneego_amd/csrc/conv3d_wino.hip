@@ -18,12 +18,14 @@
 // Wave w of 8: z pair w>>2 (outputs z = 2*zp, 2*zp+1 of the tile), rows 2*(w&3), 2*(w&3)+1 -> one 16-position tile,
 // 4 xi x 2 cout tiles = 8 accumulators.
 #include "conv_common.h"
-#include "wino47_matrices.h"
 
 #include <type_traits>
 #include <utility>
 
 extern int g_variant;
+// F(4,7) 7^3 kernel, one translation unit per input layout (conv3d_wino47.hip compiled with -DSE_K7F_PLANAR=0 / 1)
+int se_conv3d_k7_wino47_launch_cl(const ConvArgs& a, int batch, int num_cus, hipStream_t s, unsigned long long* dbg);
+int se_conv3d_k7_wino47_launch_p3(const ConvArgs& a, int batch, int num_cus, hipStream_t s, unsigned long long* dbg);
 
 namespace {
 
@@ -537,225 +539,6 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino_kernel(ConvArgs a, int til
         o0 = o0_n;
         part[0] = part_n[0];
         part[1] = part_n[1];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 7x7x7 convolution (front layer, cout = 16) with the 1-D Winograd transform F(4,7) along z (production): 10 multiplies per
-// 4 z-neighbouring outputs instead of 28 — 1.6x fewer MFMAs than F(2,7) above, 2.8x fewer than the direct form.  Points
-// {0, +-1, +-2, +-1/2, +-3/4, inf} (tools/wino47_matrices.py -> wino47_matrices.h); float32 error of the transform on N(0,1)
-// data: 3.6e-6 mean, 3.2e-5 max per 7-tap dot product (F(2,7): 8.6e-7 / 8.2e-6; direct float32: 1.4e-7 / 7.8e-7).
-// Same structure as the F(2,7) kernel (persistent 512-thread workgroup, chunk-outer, y-domain partial sums through the output
-// tensor, B^T applied once per element when the halo is committed, G folded into the packed weights, A^T in the epilogue), but:
-//   * 3-channel chunks (33 input channels = 11 chunks exactly): 13 tap groups x 10 xi x 768 B = 97.5 KB of weights in LDS,
-//   * a tile is 8(z) x 8 x 8 = two z quads; one transformed tile = 2 x 10 xi x 14 x 14 x 12 B = 46 KB,
-//   * wave w: z quad w >> 2, rows 2 (w & 3), +1 -> one 16-position tile, 10 accumulators (one per xi), 390 MFMAs per item.
-// ------------------------------------------------------------------------------------------------
-struct f32x3 { float x, y, z; };
-constexpr int K7F_VT_FLOATS = 2 * SE_K7F_XI * K7_COLS * 3;                     // 11760 floats = 47040 B
-constexpr int K7F_W_FLOATS = SE_K7F_CHUNK_FLOATS;                              // 24960 floats = 99840 B
-constexpr int K7F_SUBSTEPS = SE_K7W_GROUPS * SE_K7F_XI;                        // 130
-
-__global__ __launch_bounds__(512) void conv3d_k7_wino47_kernel(ConvArgs a, int tiles_per_dim, int ztiles, int total_tiles,
-                                                               int units_per_wg) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wl = lds;
-    float* vt = lds + K7F_W_FLOATS;
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4* utab = reinterpret_cast<i32x4*>(lds + K7F_W_FLOATS + K7F_VT_FLOATS);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int vl = lane & 15;
-    const int h = lane >> 4;
-    const int dim = a.dim;
-    const int chunks = (a.cin + 2) / 3;
-    const int u_begin = (int)blockIdx.x * units_per_wg;
-    const int u_end = min(u_begin + units_per_wg, total_tiles);
-    if (u_begin >= u_end) return;
-    const int n = u_end - u_begin;
-
-    for (int i = tid; i < n; i += 512) {
-        int t = u_begin + i;
-        i32x4 e;
-        e.w = t % tiles_per_dim; t /= tiles_per_dim;
-        e.z = t % tiles_per_dim; t /= tiles_per_dim;
-        e.y = t % ztiles; t /= ztiles;
-        e.x = t;
-        utab[i] = e;
-    }
-
-    // compute role: z quad zq, 16 positions (rows 2m, 2m+1 of the 8x8 tile)
-    const int zq = wave >> 2;
-    const int ry = (wave & 3) * 2 + (vl >> 3);
-    const int rx = vl & 7;
-    int toff[SE_K7W_GROUPS];       // per-lane LDS offsets (floats) of the 13 tap groups: tap 4g+h -> (dy,dx)
-#pragma unroll
-    for (int g = 0; g < SE_K7W_GROUPS; ++g) {
-        int tap = 4 * g + h;
-        tap = tap < 49 ? tap : 0;   // zero-weight padding
-        toff[g] = (zq * SE_K7F_XI * K7_COLS + (ry + tap / 7) * K7_HX + rx + tap % 7) * 3;
-    }
-
-    // staging role: thread t < 392 owns halo column (t % 196) of z quad (t / 196): 10 raw slabs -> 10 transformed slabs
-    const bool s_on = tid < 2 * K7_COLS;
-    const int s_col = tid % K7_COLS, s_zq = s_on ? tid / K7_COLS : 0;
-    const int s_cy = s_col / K7_HX, s_cx = s_col % K7_HX;
-    f32x3 raw[10];
-    auto fetch = [&](int k, int c) {
-        const i32x4 e = utab[k];
-        const int gy = e.z * 8 - 3 + s_cy, gx = e.w * 8 - 3 + s_cx;
-        const int gz0 = e.y * 8 + 4 * s_zq - 3;
-        const bool okc = s_on && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim;
-        const long long base = ((((long long)e.x * dim) * dim + gy) * dim + gx) * a.cin_pad + c * 3;
-        const long long zs = (long long)dim * dim * a.cin_pad;
-#pragma unroll
-        for (int q = 0; q < 10; ++q) {
-            const bool ok = okc && (unsigned)(gz0 + q) < (unsigned)dim;
-            const f32x3 t = *reinterpret_cast<const f32x3*>(a.in + (ok ? base + (gz0 + q) * zs : 0));
-            raw[q].x = ok ? t.x : 0.f; raw[q].y = ok ? t.y : 0.f; raw[q].z = ok ? t.z : 0.f;
-        }
-    };
-    auto commit = [&]() {   // V = B^T d (rows 1..8 come in +- pairs: even-q part + / - odd-q part)
-        if (!s_on) return;
-        float* dst = vt + (s_zq * SE_K7F_XI * K7_COLS + s_col) * 3;
-        auto put = [&](int xi, float vx, float vy, float vz) {
-            float* p = dst + xi * K7_COLS * 3;
-            p[0] = vx; p[1] = vy; p[2] = vz;
-        };
-        {   // xi = 0: even q only; xi = 9: odd q only
-            float ax = 0.f, ay = 0.f, az = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
-#pragma unroll
-            for (int q = 0; q < 10; ++q) {
-                if (SE_W47_BT[0][q] != 0.f) { ax += SE_W47_BT[0][q] * raw[q].x; ay += SE_W47_BT[0][q] * raw[q].y; az += SE_W47_BT[0][q] * raw[q].z; }
-                if (SE_W47_BT[9][q] != 0.f) { bx += SE_W47_BT[9][q] * raw[q].x; by += SE_W47_BT[9][q] * raw[q].y; bz += SE_W47_BT[9][q] * raw[q].z; }
-            }
-            put(0, ax, ay, az);
-            put(9, bx, by, bz);
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int xi = 2 * p + 1;
-            float ex = 0.f, ey = 0.f, ez = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
-#pragma unroll
-            for (int q = 1; q < 9; ++q) {
-                const float cf = SE_W47_BT[xi][q];
-                if (q & 1) { ox += cf * raw[q].x; oy += cf * raw[q].y; oz += cf * raw[q].z; }
-                else { ex += cf * raw[q].x; ey += cf * raw[q].y; ez += cf * raw[q].z; }
-            }
-            put(xi, ex + ox, ey + oy, ez + oz);
-            put(xi + 1, ex - ox, ey - oy, ez - oz);
-        }
-    };
-    auto load_weights = [&](int c) {
-        fill_lds<512>(wl, reinterpret_cast<const f32x4*>(a.wpack_f + (size_t)c * K7F_W_FLOATS), K7F_W_FLOATS / 4, tid);
-    };
-    auto out_offset = [&](int k) -> long long {
-        const i32x4 e = utab[k];
-        const int oz = e.y * 8 + 4 * zq, oy = e.z * 8 + ry, ox = e.w * 8 + rx;
-        return ((((long long)e.x * dim + oz) * dim + oy) * dim + ox) * 16 + 4 * h;
-    };
-    const long long zstride = (long long)dim * dim * 16;
-
-    const bool relu = a.flags & SE_EPI_RELU;
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + 4 * h);
-    const bool lone = n == 1;
-
-    __syncthreads();   // utab
-    fetch(0, 0);
-    commit();
-    load_weights(0);
-    __syncthreads();
-
-    f32x4 part[4], part_n[4];
-#pragma unroll
-    for (int z = 0; z < 4; ++z) part[z] = part_n[z] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    long long o0 = out_offset(0), o0_n = 0;
-    const int n_items = chunks * n;
-    for (int item = 0; item < n_items; ++item) {
-        const int c = item / n, k = item - c * n;
-        const bool has_next = item + 1 < n_items;
-        const int c_next = has_next ? (item + 1) / n : c;
-        const int k_next = has_next ? (item + 1) - c_next * n : k;
-        const bool last_chunk = c == chunks - 1;
-        if (c > 0 && lone) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // same tile as the previous item: stores first
-#pragma unroll
-            for (int z = 0; z < 4; ++z) part[z] = *reinterpret_cast<const f32x4*>(a.out + o0 + z * zstride);
-        }
-        const bool n_part = has_next && c_next > 0 && !lone;
-
-        f32x4 acc[SE_K7F_XI];
-#pragma unroll
-        for (int x = 0; x < SE_K7F_XI; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* wrow = wl + lane * 3;
-        // software pipeline over the 130 sub-steps (tap group, xi): operands of sub-step s+1 are read before the MFMAs of s
-        f32x3 wc = *reinterpret_cast<const f32x3*>(wrow), vc = *reinterpret_cast<const f32x3*>(vt + toff[0]);
-        f32x3 wn = wc, vn = vc;
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        auto substep = [&](auto s_tag) {
-            constexpr int S = decltype(s_tag)::value;
-            constexpr int x = S % SE_K7F_XI;
-            if constexpr (S == 3) fetch(k_next, c_next);   // next item's raw columns: global loads under the MFMAs
-            if constexpr (S == 13) {                       // ... and its running partial sums
-                o0_n = out_offset(k_next);
-                if (n_part) {
-#pragma unroll
-                    for (int z = 0; z < 4; ++z) part_n[z] = *reinterpret_cast<const f32x4*>(a.out + o0_n + z * zstride);
-                }
-            }
-            if constexpr (S + 1 < K7F_SUBSTEPS) {
-                constexpr int g1 = (S + 1) / SE_K7F_XI, x1 = (S + 1) % SE_K7F_XI;
-                wn = *reinterpret_cast<const f32x3*>(wrow + (S + 1) * 192);
-                vn = *reinterpret_cast<const f32x3*>(vt + toff[g1] + x1 * K7_COLS * 3);
-            }
-            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.x, vc.x, acc[x], 0, 0, 0);
-            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.y, vc.y, acc[x], 0, 0, 0);
-            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.z, vc.z, acc[x], 0, 0, 0);
-            if constexpr (S + 1 < K7F_SUBSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 12-byte operands: read2_b32 + read_b32 each
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            wc = wn;
-            vc = vn;
-        };
-        for_each_index(substep, std::make_integer_sequence<int, K7F_SUBSTEPS>{});
-
-        // A^T (4 x 10): xi 1..8 in +- pairs
-        f32x4 y[4];
-        {
-            const f32x4 s1 = acc[1] + acc[2], d1 = acc[1] - acc[2], s2 = acc[3] + acc[4], d2 = acc[3] - acc[4];
-            const f32x4 s3 = acc[5] + acc[6], d3 = acc[5] - acc[6], s4 = acc[7] + acc[8], d4 = acc[7] - acc[8];
-            y[0] = acc[0] + (s1 + s2) + (s3 + s4);
-            y[1] = d1 + 2.f * d2 + 0.5f * d3 + 0.75f * d4;
-            y[2] = s1 + 4.f * s2 + 0.25f * s3 + 0.5625f * s4;
-            y[3] = d1 + 8.f * d2 + 0.125f * d3 + 0.421875f * d4 + acc[9];
-        }
-        if (c > 0) {
-#pragma unroll
-            for (int z = 0; z < 4; ++z) y[z] += part[z];
-        }
-        // single transformed tile: every wave must be done reading it before the next item's columns are committed
-        __syncthreads();
-        if (has_next) {
-            commit();
-            if (c_next != c) load_weights(c_next);
-        }
-        if (last_chunk) {
-#pragma unroll
-            for (int z = 0; z < 4; ++z) {
-                y[z] += bias;
-                if (relu) {
-                    y[z].x = fmaxf(y[z].x, 0.f); y[z].y = fmaxf(y[z].y, 0.f); y[z].z = fmaxf(y[z].z, 0.f); y[z].w = fmaxf(y[z].w, 0.f);
-                }
-            }
-        }
-#pragma unroll
-        for (int z = 0; z < 4; ++z) *reinterpret_cast<f32x4*>(a.out + o0 + z * zstride) = y[z];
-        if (!has_next) break;
-        __syncthreads();
-        o0 = o0_n;
-#pragma unroll
-        for (int z = 0; z < 4; ++z) part[z] = part_n[z];
     }
 }
 
@@ -1613,7 +1396,7 @@ int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
 
 // Debug only: device buffer (grid * 8 waves * 4 u64) that makes the Winograd kernel run its STAMP build.
 extern "C" void se_debug_set_stamp_buffer(void* p) {
-#if defined(SE_STAMP43) || defined(SE_STAMPPP)
+#if defined(SE_STAMP43) || defined(SE_STAMPPP) || defined(SE_STAMP47)
     g_wino_dbg43 = reinterpret_cast<unsigned long long*>(p);
 #else
     g_wino_dbg = reinterpret_cast<unsigned long long*>(p);
@@ -1642,26 +1425,12 @@ int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
             num_cus = n;
         attr_set = true;
     }
-    if (a.wpack_f && g_variant != 17 && g_variant != 19) {       // production: F(4,7); se_debug_set_variant(17) = F(2,7)
-        constexpr int LDSF_FIXED = (K7F_W_FLOATS + K7F_VT_FLOATS) * 4;
-        constexpr int MAXF = (LDS_BYTES - LDSF_FIXED) / 16;
-        static bool attr_f = false;
-        if (!attr_f) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k7_wino47_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-            attr_f = true;
-        }
-        const int tl = dim / 8;
-        const int total_f = batch * tl * tl * tl;
-        const int grid_f = total_f < num_cus ? total_f : num_cus;
-        const int per_f = (total_f + grid_f - 1) / grid_f;
-        if (per_f <= MAXF) {
-            hipLaunchKernelGGL(conv3d_k7_wino47_kernel, dim3((total_f + per_f - 1) / per_f), dim3(512), LDS_BYTES, s, a, tl, tl, total_f, per_f);
-            SE_CHECK_LAUNCH();
-            return 0;
-        }
+    if (a.wpack_f && g_variant != 17 && g_variant != 19) {       // production: F(4,7) (conv3d_wino47.hip); se_debug_set_variant(17) = F(2,7)
+        const int rc = (a.flags & SE_IN_PLANAR3) ? se_conv3d_k7_wino47_launch_p3(a, batch, num_cus, s, g_wino_dbg43)
+                                                 : se_conv3d_k7_wino47_launch_cl(a, batch, num_cus, s, g_wino_dbg43);
+        if (rc != SE_TILED_NOT_TAKEN) return rc;
     }
+    if (a.flags & SE_IN_PLANAR3) return SE_ERR_BAD_ARG;   // only the F(4,7) kernel reads the triplet-planar layout
     const int tiles = dim / 8, ztiles = dim / 4;
     const int total_tiles = batch * ztiles * tiles * tiles;
     const int grid = total_tiles < num_cus ? total_tiles : num_cus;

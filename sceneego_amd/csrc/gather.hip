@@ -34,6 +34,52 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ f
     *reinterpret_cast<f32x4*>(o) = acc;
 }
 
+// Triplet-planar form (SE_IN_PLANAR3 input of the 7^3 layer): one thread per voxel gathers all CQ*4 channels (same tap order and
+// arithmetic as gather_kernel) and stores them as [triplet][voxel][3]: a wave writes 64 x 12 contiguous bytes per triplet.
+// Slots beyond the last channel in the last triplet are written as zero (the occupancy slot: se_voxelize_planar3_f64).
+struct f32x3s { float x, y, z; };
+template <int CQ>
+__global__ __launch_bounds__(256) void gather_planar3_kernel(const float* __restrict__ feat, const int4* __restrict__ idx,
+                                                             const f32x4* __restrict__ w, float* __restrict__ out,
+                                                             int texels, int voxels, int triplets_total) {
+    constexpr int C = CQ * 4;
+    constexpr int T = (C + 2) / 3;
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= voxels) return;
+    const int4 id = idx[v];
+    const f32x4 wt = w[v];
+    const float* fb = feat + (size_t)b * texels * C;
+    f32x4 acc[CQ];
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (id.x >= 0) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) acc[q] += *reinterpret_cast<const f32x4*>(fb + (size_t)id.x * C + q * 4) * wt.x;
+    }
+    if (id.y >= 0) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) acc[q] += *reinterpret_cast<const f32x4*>(fb + (size_t)id.y * C + q * 4) * wt.y;
+    }
+    if (id.z >= 0) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) acc[q] += *reinterpret_cast<const f32x4*>(fb + (size_t)id.z * C + q * 4) * wt.z;
+    }
+    if (id.w >= 0) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) acc[q] += *reinterpret_cast<const f32x4*>(fb + (size_t)id.w * C + q * 4) * wt.w;
+    }
+    float f[T * 3];
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) { f[4 * q] = acc[q].x; f[4 * q + 1] = acc[q].y; f[4 * q + 2] = acc[q].z; f[4 * q + 3] = acc[q].w; }
+#pragma unroll
+    for (int c = C; c < T * 3; ++c) f[c] = 0.f;
+    float* o = out + ((size_t)b * triplets_total * voxels + v) * 3;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        *reinterpret_cast<f32x3s*>(o + (size_t)t * voxels * 3) = (f32x3s){f[3 * t], f[3 * t + 1], f[3 * t + 2]};
+}
+
 __global__ __launch_bounds__(256) void intersection_kernel(float* __restrict__ buf, const float* __restrict__ occ,
                                                            long long total_vox, int cq, int stride_c) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -60,6 +106,23 @@ extern "C" int se_unproject_gather_f32(const float* feat, const int* idx, const 
     hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, se_stream(stream), feat,
                        reinterpret_cast<const int4*>(idx), reinterpret_cast<const f32x4*>(w), out, texels, cq,
                        voxels, out_stride_c, out_c_offset);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int se_unproject_gather_planar3_f32(const float* feat, const int* idx, const float* w, float* out, int batch,
+                                               int texels, int channels, int voxels, int triplets_total, void* stream) {
+    if (batch <= 0 || texels <= 0 || voxels <= 0 || channels <= 0 || triplets_total * 3 < channels) return SE_ERR_BAD_ARG;
+    dim3 grid((unsigned)((voxels + 255) / 256), batch);
+    hipStream_t s = se_stream(stream);
+    const int4* ip = reinterpret_cast<const int4*>(idx);
+    const f32x4* wp = reinterpret_cast<const f32x4*>(w);
+    switch (channels) {
+        case 16: hipLaunchKernelGGL(gather_planar3_kernel<4>, grid, dim3(256), 0, s, feat, ip, wp, out, texels, voxels, triplets_total); break;
+        case 32: hipLaunchKernelGGL(gather_planar3_kernel<8>, grid, dim3(256), 0, s, feat, ip, wp, out, texels, voxels, triplets_total); break;
+        case 64: hipLaunchKernelGGL(gather_planar3_kernel<16>, grid, dim3(256), 0, s, feat, ip, wp, out, texels, voxels, triplets_total); break;
+        default: return SE_ERR_BAD_ARG;
+    }
     SE_CHECK_LAUNCH();
     return 0;
 }

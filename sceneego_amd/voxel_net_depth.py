@@ -109,6 +109,7 @@ class VoxelNetwork_depth(nn.Module):
         self._gather_idx = self._gather_w = self._ray_tab = self._coord_flat = None
         self._folded = None
         self.use_graphs = False
+        self.planar3_input = True      # float32 V2V input in the triplet-planar layout (False: channels-last; A/B switch)
         self._graphs = {}
         self._xbuf = {}
         # V2V storage type: "fp32" (parity path, default) or "bf16" (BASELINE config 3: bf16 activations/weights,
@@ -275,21 +276,33 @@ class VoxelNetwork_depth(nn.Module):
         bf16 = prog.dtype == torch.bfloat16
         fast_occ = (self.with_scene is True and scene_volumes is None and not self.with_intersection
                     and prog.cin_pad >= C + (8 if bf16 else 4))
-        xkey = (B, G, prog.cin_pad, str(dev), prog.dtype)
+        # float32 production case (features + depth occupancy): triplet-planar input [B,11,G,G,G,3] for the F(4,7) front layer
+        planar3 = (fast_occ and not bf16 and prog.cin == C + 1 and G % 8 == 0 and G >= 16 and self.planar3_input)
+        xkey = (B, G, prog.cin_pad, str(dev), prog.dtype, planar3)
         x = self._xbuf.get(xkey)
         if x is None:
             self._xbuf.clear()
             shape = (B, prog.cin_pad // 8, G, G, G, 8) if bf16 else (B, G, G, G, prog.cin_pad)   # bf16: octet-planar
+            if planar3:
+                shape = (B, (C + 3) // 3, G, G, G, 3)
             x = torch.zeros(shape, device=dev, dtype=prog.dtype)
             self._xbuf[xkey] = x
         xb = None
         if bf16 and not fast_occ and self.with_scene is True:
             # scene_volumes / with_intersection inputs: assembled in float32 by the _f32 operators, rounded once
             xb, x = x, torch.zeros((B, G, G, G, prog.cin_pad), device=dev, dtype=torch.float32)
-        _lib.unproject_gather(feat_nhwc, self._gather_idx, self._gather_w, x, B, feat_nhwc.shape[1] * feat_nhwc.shape[2],
-                              C, N, prog.cin_pad, 0)
+        texels = feat_nhwc.shape[1] * feat_nhwc.shape[2]
+        if planar3:
+            _lib.unproject_gather_planar3(feat_nhwc, self._gather_idx, self._gather_w, x, B, texels, C, N, x.shape[1])
+        else:
+            _lib.unproject_gather(feat_nhwc, self._gather_idx, self._gather_w, x, B, texels, C, N, prog.cin_pad, 0)
 
-        if fast_occ:
+        if planar3:
+            # the gather zeroed slot (10, 2) = channel 32; the voxeliser scatters the occupancy into it
+            depth = depth_map_batch.reshape(B, depth_map_batch.shape[-2], depth_map_batch.shape[-1]).float().contiguous()
+            _lib.voxelize_planar3(depth, self._ray_tab, x, B, depth.shape[1], depth.shape[2], op.UPSAMPLED, op.PAD_X, G,
+                                  self.cuboid_side, x.shape[1], C)
+        elif fast_occ:
             # occupancy straight into channel 32 of the V2V input (channels 33..35 cleared; 36.. are never read: the
             # 7^3 kernels walk ceil(33/4) = 9 four-channel chunks and the packed weights beyond channel 32 are zero)
             depth = depth_map_batch.reshape(B, depth_map_batch.shape[-2], depth_map_batch.shape[-1]).float().contiguous()

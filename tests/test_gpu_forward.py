@@ -221,3 +221,19 @@ def test_scene_volumes_from_dataset_side_voxeliser(net64, oracle_constants):
     sd = synthetic_state_dict()
     oj, _, _ = O.forward(sd, c, img, None, scene_volumes=want, accumulate64=True)
     assert float((kp.cpu() - oj).abs().max()) <= JOINT_TOL
+
+
+def test_planar3_input_layout_matches_channels_last(net64):
+    """The production float32 path feeds the 7^3 layer a triplet-planar V2V input; the channels-last layout (A/B switch) runs the
+    same arithmetic in the same order, so logits-derived outputs agree up to MIOpen's run-to-run noise in the backbone."""
+    img, depth = synth.make_inputs(77, 2, "floor")
+    assert net64.planar3_input
+    kp_p, _, vol_p, _ = _forward(net64, img, depth)
+    kp_p, vol_p = kp_p.clone(), vol_p.clone()
+    net64.planar3_input = False
+    try:
+        kp_c, _, vol_c, _ = _forward(net64, img, depth)
+    finally:
+        net64.planar3_input = True
+    assert float((kp_p - kp_c).abs().max()) < 5e-5
+    assert float((vol_p - vol_c).abs().max()) <= 1e-4 * float(vol_c.max())

@@ -3,6 +3,7 @@
 Integer / index work (voxeliser) must be bit-exact; float32 kernels use the tolerances written next to
 each assertion (the f32 MFMA is an exact fmaf chain, so differences are summation-order only).
 """
+import ctypes
 import os
 
 import numpy as np
@@ -383,3 +384,69 @@ def test_preprocess_image_device_matches_host():
     a = _hip_voxelize(torch.from_numpy(d).to(DEV).clamp_(max=10.0), tab)
     b = _hip_voxelize(pp.prepare_depth(d[0])[None].to(DEV), tab)
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# triplet-planar float32 V2V input (SE_IN_PLANAR3): producers and the 7^3 layer, bit-exact against the channels-last forms
+# ------------------------------------------------------------------------------------------------
+def _to_planar3(x_cl, channels):
+    """[B,G,G,G,C>=channels] channels-last -> [B,ceil(channels/3),G,G,G,3] (slots beyond `channels` zero)."""
+    B, G = x_cl.shape[0], x_cl.shape[1]
+    T = (channels + 2) // 3
+    p = torch.zeros(B, G, G, G, T * 3, device=x_cl.device)
+    p[..., :channels] = x_cl[..., :channels]
+    return p.view(B, G, G, G, T, 3).permute(0, 4, 1, 2, 3, 5).contiguous()
+
+
+def test_planar3_producers_bit_exact(voxel_setup, oracle_constants):
+    c, tab = voxel_setup
+    feat = torch.from_numpy(synth.normal(31, "feat", (2, 64, 64, 32))).to(DEV)
+    idx, w = op.build_gather_table(c.grid, (1024, 1280), 64)
+    idx, w = idx.to(DEV), w.to(DEV)
+    _, depth = synth.make_inputs(22, 2, "floor")
+    N = 64 ** 3
+    cl = torch.zeros((2, N, 48), device=DEV)
+    _lib.unproject_gather(feat, idx, w, cl, 2, 4096, 32, N, 48, 0)
+    _lib.voxelize_strided(depth.to(DEV), tab, cl, 2, 1024, 1280, 1024, 128, 64, 2, 48, 32)
+    p3 = torch.full((2, 11, N, 3), 7.0, device=DEV)      # poison: every slot of the 11 triplets must be written
+    _lib.unproject_gather_planar3(feat, idx, w, p3, 2, 4096, 32, N, 11)
+    assert float(p3[:, 10, :, 2].abs().max()) == 0.0     # the occupancy slot is cleared by the gather
+    _lib.voxelize_planar3(depth.to(DEV), tab, p3, 2, 1024, 1280, 1024, 128, 64, 2, 11, 32)
+    want = _to_planar3(cl.view(2, 64, 64, 64, 48), 33).view(2, 11, N, 3)
+    assert torch.equal(p3, want)
+    assert float(p3[:, 10, :, 2].sum()) > 0
+    # extra triplets (triplets_total > 11) are left alone
+    p4 = torch.full((1, 12, N, 3), 7.0, device=DEV)
+    _lib.unproject_gather_planar3(feat[:1], idx, w, p4, 1, 4096, 32, N, 12)
+    assert float(p4[:, 11].min()) == 7.0 and torch.equal(p4[:, :10], want[:1, :10])
+
+
+@pytest.mark.parametrize("B,dim", [(1, 16), (2, 32), (8, 64), (35, 32)])      # B > 32: sliced into launches of 32 samples
+def test_conv7_planar3_input_bit_exact(B, dim):
+    conv = nn.Conv3d(33, 16, 7, padding=3).to(DEV)
+    bn = nn.BatchNorm3d(16).to(DEV).eval()
+    with torch.no_grad():
+        bn.running_var.uniform_(0.5, 2.0); bn.running_mean.normal_(); bn.weight.normal_(); bn.bias.normal_()
+    pc = _PackedConv(conv, bn, cin_pad=48)
+    x = torch.zeros(B, dim, dim, dim, 48, device=DEV)
+    x[..., :33] = torch.randn(B, dim, dim, dim, 33, device=DEV)
+    out_cl = torch.empty((B, dim, dim, dim, 16), device=DEV)
+    _lib.conv3d(x, pc.w, pc.b, None, out_cl, B, dim, 33, 48, 16, 7, _lib.EPI_RELU)
+    out_p3 = torch.full_like(out_cl, -3.0)
+    _lib.conv3d(_to_planar3(x, 33), pc.w, pc.b, None, out_p3, B, dim, 33, 48, 16, 7, _lib.EPI_RELU | _lib.IN_PLANAR3)
+    assert torch.equal(out_cl, out_p3)
+    if dim <= 32:
+        with torch.no_grad():
+            want = torch.relu(bn(conv(_ncdhw(x[..., :33]))))
+        assert float((_ncdhw(out_p3) - want).abs().max()) < 1e-4
+
+
+def test_planar3_bad_arguments():
+    lib = _lib.load()
+    d = torch.zeros(64, device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    # the planar input flag is only defined for the 7^3 layer
+    assert lib.se_conv3d_f32(p(d), p(d), p(d), None, p(d), 1, 16, 32, 32, 32, 3, _lib.IN_PLANAR3, None, 0, None) == -1
+    assert lib.se_unproject_gather_planar3_f32(p(d), p(d), p(d), p(d), 1, 16, 20, 8, 11, None) == -1     # channels not 16/32/64
+    assert lib.se_unproject_gather_planar3_f32(p(d), p(d), p(d), p(d), 1, 16, 32, 8, 10, None) == -1     # too few triplets
+    assert lib.se_voxelize_planar3_f64(p(d), p(d), p(d), 1, 8, 8, 8, 0, 8, 2.0, 11, 33, None) == -1      # channel out of range
