@@ -9,8 +9,10 @@ same 4-tuple return as ``network/voxel_net_depth.py:19-275``; ``state_dict()`` h
 What runs underneath is this build's own pipeline (one HIP stream, no host round trips):
 
     images --MIOpen--> features[B,64,64,256] --1x1 conv--> F[B,64,64,32]          (pose_resnet.FoldedBackbone)
-    F --se_unproject_gather_f32--> X[B,G,G,G, 0:32]   (table-driven 4-tap, no 1024x1280 intermediate)
-    depth --se_voxelize_f64--> occ[B,G,G,G] --> X[..., 32]                          (float64, bit-exact)
+    F --se_unproject_gather_planar3_f32--> X channels 0..31   (table-driven 4-tap, no 1024x1280 intermediate)
+    depth --se_voxelize_planar3_f64--> X channel 32             (float64, bit-exact; occupancy straight into X)
+         X is triplet-planar [B,11,G,G,G,3] on the float32 production path; channels-last [B,G,G,G,48|80] for
+         with_intersection / scene_volumes inputs (se_unproject_gather_f32, se_voxelize_*_f64, se_intersection_f32)
     X --V2VProgram (se_conv3d_f32 / se_deconv3d_k2s2_f32 / se_maxpool3d_2_f32)--> logits[B,15,G^3]
     logits --se_softargmax3d_f32--> joints[B,15,3], volumes[B,15,G,G,G]
 
