@@ -450,3 +450,22 @@ def test_planar3_bad_arguments():
     assert lib.se_unproject_gather_planar3_f32(p(d), p(d), p(d), p(d), 1, 16, 20, 8, 11, None) == -1     # channels not 16/32/64
     assert lib.se_unproject_gather_planar3_f32(p(d), p(d), p(d), p(d), 1, 16, 32, 8, 10, None) == -1     # too few triplets
     assert lib.se_voxelize_planar3_f64(p(d), p(d), p(d), 1, 8, 8, 8, 0, 8, 2.0, 11, 33, None) == -1      # channel out of range
+
+
+@pytest.mark.parametrize("channels", [16, 64])
+def test_gather_planar3_other_channel_counts(channels):
+    """The 16- and 64-channel instantiations of the planar gather against the channels-last gather (random tap table, some
+    taps disabled): identical bits, trailing slots of the last triplet zeroed."""
+    g = torch.Generator().manual_seed(channels)
+    V, TEX, B = 1000, 96, 3
+    feat = torch.randn(B, TEX, channels, generator=g).to(DEV)
+    idx = torch.randint(-1, TEX, (V, 4), generator=g, dtype=torch.int32).to(DEV)
+    w = torch.rand(V, 4, generator=g).to(DEV)
+    cl = torch.zeros(B, V, channels, device=DEV)
+    _lib.unproject_gather(feat, idx, w, cl, B, TEX, channels, V, channels, 0)
+    T = (channels + 2) // 3
+    p3 = torch.full((B, T, V, 3), 9.0, device=DEV)
+    _lib.unproject_gather_planar3(feat, idx, w, p3, B, TEX, channels, V, T)
+    flat = p3.permute(0, 2, 1, 3).reshape(B, V, T * 3)
+    assert torch.equal(flat[..., :channels], cl)
+    assert float(flat[..., channels:].abs().max()) == 0.0
