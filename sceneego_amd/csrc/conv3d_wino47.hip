@@ -128,20 +128,29 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino47_kernel(ConvArgs a, int t
     const int s_col = tid % K7_COLS, s_zq = s_on ? tid / K7_COLS : 0;
     const int s_cy = s_col / K7_HX, s_cx = s_col % K7_HX;
     f32x3 raw[10];
-    auto fetch = [&](int k, int c) {
+    // halo fetch of one item, split so that the 10 loads can be issued one per MFMA step (-DSE_K47_SPREAD) instead of back to
+    // back at step 1: measured no difference (2.375 vs 2.365 ms per launch inside bench.py), the back-to-back form is production
+    long long f_base = 0;
+    int f_gz0 = 0;
+    bool f_okc = false;
+    const long long f_zs = (long long)dim * dim * (PLANAR ? 3 : a.cin_pad);
+    auto fetch_setup = [&](int k, int c) {
         const i32x4 e = utab[k];
         const int gy = e.z * 8 - 3 + s_cy, gx = e.w * 8 - 3 + s_cx;
-        const int gz0 = e.y * 8 + 4 * s_zq - 3;
-        const bool okc = s_on && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim;
-        const long long base = PLANAR ? ((((long long)e.x * chunks + c) * dim * dim + gy) * dim + gx) * 3
-                                      : ((((long long)e.x * dim) * dim + gy) * dim + gx) * a.cin_pad + c * 3;
-        const long long zs = (long long)dim * dim * (PLANAR ? 3 : a.cin_pad);
-#pragma unroll
-        for (int q = 0; q < 10; ++q) {   // out-of-volume taps load the buffer's first record (one cache line for all of them) and are zeroed
-            const bool ok = okc && (unsigned)(gz0 + q) < (unsigned)dim;
-            const f32x3 t = *reinterpret_cast<const f32x3*>(a.in + (ok ? base + (gz0 + q) * zs : 0));
-            raw[q].x = ok ? t.x : 0.f; raw[q].y = ok ? t.y : 0.f; raw[q].z = ok ? t.z : 0.f;
-        }
+        f_gz0 = e.y * 8 + 4 * s_zq - 3;
+        f_okc = s_on && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim;
+        f_base = PLANAR ? ((((long long)e.x * chunks + c) * dim * dim + gy) * dim + gx) * 3
+                        : ((((long long)e.x * dim) * dim + gy) * dim + gx) * a.cin_pad + c * 3;
+    };
+    auto fetch_one = [&](auto q_tag) {   // out-of-volume taps load the buffer's first record (one cache line for all of them) and are zeroed
+        constexpr int q = decltype(q_tag)::value;
+        const bool ok = f_okc && (unsigned)(f_gz0 + q) < (unsigned)dim;
+        const f32x3 t = *reinterpret_cast<const f32x3*>(a.in + (ok ? f_base + (f_gz0 + q) * f_zs : 0));
+        raw[q].x = ok ? t.x : 0.f; raw[q].y = ok ? t.y : 0.f; raw[q].z = ok ? t.z : 0.f;
+    };
+    auto fetch = [&](int k, int c) {
+        fetch_setup(k, c);
+        for_each_index(fetch_one, std::make_integer_sequence<int, 10>{});
     };
     auto commit = [&]() {   // V = B^T d (rows 1..8 come in +- pairs: even-q part + / - odd-q part); 30 floats per column, 16-byte stores
         if (!s_on) return;
@@ -242,7 +251,12 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino47_kernel(ConvArgs a, int t
         auto step = [&](auto s_tag) {
             constexpr int S = decltype(s_tag)::value;
             constexpr int p = S % 3;
+#ifdef SE_K47_SPREAD
+            if constexpr (S == 1) fetch_setup(k_next, c_next);   // next item's raw columns: one global load per step under the MFMAs
+            if constexpr (S >= 2 && S < 12) fetch_one(std::integral_constant<int, S - 2>{});
+#else
             if constexpr (S == 1) fetch(k_next, c_next);   // next item's raw columns: global loads under the MFMAs
+#endif
 
             if constexpr (S + 1 < K7F_STEPS) read_ops(nxt, std::integral_constant<int, (S + 1) / 3>{}, std::integral_constant<int, (S + 1) % 3>{});
             const float av[12] = {cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w, cur.a2.x, cur.a2.y, cur.a2.z, cur.a2.w};
