@@ -106,6 +106,7 @@ long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, int transpose
 /* Conv3d (k = 1, 3 or 7, stride 1, zero padding (k-1)/2) + folded BN + epilogue.
  * Replaces Basic3DBlock / Res3DBlock convs and output_layer (network/v2v.py:8-43,161).
  *   in  [B][D][D][D][cin_pad]   out [B][D][D][D][cout] (or planar, SE_EPI_OUT_PLANAR)
+ *       (flags & SE_IN_PLANAR3, k = 7 only: in is [B][ceil(cin/3)][D][D][D][3]; cin_pad then only names the packed weights)
  *   residual: same shape as out (NDHWC) or NULL.  cin = real input channels (<= cin_pad, the channel stride
  *   of `in`; channels [cin, cin_pad) must hold finite values, they meet zero weights); cin_pad % 16 == 0;
  *   cout % 16 == 0 unless planar.  Volumes with dim % 8 == 0 and dim >= 16 run the LDS-tiled kernels, everything
