@@ -5,8 +5,8 @@
     python demo.py --config experiments/sceneego/test/sceneego.yaml --img_dir data/demo/imgs \\
                    --depth_dir data/demo/depths --output_dir data/demo/out [--weights synthetic]
 
-Differences: ``--vis`` (open3d GUI) is out of scope; depth maps are read from ``<img_name>.npy|.npz`` (EXR/PIZ decoding
-is not implemented yet); ``--weights synthetic`` uses the portable seeded weights when no checkpoint exists
+Differences: ``--vis`` (open3d GUI) is out of scope; depth maps are read from ``<img_name>.exr`` (the reference's format:
+scanline OpenEXR, NONE/ZIP/PIZ, decoded by ``sceneego_amd/exr.py``) or ``.npy`` / ``.npz``; ``--weights synthetic`` uses the portable seeded weights when no checkpoint exists
 (``config.test.model_path`` is loaded strictly otherwise, exactly like ``demo.py:29-31``).
 """
 import argparse

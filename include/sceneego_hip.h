@@ -214,10 +214,20 @@ int se_preprocess_image_u8(const unsigned char* img, float* out, int batch, int 
 int se_bias_act_nchw_bf16(const se_bf16* x, const se_bf16* bias, const se_bf16* residual, se_bf16* out,
                           int batch, int channels, int hw, int relu, void* stream);
 
-/* Debug / benchmarking only: selects alternative kernel variants for A/B timing (0 = production dispatch). */
+/* Which kernel family se_conv3d_f32 selects for a float32 convolution of this shape (bench.py prices the roofline with it):
+ *   0 direct implicit GEMM (every product on the matrix cores),
+ *   1 1-D Winograd F(4,3) along z (1/2 of the direct products), 2 2-D Winograd F(4,3) x F(2,3) along z, y (1/3),
+ *   7 1-D Winograd F(4,7) along z for the 7x7x7 front layer (10/28).
+ * Pure function of the arguments; no device access. */
+int se_conv3d_f32_algo(int dim, int cin, int cout, int ksize);
+
+#ifdef SE_DEVTOOLS
+/* Development builds only (csrc/build.sh --devtools; absent from the production library): A/B kernel selection for
+ * tools/bench_conv.py and the cycle-stamp diagnostics.  The selector is thread-local. */
 void se_debug_set_variant(int variant);
-/* Debug only: u64 device buffer [workgroups][8 waves][4]; non-NULL switches the Winograd conv to its cycle-stamp build. */
+/* u64 device buffer [workgroups][8 waves][6]; non-NULL switches the Winograd conv to its cycle-stamp build. */
 void se_debug_set_stamp_buffer(void* device_buffer);
+#endif
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -52,6 +52,10 @@ SIGNATURES = {
     "se_voxelize_strided_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "se_preprocess_image_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "se_bias_act_nchw_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "se_conv3d_f32_algo": (_i, [_i, _i, _i, _i]),
+}
+# present only in development builds (csrc/build.sh --devtools): A/B kernel selection and cycle-stamp diagnostics (tools/)
+DEVTOOLS_SIGNATURES = {
     "se_debug_set_variant": (None, [_i]),
     "se_debug_set_stamp_buffer": (None, [_vp]),
 }
@@ -77,6 +81,11 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in DEVTOOLS_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     got = lib.se_abi_version()
     if got != ABI_VERSION:
         raise HipExtensionError(f"libsceneego_hip.so ABI {got} != expected {ABI_VERSION}; rebuild")
@@ -249,6 +258,25 @@ def stop_profile():
     for key, e0, e1 in rec or []:
         out.setdefault(key, []).append(e0.elapsed_time(e1))
     return out
+
+
+class stage:
+    """HIP events around one STAGE of the forward (backbone / gather / voxelise / v2v / softargmax) when profiling is on
+    (bench.py's separate untimed pass); a no-op otherwise.  Keys are ("stage", name)."""
+
+    def __init__(self, name):
+        self.key = ("stage", name)
+
+    def __enter__(self):
+        if _prof is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _prof is not None and exc[0] is None:
+            self.e1.record()
+            _prof.append((self.key, self.e0, self.e1))
+        return False
 
 
 class _timed:

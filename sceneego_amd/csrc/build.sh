@@ -1,29 +1,41 @@
 #!/bin/bash
-# Builds libsceneego_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [extra hipcc flags]
+# Builds libsceneego_hip.so for gfx950 (cross-compiles without a GPU).
+# Usage: build.sh [--devtools] [extra hipcc flags]
+#   --devtools  adds -DSE_DEVTOOLS: the A/B kernel selector (se_debug_set_variant), the retired kernel variants it selects and the
+#               cycle-stamp hooks used by tools/.  The production library is built WITHOUT it.
+# Objects live in _obj/<key>/ where <key> hashes the compiler version and the flag line, so objects of another compiler or
+# another flag set are never reused; inside a key a source is rebuilt when it or a shared header is newer than its object.
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libsceneego_hip.so
-FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function $*"
-mkdir -p _obj
+DEV=""
+if [ "${1:-}" = "--devtools" ]; then DEV="-DSE_DEVTOOLS"; shift; fi
+FLAGS="-O3 $DEV --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function $*"
+KEY=$( (hipcc --version 2>/dev/null; echo "$FLAGS") | sha256sum | cut -c1-12)
+OBJ=_obj/$KEY
+mkdir -p "$OBJ"
 pids=()
 newer() {  # source $1 or a shared header newer than object $2
-  [ ! -f $2 ] || [ $1 -nt $2 ] || [ common.h -nt $2 ] || [ conv_common.h -nt $2 ] || [ bf16_common.h -nt $2 ] || [ ../../include/sceneego_hip.h -nt $2 ]
+  [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ common.h -nt "$2" ] || [ conv_common.h -nt "$2" ] || [ bf16_common.h -nt "$2" ] || [ ../../include/sceneego_hip.h -nt "$2" ]
 }
-for f in voxelize gather softargmax conv3d conv3d_tiled conv3d_wino conv3d_bf16 conv3d_bf16_tiled; do
+for f in voxelize gather softargmax conv3d conv3d_tiled conv3d_wino conv3d_wino2d conv3d_bf16 conv3d_bf16_tiled; do
+  [ -f $f.hip ] || continue
   extra=""
   [ "$f" = voxelize ] && extra="-ffp-contract=off"
-  if newer $f.hip _obj/$f.o; then
-    hipcc $FLAGS $extra -c $f.hip -o _obj/$f.o &
+  if newer $f.hip $OBJ/$f.o; then
+    hipcc $FLAGS $extra -c $f.hip -o $OBJ/$f.o &
     pids+=($!)
   fi
 done
 # the F(4,7) 7^3 kernel: one object per input layout (each takes minutes to compile: 390 unrolled MFMAs under sched_group_barrier)
 for v in 0 1; do
-  if newer conv3d_wino47.hip _obj/conv3d_wino47_$v.o || [ wino47_matrices.h -nt _obj/conv3d_wino47_$v.o ]; then
-    hipcc $FLAGS -DSE_K7F_PLANAR=$v -c conv3d_wino47.hip -o _obj/conv3d_wino47_$v.o &
+  if newer conv3d_wino47.hip $OBJ/conv3d_wino47_$v.o || [ wino47_matrices.h -nt $OBJ/conv3d_wino47_$v.o ]; then
+    hipcc $FLAGS -DSE_K7F_PLANAR=$v -c conv3d_wino47.hip -o $OBJ/conv3d_wino47_$v.o &
     pids+=($!)
   fi
 done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT _obj/*.o
-echo "built $(realpath $OUT)"
+rc=0
+for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait $p || rc=1; }; done
+[ $rc -eq 0 ] || { echo "build.sh: compilation failed" >&2; exit 1; }
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/*.o
+echo "built $(realpath $OUT) (objects: $OBJ)"

@@ -543,7 +543,15 @@ int launch_direct(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int se_abi_version(void) { return 5; }
+extern "C" int se_abi_version(void) { return 6; }
+
+// Mirrors the dispatch of se_conv3d_f32 -> se_conv3d_tiled_try -> se_conv3d_wino_try / se_conv3d_k7_wino_try for the
+// default channels-last call (no SE_EPI_OUT_PLANAR / SE_EPI_RES_POST_RELU flags).
+extern "C" int se_conv3d_f32_algo(int dim, int cin, int cout, int ksize) {
+    if (ksize == 3 && dim >= 16 && (dim & 7) == 0 && (cout & 31) == 0 && (cin & 15) == 0) return 1;
+    if (ksize == 7 && dim >= 16 && (dim & 7) == 0 && cout == 16) return 7;
+    return 0;
+}
 
 static long long packed_elems_a(int cout, int cin_pad, int ksize, int transposed) {
     const long long taps = transposed ? 8 : (long long)ksize * ksize * ksize;
@@ -589,7 +597,6 @@ extern "C" int se_conv3d_pack_f32(const float* w, const float* b, const float* g
 // implemented in conv3d_tiled.hip; returns 1 if it took the launch, 0 if the shape is not covered, <0 / hipError on failure
 int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s);
 
-extern int g_variant;
 #define g_variant_direct (g_variant == 18 ? 1 : 0)   // se_debug_set_variant(18): A/B, grid-level split-K for every small level
 
 extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const float* residual,

@@ -595,13 +595,7 @@ __global__ __launch_bounds__(256, ROW16 ? 2 : 1) void conv_bf16_k7_kernel(ConvBA
 template <bool ROW16>
 int launch_k7(const ConvBArgs& a, int batch, hipStream_t s) {
     using G = K7Geo<ROW16>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_k7_kernel<ROW16>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    SE_ENSURE_LDS(conv_bf16_k7_kernel<ROW16>, G::LDS_BYTES);
     const int tx = a.dim / G::TX, ty = a.dim / G::TY, tz = a.dim / G::TZ;
     hipLaunchKernelGGL(conv_bf16_k7_kernel<ROW16>, dim3((unsigned)(batch * tx * ty * tz)), dim3(256), G::LDS_BYTES, s, a, tx, ty, tz);
     SE_CHECK_LAUNCH();
@@ -612,18 +606,14 @@ int launch_k7(const ConvBArgs& a, int batch, hipStream_t s) {
 
 #ifdef SE_STAMPB
 static unsigned long long* g_stampb = nullptr;
+#ifdef SE_DEVTOOLS
 extern "C" void se_debug_set_stamp_buffer_b(void* p) { g_stampb = reinterpret_cast<unsigned long long*>(p); }
+#endif
 #endif
 
 template <int TY>
 static int launch_k3(const ConvBArgs& a, int batch, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_k3_kernel<TY>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, K3G<TY>::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    SE_ENSURE_LDS(conv_bf16_k3_kernel<TY>, K3G<TY>::LDS_BYTES);
     const int tx = a.dim / K3_TX, ty = a.dim / TY, tz = a.dim / K3_TZ;
 #ifdef SE_STAMPB
     hipLaunchKernelGGL(conv_bf16_k3_kernel<TY>, dim3((unsigned)(batch * tx * ty * tz), a.cout / 32), dim3(256), K3G<TY>::LDS_BYTES, s,
@@ -636,25 +626,14 @@ static int launch_k3(const ConvBArgs& a, int batch, hipStream_t s) {
     return 0;
 }
 
-extern int g_variant;   // A/B switch for tools/bench_conv.py (se_debug_set_variant, conv3d_tiled.hip)
 
 static bool epi_has_res_host(const ConvBArgs& a) { return a.res && (a.flags & (SE_EPI_RES_PRE_RELU | SE_EPI_RES_POST_RELU)); }
 
 int se_conv3d_bf16_tiled_try(const ConvBArgs& a, int batch, int ksize, hipStream_t s) {
     if (ksize == 3 && a.dim % 16 == 0 && a.cin_pad % 16 == 0 && a.cout % 32 == 0 && a.kpc == K3_KPC && a.total_vox < (1LL << 31) &&
         g_variant == 3) {      // A/B only: the persistent form measured 13-18 % SLOWER than two independent workgroups per CU
-        static bool attr_setp = false;
-        static int num_cus = 256;
-        if (!attr_setp) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_k3p_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, K3P_LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                num_cus = prop.multiProcessorCount;
-            attr_setp = true;
-        }
+        SE_ENSURE_LDS(conv_bf16_k3p_kernel, K3P_LDS_BYTES);
+        const int num_cus = se_num_cus();
         const int tx = a.dim / K3_TX, ty = a.dim / K3_TY, tz = a.dim / K3_TZ;
         const long long nitems = (long long)batch * tx * ty * tz * (a.cout / 32);
         if (nitems < (1LL << 31)) {

@@ -23,19 +23,12 @@
 
 #define SE_K7_TSTRIDE 92   // per-k-lane row of the 7^3 tap-offset table (86 groups + pad, multiple of 4)
 
-int g_variant = 0;   // debug/bench switch (se_debug_set_variant): 1 = disable the persistent 64^3 kernel
+#ifdef SE_DEVTOOLS
+thread_local int g_variant = 0;   // A/B switch of development builds (se_debug_set_variant): 1 = disable the persistent 64^3 kernel
+#endif
 
 namespace {
 
-int g_num_cus = 256;
-void ensure_device_info() {
-    static bool done = false;
-    if (done) return;
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-        g_num_cus = n;
-    done = true;
-}
 
 template <int KS, int CK, int TZ>
 struct TileGeom {
@@ -375,14 +368,9 @@ int launch_k3_c32_persistent(const ConvArgs& a, int batch, hipStream_t s) {
     const int tiles = a.dim / 8, ztiles = a.dim / 4;
     const int total_tiles = batch * ztiles * tiles * tiles;
     auto kern = conv3d_k3_c32_persistent_kernel<CHUNKS, PIPE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const int grid = total_tiles < g_num_cus ? total_tiles : g_num_cus;
+    SE_ENSURE_LDS(kern, LDS_BYTES);
+    const int num_cus = se_num_cus();
+    const int grid = total_tiles < num_cus ? total_tiles : num_cus;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, s, a, tiles, ztiles, total_tiles, g_variant >= 10 ? g_variant - 10 : 0);
     SE_CHECK_LAUNCH();
     return 0;
@@ -609,14 +597,9 @@ int launch_k7_persistent(const ConvArgs& a, int batch, hipStream_t s) {
     constexpr int LDS_BYTES = (SE_K7_GROUPS * 256 + 2 * 1960 * 4) * 4 + 4 * SE_K7_TSTRIDE * 4;
     const int tiles = a.dim / 8, ztiles = a.dim / 4;
     const int total_tiles = batch * ztiles * tiles * tiles;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k7_persistent_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const int grid = total_tiles < g_num_cus ? total_tiles : g_num_cus;
+    SE_ENSURE_LDS(conv3d_k7_persistent_kernel, LDS_BYTES);
+    const int num_cus = se_num_cus();
+    const int grid = total_tiles < num_cus ? total_tiles : num_cus;
     hipLaunchKernelGGL(conv3d_k7_persistent_kernel, dim3(grid), dim3(512), LDS_BYTES, s, a, tiles, ztiles, total_tiles,
                        g_variant >= 10 ? g_variant - 10 : 0);
     SE_CHECK_LAUNCH();
@@ -630,13 +613,7 @@ int launch_tiled(const ConvArgs& a, int batch, hipStream_t s) {
     dim3 grid((unsigned)(batch * ztiles * tiles * tiles), (unsigned)(a.nts / N_T));
     auto kern = conv3d_tiled_kernel<KS, CK, TZ, N_T>;
     if (G::LDS_BYTES > 48 * 1024) {
-        static bool attr_set = false;  // per instantiation
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        SE_ENSURE_LDS(kern, G::LDS_BYTES);
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, s, a, tiles, ztiles);
     SE_CHECK_LAUNCH();
@@ -656,7 +633,11 @@ static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s)
 // (a few hundred entries): large batches are cut into slices of 32 samples, one launch each (weak-scaling config 4 runs
 // 32 samples per GPU, i.e. exactly one slice).
 int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) {
-    constexpr int SLICE = 32;
+    // unit-table budget: the smallest table among the persistent kernels holds ~430 entries per workgroup
+    const long long t8 = a.dim / 8;
+    const long long units_per_sample = ksize == 7 ? t8 * t8 * t8 : (long long)(a.cout >= 32 ? a.cout / 32 : 1) * (a.dim / 4) * t8 * t8;
+    long long budget = units_per_sample > 0 ? 400LL * se_num_cus() / units_per_sample : 32;
+    const int SLICE = (int)(budget < 1 ? 1 : budget > 32 ? 32 : budget);
     if (batch <= SLICE) return tiled_try_one(a, batch, ksize, s);
     const long long vox = (long long)a.dim * a.dim * a.dim;
     for (int b0 = 0; b0 < batch; b0 += SLICE) {
@@ -692,7 +673,6 @@ static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s)
         }
         if (g_variant != 1 && g_variant != 3 && a.cout == 32 && dim >= 32 && (a.cin == 16 || a.cin == 32) && a.cin_pad == a.cin &&
             !(a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR))) {
-            ensure_device_info();
             if (g_variant == 2)
                 return a.cin == 32 ? launch_k3_c32_persistent<2, false>(a, batch, s) : launch_k3_c32_persistent<1, false>(a, batch, s);
             return a.cin == 32 ? launch_k3_c32_persistent<2, true>(a, batch, s) : launch_k3_c32_persistent<1, true>(a, batch, s);
@@ -708,7 +688,6 @@ static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s)
         }
         if (a.flags & SE_IN_PLANAR3) return SE_ERR_BAD_ARG;
         if (g_variant != 1 && dim >= 32 && a.cout == 16 && !a.res && !(a.flags & SE_EPI_OUT_PLANAR)) {
-            ensure_device_info();
             return launch_k7_persistent(a, batch, s);
         }
         return launch_tiled<7, 4, 4, 1>(a, batch, s);
@@ -716,4 +695,6 @@ static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s)
     return SE_TILED_NOT_TAKEN;
 }
 
+#ifdef SE_DEVTOOLS
 extern "C" void se_debug_set_variant(int v) { g_variant = v; }
+#endif

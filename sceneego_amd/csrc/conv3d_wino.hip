@@ -22,7 +22,6 @@
 #include <type_traits>
 #include <utility>
 
-extern int g_variant;
 // F(4,7) 7^3 kernel, one translation unit per input layout (conv3d_wino47.hip compiled with -DSE_K7F_PLANAR=0 / 1)
 int se_conv3d_k7_wino47_launch_cl(const ConvArgs& a, int batch, int num_cus, hipStream_t s, unsigned long long* dbg);
 int se_conv3d_k7_wino47_launch_p3(const ConvArgs& a, int batch, int num_cus, hipStream_t s, unsigned long long* dbg);
@@ -1315,7 +1314,6 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino43pp_kernel(ConvArgs a, int
 #endif
 }
 
-int g_num_cus_wino = 0;
 unsigned long long* g_wino_dbg = nullptr;
 unsigned long long* g_wino_dbg43 = nullptr;
 
@@ -1329,22 +1327,9 @@ int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
     constexpr int LDS_FIXED = (SE_WINO_CHUNK_FLOATS + 2 * TILE_FLOATS) * 4;
     constexpr int LDS_BYTES = 160 * 1024;                       // fixed part + unit table (16 B per unit)
     constexpr int MAX_UNITS_PER_WG = (LDS_BYTES - LDS_FIXED) / 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_wino_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_wino_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            g_num_cus_wino = n;
-        else
-            g_num_cus_wino = 256;
-        attr_set = true;
-    }
+    SE_ENSURE_LDS(conv3d_k3_wino_kernel<false>, LDS_BYTES);
+    SE_ENSURE_LDS(conv3d_k3_wino_kernel<true>, LDS_BYTES);
+    const int g_num_cus_wino = se_num_cus();
     const int tiles = dim / 8, ztiles = dim / 4;
     const int total_tiles = batch * ztiles * tiles * tiles;
     const int n_cb = a.cout / 32;
@@ -1355,21 +1340,9 @@ int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
     if (a.wpack_e && g_variant != 4 && !g_wino_dbg) {            // production: F(4,3)
         constexpr int LDS43 = 160 * 1024;
         constexpr int MAX43 = (LDS43 - (W43_FLOATS + V43_FLOATS) * 4) / 16;
-        static bool attr43 = false;
-        if (!attr43) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_wino43_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS43);
-            if (e != hipSuccess) return (int)e;
-            attr43 = true;
-        }
+        SE_ENSURE_LDS(conv3d_k3_wino43_kernel, LDS43);
         constexpr int MAXPP = (LDS43 - (W43_FLOATS + 2 * PP_VH_FLOATS) * 4) / 16;
-        static bool attrpp = false;
-        if (!attrpp) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_wino43pp_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS43);
-            if (e != hipSuccess) return (int)e;
-            attrpp = true;
-        }
+        SE_ENSURE_LDS(conv3d_k3_wino43pp_kernel, LDS43);
         if (per <= MAXPP && g_variant != 19) {       // production: ping-pong form; se_debug_set_variant(19) = single-phase form
             hipLaunchKernelGGL(conv3d_k3_wino43pp_kernel, dim3((n_units + per - 1) / per), dim3(512), LDS43, s, a, tiles, ztiles,
                                total_tiles, n_cb, per, 0, g_wino_dbg43);
@@ -1394,6 +1367,7 @@ int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
     return 0;
 }
 
+#ifdef SE_DEVTOOLS
 // Debug only: device buffer (grid * 8 waves * 4 u64) that makes the Winograd kernel run its STAMP build.
 extern "C" void se_debug_set_stamp_buffer(void* p) {
 #if defined(SE_STAMP43) || defined(SE_STAMPPP) || defined(SE_STAMP47)
@@ -1402,6 +1376,7 @@ extern "C" void se_debug_set_stamp_buffer(void* p) {
     g_wino_dbg = reinterpret_cast<unsigned long long*>(p);
 #endif
 }
+#endif
 
 // Returns 0 on launch, SE_TILED_NOT_TAKEN if not covered, else a hipError_t.
 int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
@@ -1410,21 +1385,9 @@ int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
     constexpr int LDS_FIXED = (K7_W_FLOATS + K7_VT_FLOATS) * 4;
     constexpr int LDS_BYTES = 160 * 1024;
     constexpr int MAX_UNITS = (LDS_BYTES - LDS_FIXED) / 16;
-    static bool attr_set = false;
-    static int num_cus = 256;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k7_wino_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k7_winopp_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            num_cus = n;
-        attr_set = true;
-    }
+    SE_ENSURE_LDS(conv3d_k7_wino_kernel, LDS_BYTES);
+    SE_ENSURE_LDS(conv3d_k7_winopp_kernel, LDS_BYTES);
+    const int num_cus = se_num_cus();
     if (a.wpack_f && g_variant != 17 && g_variant != 19) {       // production: F(4,7) (conv3d_wino47.hip); se_debug_set_variant(17) = F(2,7)
         const int rc = (a.flags & SE_IN_PLANAR3) ? se_conv3d_k7_wino47_launch_p3(a, batch, num_cus, s, g_wino_dbg43)
                                                  : se_conv3d_k7_wino47_launch_cl(a, batch, num_cus, s, g_wino_dbg43);

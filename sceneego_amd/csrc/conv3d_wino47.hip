@@ -354,13 +354,7 @@ int se_conv3d_k7_wino47_launch_cl(const ConvArgs& a, int batch, int num_cus, hip
     constexpr int LDS_BYTES = 160 * 1024;
     constexpr int LDS_FIXED = (K7F_W_FLOATS + K7F_VT_FLOATS) * 4;
     constexpr int MAX_UNITS = (LDS_BYTES - LDS_FIXED) / 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k7_wino47_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    SE_ENSURE_LDS(conv3d_k7_wino47_kernel, LDS_BYTES);
     const int tl = a.dim / 8;
     const int total = batch * tl * tl * tl;
     const int grid = total < num_cus ? total : num_cus;

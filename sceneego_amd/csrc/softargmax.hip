@@ -85,14 +85,19 @@ __global__ __launch_bounds__(256) void softargmax_finish_kernel(const float* __r
     const int row = blockIdx.y, s = blockIdx.x;
     const float* part = scratch + (size_t)row * SE_SA_SPLITS * SE_SA_PART;
     // every thread folds the partials in the same fixed order -> identical (M, L) everywhere
+    // a chunk is skipped only when it is EMPTY (k * chunk >= voxels), never for the value of its partial sums: a NaN logit
+    // makes its chunk's l NaN, and that must reach L, the joints and the whole row of volumes as it does through
+    // torch.softmax + einsum in the reference (utils/op.py:83-96)
+    const int chunk = (((voxels + SE_SA_SPLITS - 1) / SE_SA_SPLITS) + 3) & ~3;
     float M = -INFINITY;
     if (mode == 1)
         for (int k = 0; k < SE_SA_SPLITS; ++k)
-            if (part[k * SE_SA_PART + 1] > 0.f) M = fmaxf(M, part[k * SE_SA_PART + 0]);
+            if (k * chunk < voxels) M = fmaxf(M, part[k * SE_SA_PART + 0]);
     float L = 0.f, SX = 0.f, SY = 0.f, SZ = 0.f;
     for (int k = 0; k < SE_SA_SPLITS; ++k) {
+        if (k * chunk >= voxels) continue;
         const float* p = part + k * SE_SA_PART;
-        const float f = (mode == 1) ? ((p[1] > 0.f) ? expf(p[0] - M) : 0.f) : 1.f;
+        const float f = (mode == 1) ? expf(p[0] - M) : 1.f;
         L += p[1] * f; SX += p[2] * f; SY += p[3] * f; SZ += p[4] * f;
     }
     const float invL = (mode == 1) ? 1.f / L : 1.f;
@@ -101,7 +106,6 @@ __global__ __launch_bounds__(256) void softargmax_finish_kernel(const float* __r
         joints[row * 3 + 1] = SY * invL;
         joints[row * 3 + 2] = SZ * invL;
     }
-    const int chunk = (((voxels + SE_SA_SPLITS - 1) / SE_SA_SPLITS) + 3) & ~3;
     const int c0 = s * chunk;
     const int c1 = min(c0 + chunk, voxels);
     const float* v = vol + (size_t)row * voxels;

@@ -265,10 +265,11 @@ class VoxelNetwork_depth(nn.Module):
         fb, pw, pb = self._folded
 
         # 2D: backbone (MIOpen) + 1x1 channel reduction, channels-last
-        feat2d = torch.nn.functional.conv2d(fb(images), pw, pb)                  # [B,32,64,64]
-        feat_nhwc = feat2d.permute(0, 2, 3, 1)
-        if feat_nhwc.dtype != torch.float32 or not feat_nhwc.is_contiguous():
-            feat_nhwc = feat_nhwc.float().contiguous()
+        with _lib.stage("backbone"):
+            feat2d = torch.nn.functional.conv2d(fb(images), pw, pb)              # [B,32,64,64]
+            feat_nhwc = feat2d.permute(0, 2, 3, 1)
+            if feat_nhwc.dtype != torch.float32 or not feat_nhwc.is_contiguous():
+                feat_nhwc = feat_nhwc.float().contiguous()
 
         # lift to the volume: V2V input buffer [B,G,G,G,cin_pad], zero beyond the real channels
         prog = self.volume_net.program
@@ -294,11 +295,35 @@ class VoxelNetwork_depth(nn.Module):
             # scene_volumes / with_intersection inputs: assembled in float32 by the _f32 operators, rounded once
             xb, x = x, torch.zeros((B, G, G, G, prog.cin_pad), device=dev, dtype=torch.float32)
         texels = feat_nhwc.shape[1] * feat_nhwc.shape[2]
-        if planar3:
-            _lib.unproject_gather_planar3(feat_nhwc, self._gather_idx, self._gather_w, x, B, texels, C, N, x.shape[1])
-        else:
-            _lib.unproject_gather(feat_nhwc, self._gather_idx, self._gather_w, x, B, texels, C, N, prog.cin_pad, 0)
+        with _lib.stage("gather"):
+            if planar3:
+                _lib.unproject_gather_planar3(feat_nhwc, self._gather_idx, self._gather_w, x, B, texels, C, N, x.shape[1])
+            else:
+                _lib.unproject_gather(feat_nhwc, self._gather_idx, self._gather_w, x, B, texels, C, N, prog.cin_pad, 0)
 
+        with _lib.stage("voxelise"):
+            self._voxelise(x, planar3, fast_occ, prog, scene_volumes, depth_map_batch, B, G, N, C, dev)
+        if xb is not None:
+            xb.copy_(x.view(B, G, G, G, prog.cin_pad // 8, 8).permute(0, 4, 1, 2, 3, 5))
+            x = xb
+        with _lib.stage("v2v"):
+            logits = prog.run(x, B, G)                                           # [B,J,N] planar
+        if self.volume_multiplier != 1.0:
+            logits = logits * self.volume_multiplier
+        joints = torch.empty((B, self.num_joints, 3), device=dev, dtype=torch.float32)
+        volumes = torch.empty_like(logits)
+        with _lib.stage("softargmax"):
+            _lib.softargmax3d(logits, self._coord_flat, volumes, joints, B * self.num_joints, N,
+                              1 if self.volume_softmax else 0)
+        volumes = volumes.view(B, self.num_joints, G, G, G)
+
+        features = feat2d
+        if self.materialize_features:
+            features = self.process_features[2](self.process_features[1](feat2d.float()))
+        return joints, features, volumes, self.coord_volumes
+
+    def _voxelise(self, x, planar3, fast_occ, prog, scene_volumes, depth_map_batch, B, G, N, C, dev):
+        """Occupancy into the V2V input buffer ``x`` (reference ``:246-262``)."""
         if planar3:
             # the gather zeroed slot (10, 2) = channel 32; the voxeliser scatters the occupancy into it
             depth = depth_map_batch.reshape(B, depth_map_batch.shape[-2], depth_map_batch.shape[-1]).float().contiguous()
@@ -323,22 +348,6 @@ class VoxelNetwork_depth(nn.Module):
             else:
                 x[..., C] = occ
 
-        if xb is not None:
-            xb.copy_(x.view(B, G, G, G, prog.cin_pad // 8, 8).permute(0, 4, 1, 2, 3, 5))
-            x = xb
-        logits = prog.run(x, B, G)                                               # [B,J,N] planar
-        if self.volume_multiplier != 1.0:
-            logits = logits * self.volume_multiplier
-        joints = torch.empty((B, self.num_joints, 3), device=dev, dtype=torch.float32)
-        volumes = torch.empty_like(logits)
-        _lib.softargmax3d(logits, self._coord_flat, volumes, joints, B * self.num_joints, N,
-                          1 if self.volume_softmax else 0)
-        volumes = volumes.view(B, self.num_joints, G, G, G)
-
-        features = feat2d
-        if self.materialize_features:
-            features = self.process_features[2](self.process_features[1](feat2d.float()))
-        return joints, features, volumes, self.coord_volumes
 
 
 VoxelNetDepth = VoxelNetwork_depth  # the name BASELINE.json uses

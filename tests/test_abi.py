@@ -12,6 +12,7 @@ from sceneego_amd import _lib
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "sceneego_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef SE_DEVTOOLS.*?#endif", "", text, flags=re.S)      # development-build-only entry points
     return sorted(set(re.findall(r"\b(se_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -33,8 +34,16 @@ def test_python_binding_covers_the_header():
     assert lib.se_abi_version() == _lib.ABI_VERSION
 
 
+def test_production_library_has_no_debug_entry_points():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in _lib.DEVTOOLS_SIGNATURES:
+        assert not hasattr(lib, s), f"{s} must only exist in --devtools builds"
+
+
 def test_pure_host_entry_points():
     lib = _lib.load()
+    assert lib.se_conv3d_f32_algo(64, 32, 32, 3) in (1, 2) and lib.se_conv3d_f32_algo(64, 33, 16, 7) == 7
+    assert lib.se_conv3d_f32_algo(8, 128, 128, 3) == 0 and lib.se_conv3d_f32_algo(64, 32, 15, 1) == 0
     # packed weight sizes: taps * cin_pad/16 * ceil(cout/16) * 256 floats
     assert lib.se_conv3d_packed_elems(32, 32, 3, 0) == 27 * 2 * 2 * 256 + 2 * 9 * 4 * 2 * 256 + 2 * 9 * 6 * 2 * 256   # + F(2,3), F(4,3)
     assert lib.se_conv3d_packed_elems(15, 32, 1, 0) == 1 * 2 * 1 * 256

@@ -70,3 +70,53 @@ def test_shard_range_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _fake_forward_worker(rank, world, port, per_rank, results):
+    """What bench.py does per step, with the network replaced by a frame-wise function: rank-seeded inputs (1234 + rank),
+    a per-frame 'forward', ONE all-gather, result identical on every rank and ordered by rank."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from sceneego_amd import dist as sdist
+    r, w, dev = sdist.init_from_env(backend="gloo", device_type="cpu")
+    g = torch.Generator().manual_seed(1234 + rank)                    # bench.py: device_inputs(batch, rank, ...)
+    img = torch.randn((per_rank, 3, 8, 8), generator=g)
+    depth = torch.rand((per_rank, 16, 20), generator=g) * 2.7 + 0.3
+    joints = torch.stack([img.mean(dim=(2, 3)), depth.mean(dim=(1, 2)).unsqueeze(1).expand(-1, 3)], dim=1)   # [b,2,3] per frame
+    joints = joints.repeat(1, 8, 1)[:, :15]                           # [b,15,3]
+    full = sdist.all_gather_joints(joints.contiguous())
+    sdist.barrier()
+    results[rank] = full
+    dist.destroy_process_group()
+
+
+def test_sharded_fake_forward_rank_seeds_and_gather_order():
+    world, per_rank = 2, 4
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_fake_forward_worker, args=(world, _free_port(), per_rank, results), nprocs=world, join=True)
+    res = dict(results)
+    # single-process restatement: rank r's frames come from seed 1234 + r and land at rows [r*per_rank, (r+1)*per_rank)
+    want = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(1234 + r)
+        img = torch.randn((per_rank, 3, 8, 8), generator=g)
+        depth = torch.rand((per_rank, 16, 20), generator=g) * 2.7 + 0.3
+        j = torch.stack([img.mean(dim=(2, 3)), depth.mean(dim=(1, 2)).unsqueeze(1).expand(-1, 3)], dim=1)
+        want.append(j.repeat(1, 8, 1)[:, :15])
+    want = torch.cat(want)
+    assert tuple(res[0].shape) == (world * per_rank, 15, 3)
+    assert torch.equal(res[0], want) and torch.equal(res[1], want)
+    assert not torch.equal(want[:per_rank], want[per_rank:])          # the two ranks really had different inputs
+
+
+def test_bench_refuses_world_size_mismatch():
+    """bench.py must never print a 1-GPU number as an N-GPU line: under a launcher whose WORLD_SIZE differs from --gpus it exits
+    non-zero before touching the GPU."""
+    import subprocess
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode != 0
+    assert "refusing" in r.stderr

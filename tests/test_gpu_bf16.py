@@ -24,6 +24,8 @@ from test_gpu_kernels import _ncdhw, _ndhwc, _rand_bn
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 BF = torch.bfloat16
+# accuracy the bf16-storage mode is specified to, against the float32 reference goldens (metres); DESIGN.md 4b
+BF16_JOINT_TOL = 1e-1
 
 
 def _r(x):
@@ -223,7 +225,7 @@ def test_forward_bf16_error_against_reference(case, golden, golden_meta):
     assert net.volume_net.program.dtype == BF
     err = float(np.abs(kp.cpu().numpy() - g["joints"]).max())
     print(f"bf16 V2V joint error vs float32 reference ({case}): {err:.2e} m")
-    assert err < 1e-1, err
+    assert err < BF16_JOINT_TOL, err
     assert torch.isfinite(vols).all()
     # switching back to float32 restores parity (weights are re-packed)
     net.set_v2v_dtype("fp32")

@@ -1,0 +1,183 @@
+"""GPU: every BASELINE.json configuration at its stated size.
+
+configs[3] (batch 256 over 8 GPUs) runs 32 frames per GPU: its per-GPU share is the B=32 float32 forward below (the
+8-process launch itself is the driver's; the sharding + all-gather are covered over gloo in test_dist_gloo.py and over
+RCCL by test_rccl_two_ranks_one_gpu_each when the box has two GPUs).  configs[2] is B=32 with bf16 V2V storage;
+configs[4] is the 128^3 grid.  Frames are independent, so inside a large batch the frames taken from the reference
+goldens must reproduce the goldens' joints (<= 1e-3 m, BASELINE.json north_star), every frame must equal its own B=1
+run, and a batch permutation must permute the result.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from sceneego_amd import _lib, load_config, synth
+from sceneego_amd.voxel_net_depth import VoxelNetwork_depth
+
+from conftest import ROOT, case_inputs, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+JOINT_TOL = 1e-3
+RUN_NOISE = 5e-5        # MIOpen's atomic split-K backbone kernels are not bitwise reproducible (test_gpu_forward.py)
+
+
+def _build(volume_size=64, **kw):
+    cfg = load_config()
+    cfg.model.volume_size = volume_size
+    net = VoxelNetwork_depth(cfg, device="cpu", verbose=False, **kw)
+    net.load_state_dict(synthetic_state_dict(False), strict=True)
+    return net.to(DEV).eval()
+
+
+def _forward(net, img, depth):
+    with torch.no_grad():
+        out = net(img.to(DEV), net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth.to(DEV))
+    torch.cuda.synchronize()
+    return out
+
+
+def _batch_with_golden_frames(golden_meta, total):
+    """[total] frames: frame 0 = golden b1_floor, frames 1-2 = golden b2_uniform, the rest seeded (uniform / floor mix)."""
+    m1 = next(c for c in golden_meta["cases"] if c["name"] == "b1_floor")
+    m2 = next(c for c in golden_meta["cases"] if c["name"] == "b2_uniform")
+    i1, d1 = case_inputs(m1)
+    i2, d2 = case_inputs(m2)
+    n_u = (total - 3 + 1) // 2
+    iu, du = synth.make_inputs(4242, n_u, "uniform")
+    i_f, d_f = synth.make_inputs(4243, total - 3 - n_u, "floor")
+    return torch.cat([i1, i2, iu, i_f]), torch.cat([d1, d2, du, d_f])
+
+
+@pytest.fixture(scope="module")
+def net64():
+    return _build()
+
+
+def test_config4_per_gpu_share_b32_fp32(net64, golden, golden_meta):
+    """configs[3]: 32 frames per GPU, float32."""
+    img, depth = _batch_with_golden_frames(golden_meta, 32)
+    kp, feats, vols, _ = _forward(net64, img, depth)
+    assert tuple(kp.shape) == (32, 15, 3) and tuple(vols.shape) == (32, 15, 64, 64, 64)
+    k = kp.cpu().numpy()
+    e1 = float(np.abs(k[0:1] - golden("b1_floor")["joints"]).max())
+    e2 = float(np.abs(k[1:3] - golden("b2_uniform")["joints"]).max())
+    assert e1 <= JOINT_TOL and e2 <= JOINT_TOL, (e1, e2)
+    # every 5th frame equals its own B=1 run
+    for b in range(3, 32, 5):
+        one = _forward(net64, img[b:b + 1], depth[b:b + 1])[0]
+        assert float((one - kp[b:b + 1]).abs().max()) < RUN_NOISE, b
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(1))
+    kp_perm = _forward(net64, img[perm], depth[perm])[0]
+    assert float((kp_perm - kp[perm.to(DEV)]).abs().max()) < RUN_NOISE
+    assert bool(torch.isfinite(kp).all()) and bool(torch.isfinite(vols).all())
+    s = vols.reshape(32, 15, -1).sum(dim=2)
+    assert float((s - 1).abs().max()) < 1e-3          # softmaxed volumes
+
+
+def test_config3_b32_bf16_accuracy(golden, golden_meta):
+    """configs[2]: B=32 with bf16 V2V storage.  The bound is the accuracy this mode is specified to."""
+    from test_gpu_bf16 import BF16_JOINT_TOL
+    net = _build()
+    net.set_v2v_dtype("bf16")
+    img, depth = _batch_with_golden_frames(golden_meta, 32)
+    kp, _, vols, _ = _forward(net, img, depth)
+    assert net.volume_net.program.dtype == torch.bfloat16
+    k = kp.cpu().numpy()
+    e1 = float(np.abs(k[0:1] - golden("b1_floor")["joints"]).max())
+    e2 = float(np.abs(k[1:3] - golden("b2_uniform")["joints"]).max())
+    print(f"bf16 B=32: joint error vs float32 reference goldens {e1:.2e} / {e2:.2e} m")
+    assert e1 <= BF16_JOINT_TOL and e2 <= BF16_JOINT_TOL, (e1, e2)
+    net.set_v2v_dtype("fp32")
+    kp32 = _forward(net, img, depth)[0]
+    err = float((kp - kp32).abs().max())
+    print(f"bf16 B=32: max joint difference to the float32 program over all 32 frames {err:.2e} m")
+    assert err <= BF16_JOINT_TOL, err
+    assert bool(torch.isfinite(vols).all())
+
+
+def test_config5_g128_b2(golden, golden_meta):
+    """configs[4] grid (128^3) at B=2: frame 0 reproduces the reference golden, frame 1 equals its B=1 run."""
+    net = _build(volume_size=128)
+    m = next(c for c in golden_meta["cases"] if c["name"] == "b1_g128_floor")
+    i1, d1 = case_inputs(m)
+    i2, d2 = synth.make_inputs(909, 1, "uniform")
+    img, depth = torch.cat([i1, i2]), torch.cat([d1, d2])
+    kp, _, vols, _ = _forward(net, img, depth)
+    assert tuple(vols.shape) == (2, 15, 128, 128, 128)
+    err = float(np.abs(kp[0:1].cpu().numpy() - golden("b1_g128_floor")["joints"]).max())
+    assert err <= JOINT_TOL, err
+    one = _forward(net, i2, d2)[0]
+    assert float((one - kp[1:2]).abs().max()) < RUN_NOISE
+
+
+def test_conv7_planar3_g128_b32_unit_table_budget():
+    """the F(4,7) front layer at 128^3 with B >= 28 used to overflow its per-workgroup unit table (436 entries) and
+    raise; the launcher now cuts the batch by the table budget.  Every sample of the B=32 launch equals the B=2 launch."""
+    from sceneego_amd.v2v import _PackedConv
+    torch.manual_seed(3)
+    conv = torch.nn.Conv3d(33, 16, 7, padding=3).to(DEV)
+    bn = torch.nn.BatchNorm3d(16).to(DEV).eval()
+    pc = _PackedConv(conv, bn, 48, torch.float32)
+    G = 128
+    base = torch.randn((2, 11, G, G, G, 3), device=DEV)
+    x = base.repeat(16, 1, 1, 1, 1, 1).contiguous()
+    out = torch.empty((32, G, G, G, 16), device=DEV)
+    _lib.conv3d(x, pc.w, pc.b, None, out, 32, G, 33, 48, 16, 7, _lib.EPI_RELU | _lib.IN_PLANAR3)
+    ref = torch.empty((2, G, G, G, 16), device=DEV)
+    _lib.conv3d(base, pc.w, pc.b, None, ref, 2, G, 33, 48, 16, 7, _lib.EPI_RELU | _lib.IN_PLANAR3)
+    torch.cuda.synchronize()
+    for k in (0, 13, 27, 31):
+        assert torch.equal(out[k], ref[k % 2]), k
+    assert float(out.abs().max()) > 0
+
+
+def test_materialize_features_matches_reference_golden(golden):
+    """Boundary: with materialize_features=True the 2nd return value is the reference's literal [B,32,1024,1280] tensor
+    (network/voxel_net_depth.py:238,275); compared with values sampled from the real reference forward (tools/make_golden.py
+    --only-features-big)."""
+    g = golden("b1_floor_features_big")
+    net = _build(materialize_features=True)
+    img, depth = synth.make_inputs(77, 1, "floor")
+    kp, feats, _, _ = _forward(net, img, depth)
+    assert tuple(feats.shape) == tuple(g["shape"]) == (1, 32, 1024, 1280) and feats.dtype == torch.float32
+    rows = torch.from_numpy(g["rows"]).to(DEV)
+    cols = torch.from_numpy(g["cols"]).to(DEV)
+    got = feats[0][:, rows][:, :, cols].cpu().numpy()
+    np.testing.assert_allclose(got, g["values"], rtol=2e-3, atol=2e-3)          # MIOpen vs oneDNN float32 backbone
+    assert float(np.abs(g["values"][:, :, -7]).max()) == 0.0 and float(np.abs(got[:, :, -7]).max()) == 0.0   # column 127: zero pad
+    assert float(np.abs(kp.cpu().numpy() - golden("b1_floor")["joints"]).max()) <= JOINT_TOL
+    # default build: compact map, documented deviation
+    assert tuple(_forward(_build(), img, depth)[1].shape) == (1, 32, 64, 64)
+
+
+def test_softargmax_propagates_nan():
+    """torch.softmax + einsum propagate a NaN logit (utils/op.py:83-96); so must the HIP soft-argmax."""
+    G = 16
+    N = G ** 3
+    vol = torch.randn((2, N), device=DEV)
+    vol[1, 1234] = float("nan")
+    coord = torch.rand((N, 3), device=DEV)
+    out_vol = torch.empty_like(vol)
+    joints = torch.empty((2, 3), device=DEV)
+    _lib.softargmax3d(vol, coord, out_vol, joints, 2, N, 1)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(joints[0]).all()) and bool(torch.isfinite(out_vol[0]).all())
+    assert bool(torch.isnan(joints[1]).all()) and bool(torch.isnan(out_vol[1]).all())
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_rccl_two_ranks_one_gpu_each():
+    """`python bench.py --gpus 2` typed without a launcher starts its own 2-rank job over RCCL and prints a 2-GPU line."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extras", "--master-port", "29577"], capture_output=True, text=True,
+                       env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16

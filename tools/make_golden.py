@@ -225,6 +225,23 @@ def main():
 
     RefNet, cfg_mod, op_mod = import_reference()
     metas = []
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-features-big":
+        # 2nd return value of the reference forward, the literal [B,32,1024,1280] tensor (voxel_net_depth.py:238,275),
+        # sub-sampled on a fixed lattice that hits the zero pad columns, block interiors and block edges
+        config = cfg_mod.load_config("experiments/sceneego/test/sceneego.yaml")
+        net = RefNet(config, device="cpu").eval()
+        net.load_state_dict(synth.make_state_dict(net.state_dict(), seed=0), strict=True)
+        img, depth = synth.make_inputs(77, 1, "floor")
+        with torch.no_grad():
+            _, feats, _, _ = net(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth)
+        assert tuple(feats.shape) == (1, 32, 1024, 1280)
+        rows = np.arange(0, 1024, 37)
+        cols = np.concatenate([np.arange(0, 1280, 41), np.array([127, 128, 143, 144, 1151, 1152, 1279])])
+        np.savez_compressed(os.path.join(GOLD, "b1_floor_features_big.npz"), rows=rows, cols=cols,
+                            values=feats[0][:, rows][:, :, cols].numpy().astype(np.float32),
+                            shape=np.array(feats.shape), absmax=np.float32(feats.abs().max()))
+        print("wrote b1_floor_features_big.npz", feats.shape)
+        return
     if len(sys.argv) > 1 and sys.argv[1] in ("--only-demo", "--only-demo-exr"):
         if sys.argv[1] == "--only-demo":
             m, _ = run_case("demo_b1", RefNet, cfg_mod, synth, O, batch=1, in_seed=1000, depth_kind="floor")
