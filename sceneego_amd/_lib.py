@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsceneego_hip.so")
+# tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
+LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
 ABI_VERSION = 6
 
 EPI_RELU = 1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds libsceneego_hip.so for gfx950 (cross-compiles without a GPU).
 # Usage: build.sh [--devtools] [extra hipcc flags]
-#   --devtools  adds -DSE_DEVTOOLS: the A/B kernel selector (se_debug_set_variant), the retired kernel variants it selects and the
+#   --devtools  builds ../libsceneego_hip_dev.so instead (tools/ load it through SCENEEGO_HIP_LIB) with -DSE_DEVTOOLS: the A/B kernel selector (se_debug_set_variant), the retired kernel variants it selects and the
 #               cycle-stamp hooks used by tools/.  The production library is built WITHOUT it.
 # Objects live in _obj/<key>/ where <key> hashes the compiler version and the flag line, so objects of another compiler or
 # another flag set are never reused; inside a key a source is rebuilt when it or a shared header is newer than its object.
@@ -9,7 +9,7 @@ set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libsceneego_hip.so
 DEV=""
-if [ "${1:-}" = "--devtools" ]; then DEV="-DSE_DEVTOOLS"; shift; fi
+if [ "${1:-}" = "--devtools" ]; then DEV="-DSE_DEVTOOLS"; OUT=../libsceneego_hip_dev.so; shift; fi
 FLAGS="-O3 $DEV --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function $*"
 KEY=$( (hipcc --version 2>/dev/null; echo "$FLAGS") | sha256sum | cut -c1-12)
 OBJ=_obj/$KEY

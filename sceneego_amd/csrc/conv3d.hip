@@ -548,6 +548,7 @@ extern "C" int se_abi_version(void) { return 6; }
 // Mirrors the dispatch of se_conv3d_f32 -> se_conv3d_tiled_try -> se_conv3d_wino_try / se_conv3d_k7_wino_try for the
 // default channels-last call (no SE_EPI_OUT_PLANAR / SE_EPI_RES_POST_RELU flags).
 extern "C" int se_conv3d_f32_algo(int dim, int cin, int cout, int ksize) {
+    if (ksize == 3 && dim >= 16 && (dim & 15) == 0 && (cout & 31) == 0 && (cin & 7) == 0) return 2;
     if (ksize == 3 && dim >= 16 && (dim & 7) == 0 && (cout & 31) == 0 && (cin & 15) == 0) return 1;
     if (ksize == 7 && dim >= 16 && (dim & 7) == 0 && cout == 16) return 7;
     return 0;
@@ -565,8 +566,13 @@ extern "C" long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, in
     if (!transposed && ksize == 7 && cout <= 16) n += (long long)((cin_pad + 2) / 3) * SE_K7F_CHUNK_FLOATS;     // section F (last)
     if (!transposed && ksize == 3 && cout % 32 == 0)
         n += (long long)(cin_pad / 16) * (cout / 32) * (SE_WINO_CHUNK_FLOATS + SE_WINO43_CHUNK_FLOATS);
+    if (!transposed && ksize == 3 && cout % 32 == 0) n += (long long)(cin_pad / 8) * (cout / 32) * SE_WINO2D_CHUNK_FLOATS;   // section G (last)
     return n;
 }
+
+// conv3d_wino2d.hip
+int se_conv3d_pack_wino2d(const float* w, const float* gamma, const float* var, float eps, float* out, int cout, int cin,
+                          int cin_pad, hipStream_t s);
 
 extern "C" int se_conv3d_pack_f32(const float* w, const float* b, const float* gamma, const float* beta,
                                   const float* mean, const float* var, float eps, float* wpack, float* bpack,
@@ -582,9 +588,12 @@ extern "C" int se_conv3d_pack_f32(const float* w, const float* b, const float* g
     const long long threads = total > round_up16(cout) ? total : round_up16(cout);
     long long total_main = total;
     if (!transposed && ksize == 7 && cout <= 16) total_main -= (long long)((cin_pad + 2) / 3) * SE_K7F_CHUNK_FLOATS;
+    const long long n_g = (!transposed && ksize == 3 && cout % 32 == 0) ? (long long)(cin_pad / 8) * (cout / 32) * SE_WINO2D_CHUNK_FLOATS : 0;
+    total_main -= n_g;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, se_stream(stream), w, b,
                        gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_pad, taps, transposed, total_a, total_main);
     SE_CHECK_LAUNCH();
+    if (n_g) return se_conv3d_pack_wino2d(w, gamma, var, eps, wpack + total_main, cout, cin, cin_pad, se_stream(stream));
     if (total_main != total) {
         const long long nf = total - total_main;
         hipLaunchKernelGGL(pack_k7f_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, se_stream(stream), w, gamma, var, eps,
@@ -621,6 +630,8 @@ extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* b
     if (ksize == 7 && cout <= 16) a.wpack_f = a.wpack_d + (long long)(cin_pad / 4) * SE_K7W_CHUNK_FLOATS;
     a.wpack_e = nullptr;
     if (ksize == 3 && cout % 32 == 0) a.wpack_e = a.wpack_b + (long long)(cin_pad / 16) * (cout / 32) * SE_WINO_CHUNK_FLOATS;
+    a.wpack_g = nullptr;
+    if (ksize == 3 && cout % 32 == 0) a.wpack_g = a.wpack_e + (long long)(cin_pad / 16) * (cout / 32) * SE_WINO43_CHUNK_FLOATS;
     if (ksize == 3 && (cout % 32)) a.wpack_b = nullptr;
     if (ksize == 1) a.wpack_b = nullptr;
     if ((flags & SE_IN_PLANAR3) && ksize != 7) return SE_ERR_BAD_ARG;
@@ -675,6 +686,7 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
     a.wpack_d = nullptr;
     a.wpack_e = nullptr;
     a.wpack_f = nullptr;
+    a.wpack_g = nullptr;
     const long long vox_per_wg = 4 * 4 * 16;
     const unsigned gx = (unsigned)((a.total_vox + vox_per_wg - 1) / vox_per_wg);
     if (a.nts % 2 == 0) {

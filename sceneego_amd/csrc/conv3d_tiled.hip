@@ -625,6 +625,7 @@ int launch_tiled(const ConvArgs& a, int batch, hipStream_t s) {
 // Returns 0 if a tiled kernel took the launch, SE_TILED_NOT_TAKEN if the shape is left to the direct kernel,
 // otherwise the hipError_t of the failed launch.
 int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s);   // conv3d_wino.hip
+int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s); // conv3d_wino2d.hip
 int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s);
 
 static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s);
@@ -656,7 +657,11 @@ int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) 
 
 static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s) {
     const int dim = a.dim;
-    if (ksize == 3 && (g_variant == 0 || g_variant == 4 || (g_variant >= 10 && g_variant < 20))) {   // production: 1-D Winograd persistent kernels
+    if (ksize == 3 && g_variant == 0) {   // production: 2-D Winograd F(4,3) x F(2,3), register accumulators (se_debug_set_variant(30): 1-D F(4,3))
+        const int rc = se_conv3d_wino2d_try(a, batch, s);
+        if (rc != SE_TILED_NOT_TAKEN) return rc;
+    }
+    if (ksize == 3 && (g_variant == 0 || g_variant == 4 || g_variant == 30 || (g_variant >= 10 && g_variant < 20))) {   // 1-D Winograd persistent kernels
         const int rc = se_conv3d_wino_try(a, batch, s);
         if (rc != SE_TILED_NOT_TAKEN) return rc;
     }

@@ -10,6 +10,9 @@
 #define SE_WINO_CHUNK_FLOATS (9 * 4 * 2 * 256)
 // F(4,3) variant (section E): 9 (dy,dx) x 6 xi x 2 cout tiles x 1 KiB = 108 KB per (16-cin group, 32-cout block)
 #define SE_WINO43_CHUNK_FLOATS (9 * 6 * 2 * 256)
+// 2-D Winograd F(4,3) x F(2,3) section (G) of the packed 3x3x3 weights (conv3d_wino2d.hip): per (32-cout block, 8-cin chunk)
+// 24 xi x 3 dx x 2 cout tiles x 64 lanes x 2 = 73,728 B
+#define SE_WINO2D_CHUNK_FLOATS (24 * 3 * 2 * 128)
 // 1-D Winograd F(2,7) section of the packed 7x7x7 weights: per 4-channel chunk 13 (dy,dx) tap groups x 8 xi x 1 KiB
 #define SE_K7W_GROUPS 13
 #define SE_K7W_CHUNK_FLOATS (SE_K7W_GROUPS * 8 * 256)
@@ -41,6 +44,7 @@ struct ConvArgs {
     const float* wpack_e;  // k = 3, cout % 32 == 0: Winograd F(4,3) section E (else NULL)
     const float* wpack_d;  // k = 7, cout <= 16: Winograd F(2,7) section D [chunk4][g13][xi8][lane][4] (else NULL)
     const float* wpack_f;  // k = 7, cout <= 16: Winograd F(4,7) section F [chunk3][g13][xi10][lane][3] (else NULL)
+    const float* wpack_g;  // k = 3, cout % 32 == 0: 2-D Winograd F(4,3) x F(2,3) section G (else NULL)
     const float* bpack;
     const float* res;
     float* out;
