@@ -22,6 +22,8 @@ for f in voxelize gather softargmax conv3d conv3d_tiled conv3d_wino conv3d_wino2
   [ -f $f.hip ] || continue
   extra=""
   [ "$f" = voxelize ] && extra="-ffp-contract=off"
+  # no SLP packing of float32 arithmetic into v_pk_*_f32: packed VALU beside an MFMA stream is an anti-lever (see commit() there)
+  [ "$f" = conv3d_wino2d ] && extra="-fno-slp-vectorize"
   if newer $f.hip $OBJ/$f.o; then
     hipcc $FLAGS $extra -c $f.hip -o $OBJ/$f.o &
     pids+=($!)

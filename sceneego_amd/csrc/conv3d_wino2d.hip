@@ -15,16 +15,14 @@
 // Channels are walked in chunks of 8 (two MFMA k steps; k lane h carries channels 2h, 2h+1).  Per chunk and group a "step" is
 //     MFMA phase     144 MFMAs per wave: 24 xi x 3 dx x 2, operands by ds_read_b64 from
 //                      W [xi_z][xi_y][dx][ct][lane][2]             73.7 KB, G-transformed weights of the (cout block, chunk)
-//                      V [xi][y-tile][18 x records of 8 channels]   27 KB per group, B^T-transformed input
+//                      V [y-tile][18 x records][xi][8 channels]     28 KB per group, B^T-transformed input
 //     staging phase  the other group meanwhile: output transform + epilogue + stores of the tile it just finished (only after the
 //                    last chunk), global loads + 2-D B^T transform + LDS commit of its next chunk, and its share of the weight stream
 // and the two groups run half a step apart (as in conv3d_k3_wino43pp_kernel), so each SIMD always has one wave in its MFMA block.
 // The weights of a chunk are re-streamed from L2 for every (unit, chunk) - 8 B/clk/CU - into ONE chunk buffer: its halves (xi_z < 3
 // / >= 3) are consumed a quarter step apart, so the half a group has finished with is refilled while the other half is in use;
 // two workgroup barriers per phase (start / middle) order this.
-// LDS reads are conflict-free: W is lane-linear; in V the two 16-byte halves of an 8-channel record are swapped for x records
-// 8..15, which puts the 32 lanes of a ds_read_b64 pass (16 positions x 2 k lanes) on 64 different banks for each of the three
-// x-shifted windows.
+// LDS reads are conflict-free: W is lane-linear; V records are 196 floats apart (see v_rec_offset).
 #include "common.h"
 
 #include "conv_common.h"
@@ -39,9 +37,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int W2_HALF_FLOATS = 3 * 4 * 3 * 2 * 128;      // xi_z 0..2 (or 3..5): 9216 floats = 36,864 B
 constexpr int W2_CHUNK_FLOATS = SE_WINO2D_CHUNK_FLOATS;  // 18,432 floats = 73,728 B
-constexpr int W2_VROW = 144;                             // floats per (xi, y-tile) row: 18 x records of 8 channels
-constexpr int W2_VG_FLOATS = 24 * 2 * W2_VROW;           // 6912 floats = 27,648 B per group
-constexpr int W2_LDS_BYTES = (W2_CHUNK_FLOATS + 2 * W2_VG_FLOATS) * 4;   // 129,024 B
+constexpr int W2_VREC = 196;                             // floats per x record: 24 xi x 8 channels + 4 pad (bank spread, see below)
+constexpr int W2_VTILE = 18 * W2_VREC;                   // one y-tile: 18 x records
+constexpr int W2_VG_FLOATS = 2 * W2_VTILE;               // 7056 floats = 28,224 B per group
+constexpr int W2_DUMMY_FLOATS = 512;                     // landing zone of the masked-off y-transform outputs (see commit())
+constexpr int W2_LDS_BYTES = (W2_CHUNK_FLOATS + 2 * W2_VG_FLOATS + W2_DUMMY_FLOATS) * 4;   // 132,224 B
 static_assert(W2_CHUNK_FLOATS == 2 * W2_HALF_FLOATS, "chunk = two halves");
 
 template <typename F, int... S>
@@ -49,15 +49,31 @@ __device__ __forceinline__ void for_each_idx(F&& f, std::integer_sequence<int, S
     (f(std::integral_constant<int, S>{}), ...);
 }
 
-// float offset of channel pair p (k lane) of x record xx inside a V row
-__device__ __forceinline__ int v_rec_offset(int xx, int p) { return xx * 8 + ((((p >> 1) ^ (xx >> 3)) & 1) << 2) + (p & 1) * 2; }
+// V layout [y-tile][x record][xi][8 channels]: all 24 xi of a position sit within 768 B of one base address, so the MFMA wave
+// reads them with immediate offsets (no address arithmetic in the MFMA stream).  Record stride 196 floats = 4 (mod 64): the 32 lanes
+// of a ds_read_b64 pass (16 consecutive x records x 2 k lanes) fall on 64 different banks for each of the three x-shifted windows.
+__device__ __forceinline__ int v_rec_offset(int xx, int p) { return xx * W2_VREC + p * 2; }
+
+// cycle stamps of the phase structure (diagnostic builds: build.sh --devtools -DSE_STAMP2D, tools/stamp_w2d.py)
+#ifdef SE_STAMP2D
+#define W2_T(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+unsigned long long* g_w2d_dbg = nullptr;
+#else
+#define W2_T(var)
+#endif
 
 struct Unit {
     int cb, b, z0, y0, x0;
 };
 
+// EXP: timing experiments of development builds (0 = the real kernel; bit 0: compact input addresses, bit 1: no weight stream,
+// bit 2: no epilogue memory traffic - all three give wrong results and exist only to attribute time)
+template <int EXP>
 __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const float* __restrict__ wg, int tiles_x, int tiles_y,
-                                                               int tiles_z, int total_tiles, int n_units, int units_per_wg) {
+                                                               int tiles_z, int total_tiles, int n_units, int units_per_wg, unsigned long long* dbg) {
+    constexpr int exp = EXP;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, t8 = 0, st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5; (void)t6; (void)t7; (void)t8; (void)st; (void)dbg;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;
     const int tid = threadIdx.x;
@@ -85,15 +101,26 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     const float* a_h1 = a_h0 + W2_HALF_FLOATS;
     const float* b_dx[3];
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) b_dx[dx] = vt + jt * W2_VROW + v_rec_offset(px + dx, h);
+    for (int dx = 0; dx < 3; ++dx) b_dx[dx] = vt + jt * W2_VTILE + v_rec_offset(px + dx, h);
 
-    // ---- staging role inside the group: thread tg < 144 owns (y-tile sj, x record sxx, channel pair sp) ----
+    // ---- staging role inside the group ----
+    // A staging TASK is (x record, channel pair): 18 x 4 = 72 per group; it covers the group's 6 halo rows (y-tile 0 uses rows 0..3,
+    // y-tile 1 rows 2..5 - the two shared rows are loaded once).  Three adjacent lanes of a 16-lane row split a task by ROW PAIR
+    // (k = 0, 1, 2 -> rows 2k, 2k+1): 12 loads per lane and all four waves of the group take part, which matters because every
+    // vector-memory instruction costs the issuing wave ~140 cycles next to a streaming MFMA partner.  The z transform is
+    // lane-local; the y transform needs one value from each neighbour lane (DPP row shifts).
     const int tg = tid & 255;
-    const bool s_on = tg < 144;
-    const int sp = tg & 3;
-    const int sq = s_on ? (tg >> 2) : 0;
-    const int sxx = sq % 18, sj = sq / 18;
-    float* v_w = vt + sj * W2_VROW + v_rec_offset(sxx, sp);
+    const int i16 = lane & 15;
+    const int sk = i16 % 3;                                    // row pair of this lane
+    const int stask = (wq * 4 + (lane >> 4)) * 5 + i16 / 3;    // 5 tasks per 16-lane row, lane 15 idle
+    const bool s_on = i16 < 15 && stask < 72;
+    const int sxx = s_on ? stask >> 2 : 0, sp = stask & 3;
+    // this lane's y-transform outputs: P, Q -> (y-tile sk, xi_y 0, 1) when sk < 2;  R, S -> (y-tile sk - 1, xi_y 2, 3) when sk > 0
+    // (lanes without that output write into a per-lane slot of a dummy area instead of being masked off: no EXEC toggling in the
+    // transform code, and distinct banks inside every store instruction)
+    float* v_dummy = lds + W2_CHUNK_FLOATS + 2 * W2_VG_FLOATS + lane * 2;
+    float* v_pq = (s_on && sk < 2) ? vt + sk * W2_VTILE + v_rec_offset(sxx, sp) : v_dummy;
+    float* v_rs = (s_on && sk > 0) ? vt + (sk - 1) * W2_VTILE + v_rec_offset(sxx, sp) + 16 : v_dummy;
 
     auto decode = [&](int u) {
         Unit r;
@@ -121,83 +148,93 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         }
         return u;
     };
-
-    // Global accesses go through raw buffer descriptors of ONE sample (base = sample b, num_records = bytes of a sample):
-    // per-lane part of the address in one 32-bit voffset, the uniform (z, y) part in the scalar offset, out-of-volume lanes
-    // get voffset = num_records and read zero.
-    const unsigned in_bytes = (unsigned)dim * dim * dim * cin * 4u;
-    auto rsrc_of = [&](const float* base, long long sample_floats, int b, unsigned bytes) {
-        const float* p0 = base + (long long)b * sample_floats;
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p0), 0, (int)bytes, 0x00020000);
+    // (unit, chunk) one step after (u, c); behind the last step of this workgroup the walk stays where it is, so the staging
+    // code needs no "is there a next step" branches (it then reloads data nobody reads)
+    auto step_after = [&](Unit& u, int& c, int& idx) {
+        if (idx + 1 >= n_steps) return;
+        ++idx;
+        if (++c == chunks) { c = 0; u = advance(u); }
     };
 
-    f32x2 raw[6][4];
-    // global loads of one chunk of this thread's halo column block: 6 z slabs x 4 rows, 8 bytes each
-    auto fetch = [&](const Unit& u, int chunk) {
-        const auto rs = rsrc_of(a.in, (long long)dim * dim * dim * cin, u.b, in_bytes);
+    // Input loads go through a raw buffer descriptor of ONE sample (base = sample b, num_records = bytes of a sample): the
+    // per-lane part of the address in a 32-bit voffset, the uniform z-slab part in the (unsigned) scalar offset; halo
+    // positions outside the volume get voffset bit 31 set, which is out of range and reads zero - no branches.
+    const unsigned in_bytes = (unsigned)dim * dim * dim * cin * 4u;
+    constexpr unsigned OOB = 0x80000000u;
+    auto fetch = [&](f32x2 (&raw)[6][2], const Unit& u, int chunk) {
+        const float* p0 = a.in + (long long)u.b * dim * dim * dim * cin;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p0), 0, (int)in_bytes, 0x00020000);
         const int gx = u.x0 - 1 + sxx;
         const bool okx = s_on && (unsigned)gx < (unsigned)dim;
-        const int gy0 = u.y0 + G * 4 + sj * 2 - 1;
+        const int gy0 = u.y0 + G * 4 - 1 + 2 * sk;
         const int gz0 = u.z0 - 1;
-        // per-lane byte offset of (row gy0 + r, column gx, channel pair) inside a z slab; the scalar offset carries the slab
-        // (scalar offsets are unsigned: nothing negative may go there)
-        unsigned voff[4];
+        unsigned voff[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 2; ++r) {
             const int gy = gy0 + r;
-            voff[r] = (okx && (unsigned)gy < (unsigned)dim) ? (unsigned)(((gy * dim + gx) * cin + chunk * 8 + sp * 2) * 4) : in_bytes;
+            voff[r] = (okx && (unsigned)gy < (unsigned)dim) ? (unsigned)(((gy * dim + gx) * ((exp & 1) ? 8 : cin) + ((exp & 1) ? 0 : chunk * 8) + sp * 2) * 4) : OOB;
         }
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
             const int gz = gz0 + s;
             const bool okz = (unsigned)gz < (unsigned)dim;       // uniform
-            const int soff = gz * dim * dim * cin * 4;
+            const unsigned zmask = okz ? 0u : OOB;
+            const int soff = okz ? gz * dim * dim * ((exp & 1) ? 8 : cin) * 4 : 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                f32x2 t = {0.f, 0.f};
-                if (okz) t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff[r], soff, 0));
-                raw[s][r] = t;
+            for (int r = 0; r < 2; ++r)
+                raw[s][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(voff[r] | zmask), soff, 0));
+        }
+    };
+    // B^T along z (F(4,3), points 0, +-1, +-2, inf) on the lane's two rows, then along y (F(2,3)) with the neighbour lanes' rows;
+    // commit to the group's V buffer.
+    // Scalar fmaf / adds on purpose (this file is built with -fno-slp-vectorize): packed float32 VALU beside the partner wave's MFMA
+    // stream is an anti-lever (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+    auto commit = [&](const f32x2 (&raw)[6][2]) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float t[6][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float d0 = raw[0][r][c], d1 = raw[1][r][c], d2 = raw[2][r][c], d3 = raw[3][r][c], d4 = raw[4][r][c], d5 = raw[5][r][c];
+                t[0][r] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+                t[5][r] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+                const float e1 = fmaf(-4.f, d2, d4), o1 = fmaf(-4.f, d1, d3);
+                t[1][r] = e1 + o1;
+                t[2][r] = e1 - o1;
+                const float e2 = d4 - d2, o2 = d3 - d1;
+                t[3][r] = fmaf(2.f, o2, e2);
+                t[4][r] = fmaf(-2.f, o2, e2);
+            }
+#pragma unroll
+            for (int z = 0; z < 6; ++z) {
+                const float ta = t[z][0], tb = t[z][1];
+                // ra: first row of the lane to the right (row_shl:1), lb: second row of the lane to the left (row_shr:1)
+                const float ra = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ta), 0x101, 0xf, 0xf, true));
+                const float lb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tb), 0x111, 0xf, 0xf, true));
+                v_pq[(z * 4 + 0) * 8 + c] = ta - ra;
+                v_pq[(z * 4 + 1) * 8 + c] = tb + ra;
+                v_rs[(z * 4 + 0) * 8 + c] = ta - lb;
+                v_rs[(z * 4 + 1) * 8 + c] = lb - tb;
             }
         }
     };
-    // B^T along z (F(4,3), points 0, +-1, +-2, inf) then along y (F(2,3)), commit to the group's V buffer
-    auto commit = [&]() {
-        if (!s_on) return;
-        f32x2 t[6][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const f32x2 d0 = raw[0][r], d1 = raw[1][r], d2 = raw[2][r], d3 = raw[3][r], d4 = raw[4][r], d5 = raw[5][r];
-            t[0][r] = 4.f * d0 - 5.f * d2 + d4;
-            t[5][r] = 4.f * d1 - 5.f * d3 + d5;
-            const f32x2 e1 = d4 - 4.f * d2, o1 = d3 - 4.f * d1;
-            t[1][r] = e1 + o1;
-            t[2][r] = e1 - o1;
-            const f32x2 e2 = d4 - d2, o2 = 2.f * (d3 - d1);
-            t[3][r] = e2 + o2;
-            t[4][r] = e2 - o2;
-        }
-#pragma unroll
-        for (int z = 0; z < 6; ++z) {
-            const f32x2 v0 = t[z][0] - t[z][2], v1 = t[z][1] + t[z][2], v2 = t[z][2] - t[z][1], v3 = t[z][1] - t[z][3];
-            *reinterpret_cast<f32x2*>(v_w + ((z * 4 + 0) * 2) * W2_VROW) = v0;
-            *reinterpret_cast<f32x2*>(v_w + ((z * 4 + 1) * 2) * W2_VROW) = v1;
-            *reinterpret_cast<f32x2*>(v_w + ((z * 4 + 2) * 2) * W2_VROW) = v2;
-            *reinterpret_cast<f32x2*>(v_w + ((z * 4 + 3) * 2) * W2_VROW) = v3;
-        }
-    };
 
-    // weight stream: one half chunk (36,864 B = 36 pieces of 1 KiB) straight from L2 into the LDS by LDS-DMA
-    // (global_load_lds_dwordx4: lane l of a wave moves 16 bytes to M0 base + 16 l), 9 pieces per wave of the staging group.
-    // The pieces land asynchronously: the issuing wave waits with vmcnt before the workgroup barrier that publishes the half.
-    auto w_stream = [&](const Unit& u, int chunk, int half) {
-        const float* src = wg + ((size_t)u.cb * chunks + chunk) * W2_CHUNK_FLOATS + half * W2_HALF_FLOATS + lane * 4;
-        float* dst = wl + half * W2_HALF_FLOATS;
+    // weight stream: one half chunk (36,864 B = 9 x 16 B per thread of a group), global (L2) -> registers -> LDS.  Plain loads,
+    // not LDS-DMA: an L2-hit load returns in a few hundred cycles, a DMA piece lands ~1 us after issue (MI355X_MICROARCH.md,
+    // ldsdma-fill) and the refill window of a half is half a phase.
+    auto w_fetch = [&](f32x4 (&wreg)[9], const Unit& u, int chunk, int half) {
+        if (exp & 2) return;
+        // uniform base in the descriptor, lane offset tg * 16 B, piece offset in the scalar/immediate offset: no address VALU
+        const float* src = wg + ((size_t)u.cb * chunks + chunk) * W2_CHUNK_FLOATS + half * W2_HALF_FLOATS;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, W2_HALF_FLOATS * 4, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int piece = k * 4 + wq;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + piece * 256),
-                                             (void __attribute__((address_space(3)))*)(dst + piece * 256), 16, 0, 0);
-        }
+        for (int k = 0; k < 9; ++k) wreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tg * 16, k * 4096, 0));
+    };
+    auto w_commit = [&](const f32x4 (&wreg)[9], int half) {
+        f32x4* dst = reinterpret_cast<f32x4*>(wl + half * W2_HALF_FLOATS);
+        if (exp & 2) return;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dst[tg + k * 256] = wreg[k];
     };
 
     f32x4 acc[24];
@@ -218,80 +255,96 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             f32x4 resv[4];
-            if (use_res) {
+            if (use_res && !(exp & 4)) {
 #pragma unroll
                 for (int z = 0; z < 4; ++z) resv[z] = *reinterpret_cast<const f32x4*>(rb + z * zstride + r * ystride + voff);
             }
-            f32x4 m[6];
+            if constexpr ((exp & 128) != 0) {
 #pragma unroll
-            for (int z = 0; z < 6; ++z)
-                m[z] = r == 0 ? acc[z * 4 + 0] + acc[z * 4 + 1] + acc[z * 4 + 2] : acc[z * 4 + 1] - acc[z * 4 + 2] - acc[z * 4 + 3];
-            const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-            f32x4 y[4];
-            y[0] = m[0] + s12 + s34;
-            y[1] = d12 + 2.f * d34;
-            y[2] = s12 + 4.f * s34;
-            y[3] = d12 + 8.f * d34 + m[5];
+                for (int z = 0; z < 4; ++z) *reinterpret_cast<f32x4*>(ob + z * zstride + r * ystride + voff) = acc[r * 12 + z];
+#pragma unroll
+                for (int e = 0; e < 24; ++e) asm volatile("" ::"v"(acc[e]));     // keep every accumulator (and its MFMAs) live
+                continue;
+            }
+            f32x4 out[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {      // scalar on purpose, see commit()
+                float m[6];
+#pragma unroll
+                for (int z = 0; z < 6; ++z)
+                    m[z] = r == 0 ? (acc[z * 4 + 0][c] + acc[z * 4 + 1][c]) + acc[z * 4 + 2][c] : (acc[z * 4 + 1][c] - acc[z * 4 + 2][c]) - acc[z * 4 + 3][c];
+                const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+                const float b = bias[c];
+                out[0][c] = ((m[0] + s12) + s34) + b;
+                out[1][c] = fmaf(2.f, d34, d12) + b;
+                out[2][c] = fmaf(4.f, s34, s12) + b;
+                out[3][c] = (fmaf(8.f, d34, d12) + m[5]) + b;
+            }
 #pragma unroll
             for (int z = 0; z < 4; ++z) {
-                f32x4 v = y[z] + bias;
-                if (use_res) v += resv[z];
-                if (relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                f32x4 v = out[z];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (use_res && !(exp & 4)) v[c] += resv[z][c];
+                    if (relu) v[c] = fmaxf(v[c], 0.f);
                 }
-                *reinterpret_cast<f32x4*>(ob + z * zstride + r * ystride + voff) = v;
+                if (!(exp & 4) || v.x == 12345.f) *reinterpret_cast<f32x4*>(ob + z * zstride + r * ystride + voff) = v;
             }
         }
     };
 
-    // Workgroup barrier that waits for this wave's LDS traffic only (lgkmcnt): global loads stay in flight across it — a
-    // __syncthreads() (and, in a kernel that uses LDS-DMA, every fence-based barrier) also waits for vmcnt(0).  The "memory"
-    // clobber keeps the compiler from moving LDS / global accesses across it.  LDS-DMA pieces are counted by vmcnt: the wave
-    // that issued them waits explicitly (wait_vm) before the barrier that publishes them.
+    // Workgroup barrier that waits for this wave's LDS traffic only (lgkmcnt): global loads stay in flight across it (a
+    // __syncthreads() also waits for vmcnt(0)).  The "memory" clobber keeps the compiler from moving LDS / global accesses across it.
     auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    auto wait_vm0 = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-    auto wait_vm8 = [&]() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); };   // all but the 8 youngest (the epilogue's stores)
 
     // ---- MFMA phase: 18 groups (xi_z, dx) of 4 xi_y x 2 k steps; the workgroup's mid-phase barrier sits in front of the first
     // access to the second weight half ----
     auto mfma_phase = [&]() {
-        f32x2 ca[4], cv[4], na[4], nv[4];
+        // operands of group g live in buffer g % 3 and are fetched two groups (16 MFMAs = 512 cycles) ahead of their use
+        f32x2 oa[3][4], ov[3][4];
+        auto load_group = [&](auto g_tag) {
+            constexpr int g2 = decltype(g_tag)::value;
+            constexpr int xz2 = g2 / 3, dx2 = g2 % 3, b = g2 % 3;
+            const float* ab = (xz2 < 3) ? a_h0 : a_h1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            ca[e] = *reinterpret_cast<const f32x2*>(a_h0 + (e * 3 + 0) * 256);
-            cv[e] = *reinterpret_cast<const f32x2*>(b_dx[0] + (e * 2) * W2_VROW);
+            for (int e = 0; e < 4; ++e) {
+                oa[b][e] = *reinterpret_cast<const f32x2*>(ab + (((xz2 % 3) * 4 + e) * 3 + dx2) * 256);
+                ov[b][e] = *reinterpret_cast<const f32x2*>(b_dx[dx2] + (xz2 * 4 + e) * 8);
+            }
+        };
+        if constexpr ((exp & 0x400) != 0) {      // experiment: the staging code alone (no operand reads, no MFMAs)
+            W2_T(t1)
+            barrier();
+            W2_T(t2)
+            return;
         }
+        load_group(std::integral_constant<int, 0>{});
+        load_group(std::integral_constant<int, 1>{});
         auto group = [&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
-            constexpr int xz = g / 3;
-            if constexpr (g == 8) {
-                // the prefetch below is the first read of weight half 1; all reads of half 0 have been issued: drain them so the
-                // staging group may refill half 0 right after the barrier
-                __builtin_amdgcn_sched_barrier(0);
+            constexpr int xz = g / 3, b = g % 3;
+#ifdef SE_STAMP2D
+            if constexpr (g == 1) { W2_T(t5) st[10] += t5 - t0; }
+            if constexpr (g == 4) { W2_T(t6) st[11] += t6 - t5; }
+#endif
+            if constexpr (g == 7) {
+                // the prefetch below (group 9) is the first read of weight half 1; all reads of half 0 have been issued and are
+                // drained by the barrier's lgkmcnt(0), so the staging group may refill half 0 right behind it
+                W2_T(t1)
                 barrier();
-                __builtin_amdgcn_sched_barrier(0);
+                W2_T(t2)
             }
-            if constexpr (g + 1 < 18) {
-                constexpr int g2 = g + 1, xz2 = g2 / 3, dx2 = g2 % 3;
-                const float* ab = (xz2 < 3) ? a_h0 : a_h1;
+            if constexpr (g + 2 < 18) load_group(std::integral_constant<int, g + 2>{});
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[xz * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][e].x, ov[b][e].x, acc[xz * 4 + e], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[xz * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][e].y, ov[b][e].y, acc[xz * 4 + e], 0, 0, 0);
+            if constexpr (g + 2 < 18) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    na[e] = *reinterpret_cast<const f32x2*>(ab + (((xz2 % 3) * 4 + e) * 3 + dx2) * 256);
-                    nv[e] = *reinterpret_cast<const f32x2*>(b_dx[dx2] + ((xz2 * 4 + e) * 2) * W2_VROW);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[xz * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[e].x, cv[e].x, acc[xz * 4 + e], 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[xz * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[e].y, cv[e].y, acc[xz * 4 + e], 0, 0, 0);
-            if constexpr (g + 1 < 18) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { ca[e] = na[e]; cv[e] = nv[e]; }
             } else {
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
@@ -299,50 +352,93 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         for_each_idx(group, std::make_integer_sequence<int, 18>{});
     };
 
-    // ---- prologue: weights of step 0 (group G streams half G), each group's V tile of step 0 ----
-    Unit ucur = decode(u_begin);      // unit of the step this group computes next / has just computed
-    int ccur = 0;                     // its chunk
-    w_stream(ucur, 0, G);
-    fetch(ucur, 0);
-    commit();
-    wait_vm0();
-    barrier();
-
-    for (int p = 0; p <= 2 * n_steps; ++p) {
-        const int r = p - G;
-        if (r >= 0 && !(r & 1) && (r >> 1) < n_steps) {
-            // ------------------------------ MFMA phase of step r/2 = (ucur, ccur) ------------------------------
-            if (ccur == 0) {
-#pragma unroll
-                for (int e = 0; e < 24; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            __builtin_amdgcn_s_setprio(3);
-            mfma_phase();
-            __builtin_amdgcn_s_setprio(0);
-        } else {
-            // ------------------------------ staging phase ------------------------------
-            const bool stage = r >= 1 && (r & 1);                 // this group has just computed step (r-1)/2 = (ucur, ccur)
-            const bool has_next = stage && ((r + 1) >> 1) < n_steps;
-            const bool epi = stage && ccur == chunks - 1;
-            Unit unext = ucur;
-            int cnext = ccur + 1;
-            if (cnext == chunks) { cnext = 0; unext = advance(ucur); }
-            // first half.  Group 1 (even p >= 2) streams weight half 1 of its next step: it must have landed at the mid-phase barrier.
-            const bool w1 = G == 1 && has_next;
-            if (has_next) fetch(unext, cnext);                    // stays in flight across the mid-phase barrier
-            if (w1) w_stream(unext, cnext, 1);
-            if (epi) epilogue(ucur);
-            if (w1) { if (epi) wait_vm8(); else wait_vm0(); }
-            barrier();                                            // mid-phase barrier
-            // second half.  Group 0 (odd p) streams weight half 0 of its next step.
-            const bool w0 = G == 0 && has_next;
-            if (w0) w_stream(unext, cnext, 0);
-            if (has_next) commit();
-            if (w0) wait_vm0();
-            if (stage) { ucur = unext; ccur = cnext; }
-        }
-        barrier();                                                // end-of-phase barrier
+    // ---- prologue: weights of step 0 (group G stages half G), each group's V tile of step 0, input of step 1 in flight ----
+    Unit ucur = decode(u_begin);      // (unit, chunk) of the step this group computes next
+    int ccur = 0, icur = 0;
+    Unit unx = ucur;                  // (unit, chunk) of the step whose input is in flight in `raw`
+    int cnx = 0, inx = 0;
+    f32x2 raw[6][2];
+    {
+        f32x4 wreg[9];
+        w_fetch(wreg, ucur, 0, G);
+        fetch(raw, ucur, 0);
+        commit(raw);
+        w_commit(wreg, G);
     }
+    step_after(unx, cnx, inx);
+    fetch(raw, unx, cnx);
+    if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(2);
+    barrier();
+    if (G == 1) {                     // group 1 runs one phase behind group 0
+        barrier();
+        barrier();
+    }
+
+    for (int i = 0; i < n_steps; ++i) {
+        // ------------------------------ MFMA phase of step i = (ucur, ccur) ------------------------------
+        W2_T(t0)
+        if (ccur == 0) {
+#pragma unroll
+            for (int e = 0; e < 24; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr ((exp & 0x300) == 0) __builtin_amdgcn_s_setprio(3);          // production
+        if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(0);      // experiment: staging wave above the MFMA wave
+        mfma_phase();
+        if constexpr ((exp & 0x300) == 0) __builtin_amdgcn_s_setprio(0);
+        if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(2);
+        W2_T(t3)
+        barrier();                                                // end of the MFMA phase
+        W2_T(t4)
+        // ------------------------------ staging phase ------------------------------
+        // `raw` holds the input of step i+1 = (unx, cnx), fetched a whole phase ago.  Order inside the phase: what the OTHER
+        // group needs first (its weight half), then this group's V tile, then the output of the finished tile, and last the
+        // fetch of step i+2, which lands during this group's next MFMA phase.
+        const bool epi = ccur == chunks - 1;
+        const Unit udone = ucur;
+        f32x4 wreg[9];
+        if (G == 1) {
+            // group 1 stages weight half 1 of step i+1 in the first half of its staging phase (group 0 reads it right after the
+            // mid-phase barrier)
+            w_fetch(wreg, unx, cnx, 1);
+            commit(raw);
+            w_commit(wreg, 1);
+            W2_T(t5)
+            barrier();                                            // mid-phase barrier
+            W2_T(t6)
+            if (epi) epilogue(udone);
+        } else {
+            // group 0 stages weight half 0 of step i+1 in the second half (group 1 reads half 0 of step i in the first half)
+            w_fetch(wreg, unx, cnx, 0);
+            commit(raw);
+            if (epi) epilogue(udone);
+            W2_T(t5)
+            barrier();                                            // mid-phase barrier
+            W2_T(t6)
+            w_commit(wreg, 0);
+        }
+        ucur = unx; ccur = cnx; icur = inx;
+        step_after(unx, cnx, inx);
+        fetch(raw, unx, cnx);
+        W2_T(t7)
+        barrier();                                                // end of the staging phase
+        W2_T(t8)
+#ifdef SE_STAMP2D
+        st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2; st[3] += t4 - t3;
+        st[4] += t5 - t4; st[5] += t6 - t5; st[6] += t7 - t6; st[7] += t8 - t7;
+        st[8] += 1; st[9] += 1;
+#endif
+    }
+    (void)icur;
+    if (G == 0) {                     // group 0 idles through group 1's last two phases
+        barrier();
+        barrier();
+    }
+#ifdef SE_STAMP2D
+    if (lane == 0 && dbg) {
+        unsigned long long* o = dbg + ((size_t)blockIdx.x * 8 + wave) * 16;
+        for (int k = 0; k < 16; ++k) o[k] = st[k];
+    }
+#endif
 }
 
 }  // namespace
@@ -398,7 +494,6 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
     const int dim = a.dim;
     if (!a.wpack_g || dim < 16 || (dim & 15) || (a.cout & 31) || (a.cin & 7) || a.cin_pad != a.cin) return SE_TILED_NOT_TAKEN;
     if (a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR)) return SE_TILED_NOT_TAKEN;
-    SE_ENSURE_LDS(conv3d_k3_wino2d_kernel, W2_LDS_BYTES);
     const int tx = dim / 16, ty = dim / 8, tz = dim / 4;
     const long long total_tiles = (long long)batch * tx * ty * tz;
     const long long n_units = total_tiles * (a.cout / 32);
@@ -406,8 +501,36 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
     const int cus = se_num_cus();
     const int grid = (int)(n_units < cus ? n_units : cus);
     const int per = (int)((n_units + grid - 1) / grid);
-    hipLaunchKernelGGL(conv3d_k3_wino2d_kernel, dim3((unsigned)((n_units + per - 1) / per)), dim3(512), W2_LDS_BYTES, s, a, a.wpack_g,
-                       tx, ty, tz, (int)total_tiles, (int)n_units, per);
+    unsigned long long* dbg = nullptr;
+#ifdef SE_STAMP2D
+    dbg = g_w2d_dbg;
+#endif
+#define W2_LAUNCH(E)                                                                                                            \
+    do {                                                                                                                        \
+        SE_ENSURE_LDS(conv3d_k3_wino2d_kernel<E>, W2_LDS_BYTES);                                                                \
+        hipLaunchKernelGGL(conv3d_k3_wino2d_kernel<E>, dim3((unsigned)((n_units + per - 1) / per)), dim3(512), W2_LDS_BYTES, s, a, \
+                           a.wpack_g, tx, ty, tz, (int)total_tiles, (int)n_units, per, dbg);                                    \
+    } while (0)
+#ifdef SE_DEVTOOLS
+    switch (g_variant) {
+        case 41: W2_LAUNCH(1); break;
+        case 42: W2_LAUNCH(2); break;
+        case 43: W2_LAUNCH(3); break;
+        case 44: W2_LAUNCH(4); break;
+        case 47: W2_LAUNCH(7); break;
+        case 48: W2_LAUNCH(0x400); break;   // staging alone
+        case 49: W2_LAUNCH(0x200); break;   // staging wave prioritised
+        default: W2_LAUNCH(0); break;
+    }
+#else
+    W2_LAUNCH(0);
+#endif
+#undef W2_LAUNCH
     SE_CHECK_LAUNCH();
     return 0;
 }
+
+#if defined(SE_DEVTOOLS) && defined(SE_STAMP2D)
+// Diagnostic builds only: u64 device buffer [workgroups][8 waves][16] filled by the stamp build of conv3d_k3_wino2d_kernel.
+extern "C" void se_debug_set_stamp_buffer_2d(void* p) { g_w2d_dbg = reinterpret_cast<unsigned long long*>(p); }
+#endif

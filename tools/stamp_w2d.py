@@ -1,0 +1,29 @@
+"""Diagnostic: phase timing of conv3d_k3_wino2d_kernel (needs `csrc/build.sh --devtools -DSE_STAMP2D`, run with
+SCENEEGO_HIP_LIB=sceneego_amd/libsceneego_hip_dev.so)."""
+import ctypes, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from sceneego_amd import _lib
+from sceneego_amd.v2v import _PackedConv
+lib = _lib.load(); dev = "cuda:0"
+B, dim, cin, cout = 8, 64, int(os.environ.get("CIN", 32)), int(os.environ.get("COUT", 32))
+conv = torch.nn.Conv3d(cin, cout, 3, padding=1).to(dev)
+pc = _PackedConv(conv, None)
+x = torch.randn(B, dim, dim, dim, cin, device=dev); res = torch.randn(B, dim, dim, dim, cout, device=dev)
+out = torch.empty_like(res)
+lib.se_debug_set_variant(int(os.environ.get("VARIANT", 0)))
+dbg = torch.zeros(256 * 8 * 16, dtype=torch.int64, device=dev)
+for _ in range(3):
+    _lib.conv3d(x, pc.w, pc.b, res, out, B, dim, cin, cin, cout, 3, 3, None)
+lib.se_debug_set_stamp_buffer_2d.argtypes = [ctypes.c_void_p]
+lib.se_debug_set_stamp_buffer_2d(ctypes.c_void_p(dbg.data_ptr()))
+_lib.conv3d(x, pc.w, pc.b, res, out, B, dim, cin, cin, cout, 3, 3, None)
+torch.cuda.synchronize()
+lib.se_debug_set_stamp_buffer_2d(None)
+d = dbg.view(256, 8, 16).double()
+for g, name in ((0, "group A (waves 0-3)"), (1, "group B (waves 4-7)")):
+    w = d[:, 4 * g:4 * g + 4]
+    nm, ns = w[:, :, 8].mean(), w[:, :, 9].mean()
+    print(f"{name}: {nm:.0f} MFMA phases, {ns:.0f} staging phases per wave")
+    print(f"   MFMA phase   : first half {w[:, :, 0].mean() / nm:7.0f}  mid-barrier wait {w[:, :, 1].mean() / nm:7.0f}  second half {w[:, :, 2].mean() / nm:7.0f}  end-barrier wait {w[:, :, 3].mean() / nm:7.0f}   (ideal 2304 + 2304 cycles of MFMA issue)")
+    print(f"   staging phase: first half {w[:, :, 4].mean() / ns:7.0f}  mid-barrier wait {w[:, :, 5].mean() / ns:7.0f}  second half {w[:, :, 6].mean() / ns:7.0f}  end-barrier wait {w[:, :, 7].mean() / ns:7.0f}")
+    print(f"   MFMA phase detail: loop top -> after group 0 {w[:, :, 10].mean() / nm:7.0f}   groups 1-3 {w[:, :, 11].mean() / nm:7.0f}  (ideal 256 / 768)")
