@@ -35,6 +35,9 @@ extern "C" {
 #define SE_IN_PLANAR3        16  /* se_conv3d_f32, k = 7, cout = 16, dim % 8 == 0, no residual only: `in` is
                                   * triplet-planar [B][ceil(cin/3)][D][D][D][3] (channel c at triplet c/3,
                                   * slot c%3; slots >= cin must be finite) - see se_unproject_gather_planar3_f32 */
+#define SE_IN_OCTET          32  /* se_conv3d_f32, k = 3 shapes with se_conv3d_f32_algo() == 2 only: `in` is octet-planar          */
+#define SE_OUT_OCTET         64  /* [B][C/8][D][D][D][8] (channel c at octet c/8, slot c%8) / `out` is written that way; the skip  */
+                                 /* tensor `residual` is always channels-last                                                   */
 
 /* ABI version; bumped on any signature change. */
 int se_abi_version(void);

@@ -20,6 +20,8 @@ EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
 EPI_RES_POST_RELU = 4
 EPI_OUT_PLANAR = 8
+IN_OCTET = 32       # se_conv3d_f32, 2-D Winograd 3x3x3 shapes: octet-planar input [B][C/8][D][D][D][8]
+OUT_OCTET = 64      # ... octet-planar output
 IN_PLANAR3 = 16     # se_conv3d_f32, k = 7: triplet-planar input [B][ceil(cin/3)][D][D][D][3]
 
 _vp, _i, _f, _d, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong
@@ -225,6 +227,11 @@ def conv3d_packed_elems(cout, cin_pad, ksize, transposed, bf16=False) -> int:
     if n <= 0:
         raise HipExtensionError(f"unsupported conv shape cout={cout} cin_pad={cin_pad} k={ksize}")
     return n
+
+
+def conv3d_algo(dim, cin, cout, ksize) -> int:
+    """Kernel family se_conv3d_f32 selects for this float32 shape (include/sceneego_hip.h: 0 direct, 1 / 2 Winograd 1-D / 2-D)."""
+    return int(load().se_conv3d_f32_algo(dim, cin, cout, ksize))
 
 
 def conv3d_pack(w, b, gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_pad, ksize, transposed):

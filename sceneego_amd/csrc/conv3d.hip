@@ -635,8 +635,10 @@ extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* b
     if (ksize == 3 && (cout % 32)) a.wpack_b = nullptr;
     if (ksize == 1) a.wpack_b = nullptr;
     if ((flags & SE_IN_PLANAR3) && ksize != 7) return SE_ERR_BAD_ARG;
+    if ((flags & (SE_IN_OCTET | SE_OUT_OCTET)) && se_conv3d_f32_algo(dim, cin, cout, ksize) != 2) return SE_ERR_BAD_ARG;
     const int took = se_conv3d_tiled_try(a, batch, ksize, s);
     if (took != SE_TILED_NOT_TAKEN) return took;
+    if (flags & (SE_IN_OCTET | SE_OUT_OCTET)) return SE_ERR_BAD_ARG;   // only the 2-D Winograd kernel knows the octet-planar forms
     if (flags & SE_IN_PLANAR3) return SE_ERR_BAD_ARG;
     // small volumes with wide channels: split the taps over grid.z when the plain launch would not fill the chip
     if (ksize == 3 && !planar && a.nts % 2 == 0 && a.total_vox >= 2048 && a.total_vox <= 8192 && g_variant_direct != 1) {

@@ -1323,7 +1323,7 @@ unsigned long long* g_wino_dbg43 = nullptr;
 int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
     const int dim = a.dim;
     if (!a.wpack_b || dim < 16 || (dim & 7) || (a.cout & 31) || (a.cin & 15) || a.cin_pad != a.cin) return SE_TILED_NOT_TAKEN;
-    if (a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR)) return SE_TILED_NOT_TAKEN;
+    if (a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR | SE_IN_OCTET | SE_OUT_OCTET)) return SE_TILED_NOT_TAKEN;
     constexpr int LDS_FIXED = (SE_WINO_CHUNK_FLOATS + 2 * TILE_FLOATS) * 4;
     constexpr int LDS_BYTES = 160 * 1024;                       // fixed part + unit table (16 B per unit)
     constexpr int MAX_UNITS_PER_WG = (LDS_BYTES - LDS_FIXED) / 16;

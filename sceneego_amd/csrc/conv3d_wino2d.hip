@@ -68,10 +68,14 @@ struct Unit {
 
 // EXP: timing experiments of development builds (0 = the real kernel; bit 0: compact input addresses, bit 1: no weight stream,
 // bit 2: no epilogue memory traffic - all three give wrong results and exist only to attribute time)
-template <int EXP>
+// LAYOUT: bit 0 = input is octet-planar [B][cin/8][D][D][D][8] (SE_IN_OCTET), bit 1 = output is octet-planar (SE_OUT_OCTET).
+// In the octet-planar form an 8-channel chunk of a halo row is ONE contiguous run (18 positions x 32 B) instead of 18 pieces of
+// 32 B at a 4*cin-byte stride: 4x fewer cache lines per load instruction.
+template <int EXP, int LAYOUT>
 __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const float* __restrict__ wg, int tiles_x, int tiles_y,
                                                                int tiles_z, int total_tiles, int n_units, int units_per_wg, unsigned long long* dbg) {
     constexpr int exp = EXP;
+    constexpr bool in_oct = LAYOUT & 1, out_oct = LAYOUT & 2;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, t8 = 0, st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5; (void)t6; (void)t7; (void)t8; (void)st; (void)dbg;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -172,14 +176,14 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int gy = gy0 + r;
-            voff[r] = (okx && (unsigned)gy < (unsigned)dim) ? (unsigned)(((gy * dim + gx) * ((exp & 1) ? 8 : cin) + ((exp & 1) ? 0 : chunk * 8) + sp * 2) * 4) : OOB;
+            voff[r] = (okx && (unsigned)gy < (unsigned)dim) ? (unsigned)(((gy * dim + gx) * ((in_oct || (exp & 1)) ? 8 : cin) + ((in_oct || (exp & 1)) ? 0 : chunk * 8) + sp * 2) * 4) : OOB;
         }
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
             const int gz = gz0 + s;
             const bool okz = (unsigned)gz < (unsigned)dim;       // uniform
             const unsigned zmask = okz ? 0u : OOB;
-            const int soff = okz ? gz * dim * dim * ((exp & 1) ? 8 : cin) * 4 : 0;
+            const int soff = okz ? (in_oct ? (chunk * dim + gz) * dim * dim * 32 : gz * dim * dim * ((exp & 1) ? 8 : cin) * 4) : 0;
 #pragma unroll
             for (int r = 0; r < 2; ++r)
                 raw[s][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(voff[r] | zmask), soff, 0));
@@ -247,17 +251,21 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         // uniform 64-bit base of the wave's first output row + a 32-bit per-lane offset (global_* saddr form); raw buffer
         // STORES with a scalar offset dropped data here, so stores and skip loads use plain global accesses
         const long long s00 = (((((long long)u.b * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * a.cout + u.cb * 32 + ct * 16);
-        const int voff = px * a.cout + 4 * h;
-        const int ystride = dim * a.cout, zstride = dim * dim * a.cout;
-        float* ob = a.out + s00;
+        const int voff_cl = px * a.cout + 4 * h;
+        const int ystride_cl = dim * a.cout, zstride_cl = dim * dim * a.cout;
         const float* rb = a.res + s00;
+        // octet-planar output: octet (cb*4 + ct*2 + h/2), 16 bytes at (h & 1) * 4 inside the 8-channel record of voxel (z, y, x)
+        const long long s00o = (((((long long)u.b * (a.cout >> 3) + u.cb * 4 + ct * 2) * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * 8;
+        const int voff = out_oct ? (h >> 1) * dim * dim * dim * 8 + px * 8 + (h & 1) * 4 : voff_cl;
+        const int ystride = out_oct ? dim * 8 : ystride_cl, zstride = out_oct ? dim * dim * 8 : zstride_cl;
+        float* ob = a.out + (out_oct ? s00o : s00);
         const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + co);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             f32x4 resv[4];
             if (use_res && !(exp & 4)) {
 #pragma unroll
-                for (int z = 0; z < 4; ++z) resv[z] = *reinterpret_cast<const f32x4*>(rb + z * zstride + r * ystride + voff);
+                for (int z = 0; z < 4; ++z) resv[z] = *reinterpret_cast<const f32x4*>(rb + z * zstride_cl + r * ystride_cl + voff_cl);
             }
             if constexpr ((exp & 128) != 0) {
 #pragma unroll
@@ -505,26 +513,36 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
 #ifdef SE_STAMP2D
     dbg = g_w2d_dbg;
 #endif
-#define W2_LAUNCH(E)                                                                                                            \
+#define W2_LAUNCH(E, L)                                                                                                         \
     do {                                                                                                                        \
-        SE_ENSURE_LDS(conv3d_k3_wino2d_kernel<E>, W2_LDS_BYTES);                                                                \
-        hipLaunchKernelGGL(conv3d_k3_wino2d_kernel<E>, dim3((unsigned)((n_units + per - 1) / per)), dim3(512), W2_LDS_BYTES, s, a, \
-                           a.wpack_g, tx, ty, tz, (int)total_tiles, (int)n_units, per, dbg);                                    \
+        auto kern = conv3d_k3_wino2d_kernel<E, L>;                                                                              \
+        SE_ENSURE_LDS(kern, W2_LDS_BYTES);                                                                                      \
+        hipLaunchKernelGGL(kern, dim3((unsigned)((n_units + per - 1) / per)), dim3(512), W2_LDS_BYTES, s, a, a.wpack_g, tx, ty, \
+                           tz, (int)total_tiles, (int)n_units, per, dbg);                                                       \
     } while (0)
+    const int layout = ((a.flags & SE_IN_OCTET) ? 1 : 0) | ((a.flags & SE_OUT_OCTET) ? 2 : 0);
 #ifdef SE_DEVTOOLS
-    switch (g_variant) {
-        case 41: W2_LAUNCH(1); break;
-        case 42: W2_LAUNCH(2); break;
-        case 43: W2_LAUNCH(3); break;
-        case 44: W2_LAUNCH(4); break;
-        case 47: W2_LAUNCH(7); break;
-        case 48: W2_LAUNCH(0x400); break;   // staging alone
-        case 49: W2_LAUNCH(0x200); break;   // staging wave prioritised
-        default: W2_LAUNCH(0); break;
+    if (layout == 0 && g_variant >= 41) {
+        switch (g_variant) {
+            case 41: W2_LAUNCH(1, 0); break;
+            case 42: W2_LAUNCH(2, 0); break;
+            case 43: W2_LAUNCH(3, 0); break;
+            case 44: W2_LAUNCH(4, 0); break;
+            case 47: W2_LAUNCH(7, 0); break;
+            case 48: W2_LAUNCH(0x400, 0); break;   // staging alone
+            case 49: W2_LAUNCH(0x200, 0); break;   // staging wave prioritised
+            default: W2_LAUNCH(0, 0); break;
+        }
+        SE_CHECK_LAUNCH();
+        return 0;
     }
-#else
-    W2_LAUNCH(0);
 #endif
+    switch (layout) {
+        case 1: W2_LAUNCH(0, 1); break;
+        case 2: W2_LAUNCH(0, 2); break;
+        case 3: W2_LAUNCH(0, 3); break;
+        default: W2_LAUNCH(0, 0); break;
+    }
 #undef W2_LAUNCH
     SE_CHECK_LAUNCH();
     return 0;

@@ -469,3 +469,32 @@ def test_gather_planar3_other_channel_counts(channels):
     flat = p3.permute(0, 2, 1, 3).reshape(B, V, T * 3)
     assert torch.equal(flat[..., :channels], cl)
     assert float(flat[..., channels:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,dim,cin,cout", [(1, 16, 32, 32), (2, 32, 16, 32), (1, 16, 64, 128)])
+def test_conv3d_octet_planar_forms_match_channels_last(B, dim, cin, cout):
+    """The 2-D Winograd 3x3x3 kernel reads / writes the octet-planar layout [B][C/8][D][D][D][8] (SE_IN_OCTET / SE_OUT_OCTET, used
+    between the two convolutions of a Res3DBlock): same arithmetic in the same order, so results are bit-identical to the
+    channels-last call."""
+    torch.manual_seed(dim + cin)
+    conv = nn.Conv3d(cin, cout, 3, padding=1).to(DEV)
+    pc = _PackedConv(conv, _rand_bn(cout, 5).to(DEV))
+    assert _lib.conv3d_algo(dim, cin, cout, 3) == 2
+    x = torch.randn(B, dim, dim, dim, cin, device=DEV)
+    res = torch.randn(B, dim, dim, dim, cout, device=DEV)
+    flags = _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU
+    ref = torch.empty(B, dim, dim, dim, cout, device=DEV)
+    _lib.conv3d(x, pc.w, pc.b, res, ref, B, dim, cin, cin, cout, 3, flags)
+    x_oct = x.view(B, dim, dim, dim, cin // 8, 8).permute(0, 4, 1, 2, 3, 5).contiguous()
+    out = torch.empty_like(ref)
+    _lib.conv3d(x_oct, pc.w, pc.b, res, out, B, dim, cin, cin, cout, 3, flags | _lib.IN_OCTET)
+    assert torch.equal(out, ref)
+    out_oct = torch.empty(B, cout // 8, dim, dim, dim, 8, device=DEV)
+    _lib.conv3d(x, pc.w, pc.b, res, out_oct, B, dim, cin, cin, cout, 3, flags | _lib.OUT_OCTET)
+    assert torch.equal(out_oct.permute(0, 2, 3, 4, 1, 5).reshape(B, dim, dim, dim, cout), ref)
+    _lib.conv3d(x_oct, pc.w, pc.b, res, out_oct, B, dim, cin, cin, cout, 3, flags | _lib.IN_OCTET | _lib.OUT_OCTET)
+    assert torch.equal(out_oct.permute(0, 2, 3, 4, 1, 5).reshape(B, dim, dim, dim, cout), ref)
+    # shapes the 2-D kernel does not take refuse the flags
+    small = torch.randn(1, 8, 8, 8, cin, device=DEV)
+    with pytest.raises(_lib.HipExtensionError):
+        _lib.conv3d(small, pc.w, pc.b, None, torch.empty(1, 8, 8, 8, cout, device=DEV), 1, 8, cin, cin, cout, 3, _lib.IN_OCTET)

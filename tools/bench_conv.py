@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--variants", default="0,1")
     ap.add_argument("--no-res", action="store_true")
     ap.add_argument("--only", type=int, default=-1, help="index into SHAPES")
+    ap.add_argument("--octet", type=int, default=0, help="extra flags for 2-D Winograd shapes: 1 = IN_OCTET, 2 = OUT_OCTET, 3 = both (timing only)")
     ap.add_argument("--bf16", action="store_true", help="time se_conv3d_bf16 (bf16 storage) instead")
     args = ap.parse_args()
     lib = _lib.load()
@@ -54,23 +55,28 @@ def main():
         res = torch.randn(B, dim, dim, dim, cout, device=dev).to(dt)
         out = torch.empty(B, dim, dim, dim, cout, device=dev, dtype=dt)
         flop = 2.0 * B * dim ** 3 * k ** 3 * cin * cout
+        octet = 0
+        if args.octet and not args.bf16 and k == 3 and _lib.conv3d_algo(dim, cin_pad, cout, 3) == 2:
+            octet = (_lib.IN_OCTET if args.octet & 1 else 0) | (_lib.OUT_OCTET if args.octet & 2 else 0)
         times = {v: [] for v in variants}
         outs = {}
         for r in range(args.rounds + 2):
             for v in variants:
-                lib.se_debug_set_variant(v)
+                if hasattr(lib, "se_debug_set_variant"):
+                    lib.se_debug_set_variant(v)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 no_res = args.no_res or k == 7     # the front-layer Winograd / bf16 kernels have no skip input
                 _lib.conv3d(x, pc.w, pc.b, None if no_res else res, out, B, dim, cin, cin_pad, cout, k,
-                            _lib.EPI_RELU | (0 if no_res else _lib.EPI_RES_PRE_RELU), None if args.bf16 else ws)
+                            _lib.EPI_RELU | (0 if no_res else _lib.EPI_RES_PRE_RELU) | octet, None if args.bf16 else ws)
                 e1.record()
                 torch.cuda.synchronize()
                 if r >= 2:
                     times[v].append(e0.elapsed_time(e1))
                 if r == 0:
                     outs[v] = out.clone()
-        lib.se_debug_set_variant(0)
+        if hasattr(lib, "se_debug_set_variant"):
+            lib.se_debug_set_variant(0)
         base = outs[variants[0]]
         msg = f"k{k} {cin:3d}->{cout:3d} @{dim}^3 B={B}:"
         for v in variants:
