@@ -37,10 +37,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int W2_HALF_FLOATS = 3 * 4 * 3 * 2 * 128;      // xi_z 0..2 (or 3..5): 9216 floats = 36,864 B
 constexpr int W2_CHUNK_FLOATS = SE_WINO2D_CHUNK_FLOATS;  // 18,432 floats = 73,728 B
-constexpr int W2_VREC = 196;                             // floats per x record: 24 xi x 8 channels + 4 pad (bank spread, see below)
+constexpr int W2_VREC = 200;                             // floats per x record: 24 xi x 8 channels + 8 pad (bank spread, see below)
 constexpr int W2_VTILE = 18 * W2_VREC;                   // one y-tile: 18 x records
 constexpr int W2_VG_FLOATS = 2 * W2_VTILE;               // 7056 floats = 28,224 B per group
-constexpr int W2_DUMMY_FLOATS = 512;                     // landing zone of the masked-off y-transform outputs (see commit())
+constexpr int W2_DUMMY_FLOATS = 512;                     // 64 lanes x 4 floats + 6 x 32 floats of xi_z offsets                     // landing zone of the masked-off y-transform outputs (see commit())
 constexpr int W2_LDS_BYTES = (W2_CHUNK_FLOATS + 2 * W2_VG_FLOATS + W2_DUMMY_FLOATS) * 4;   // 132,224 B
 static_assert(W2_CHUNK_FLOATS == 2 * W2_HALF_FLOATS, "chunk = two halves");
 
@@ -49,10 +49,13 @@ __device__ __forceinline__ void for_each_idx(F&& f, std::integer_sequence<int, S
     (f(std::integral_constant<int, S>{}), ...);
 }
 
-// V layout [y-tile][x record][xi][8 channels]: all 24 xi of a position sit within 768 B of one base address, so the MFMA wave
-// reads them with immediate offsets (no address arithmetic in the MFMA stream).  Record stride 196 floats = 4 (mod 64): the 32 lanes
-// of a ds_read_b64 pass (16 consecutive x records x 2 k lanes) fall on 64 different banks for each of the three x-shifted windows.
-__device__ __forceinline__ int v_rec_offset(int xx, int p) { return xx * W2_VREC + p * 2; }
+// LDS operand layouts are built for ds_read_b128 (4 LDS cycles per KiB; the two-address ds_read2_b64 hipcc forms from adjacent
+// 8-byte reads takes 8): a lane's 16 bytes carry the channel pair of its k lane for TWO transform points xi_y = 2q, 2q+1.
+//   W [xi_z][q][dx][ct][lane][e][c]        lane-linear: conflict-free
+//   V [y-tile][x record][xi_z][q][k lane h][e][c], 200 floats per x record (= 8 mod 64): the 16 lanes of a ds_read_b128 pass
+//     (k lane h, positions per MI355X_MICROARCH.md's b128 lane groups) fall on 64 different banks for all three x-shifted windows;
+//     all 24 xi of a position sit within 768 B of one base address (immediate offsets, no address arithmetic in the MFMA stream).
+__device__ __forceinline__ int v_rec_offset(int xx, int p) { return xx * W2_VREC + p * 4; }
 
 // cycle stamps of the phase structure (diagnostic builds: build.sh --devtools -DSE_STAMP2D, tools/stamp_w2d.py)
 #ifdef SE_STAMP2D
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     float* vt = lds + W2_CHUNK_FLOATS + G * W2_VG_FLOATS;
 
     // ---- MFMA operand addresses ----
-    const float* a_h0 = wl + ct * 128 + lane * 2;
+    const float* a_h0 = wl + ct * 256 + lane * 4;
     const float* a_h1 = a_h0 + W2_HALF_FLOATS;
     const float* b_dx[3];
 #pragma unroll
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     // this lane's y-transform outputs: P, Q -> (y-tile sk, xi_y 0, 1) when sk < 2;  R, S -> (y-tile sk - 1, xi_y 2, 3) when sk > 0
     // (lanes without that output write into a per-lane slot of a dummy area instead of being masked off: no EXEC toggling in the
     // transform code, and distinct banks inside every store instruction)
-    float* v_dummy = lds + W2_CHUNK_FLOATS + 2 * W2_VG_FLOATS + lane * 2;
+    float* v_dummy = lds + W2_CHUNK_FLOATS + 2 * W2_VG_FLOATS + lane * 4;
     float* v_pq = (s_on && sk < 2) ? vt + sk * W2_VTILE + v_rec_offset(sxx, sp) : v_dummy;
     float* v_rs = (s_on && sk > 0) ? vt + (sk - 1) * W2_VTILE + v_rec_offset(sxx, sp) + 16 : v_dummy;
 
@@ -194,32 +197,38 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     // Scalar fmaf / adds on purpose (this file is built with -fno-slp-vectorize): packed float32 VALU beside the partner wave's MFMA
     // stream is an anti-lever (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
     auto commit = [&](const f32x2 (&raw)[6][2]) {
+        float t[2][6][2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            float t[6][2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const float d0 = raw[0][r][c], d1 = raw[1][r][c], d2 = raw[2][r][c], d3 = raw[3][r][c], d4 = raw[4][r][c], d5 = raw[5][r][c];
-                t[0][r] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
-                t[5][r] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+                t[c][0][r] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+                t[c][5][r] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
                 const float e1 = fmaf(-4.f, d2, d4), o1 = fmaf(-4.f, d1, d3);
-                t[1][r] = e1 + o1;
-                t[2][r] = e1 - o1;
+                t[c][1][r] = e1 + o1;
+                t[c][2][r] = e1 - o1;
                 const float e2 = d4 - d2, o2 = d3 - d1;
-                t[3][r] = fmaf(2.f, o2, e2);
-                t[4][r] = fmaf(-2.f, o2, e2);
+                t[c][3][r] = fmaf(2.f, o2, e2);
+                t[c][4][r] = fmaf(-2.f, o2, e2);
             }
+        }
 #pragma unroll
-            for (int z = 0; z < 6; ++z) {
-                const float ta = t[z][0], tb = t[z][1];
+        for (int z = 0; z < 6; ++z) {
+            f32x4 pq, rs;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float ta = t[c][z][0], tb = t[c][z][1];
                 // ra: first row of the lane to the right (row_shl:1), lb: second row of the lane to the left (row_shr:1)
                 const float ra = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ta), 0x101, 0xf, 0xf, true));
                 const float lb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tb), 0x111, 0xf, 0xf, true));
-                v_pq[(z * 4 + 0) * 8 + c] = ta - ra;
-                v_pq[(z * 4 + 1) * 8 + c] = tb + ra;
-                v_rs[(z * 4 + 0) * 8 + c] = ta - lb;
-                v_rs[(z * 4 + 1) * 8 + c] = lb - tb;
+                pq[c] = ta - ra;          // xi_y = 0
+                pq[2 + c] = tb + ra;      // xi_y = 1
+                rs[c] = ta - lb;          // xi_y = 2
+                rs[2 + c] = lb - tb;      // xi_y = 3
             }
+            *reinterpret_cast<f32x4*>(v_pq + z * 32) = pq;
+            *reinterpret_cast<f32x4*>(v_rs + z * 32) = rs;
         }
     };
 
@@ -307,34 +316,24 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
 
     // ---- MFMA phase: 18 groups (xi_z, dx) of 4 xi_y x 2 k steps; the workgroup's mid-phase barrier sits in front of the first
     // access to the second weight half ----
-    auto mfma_phase = [&]() {
+    auto mfma_phase = [&](auto&& vmem_a, auto&& vmem_b) {
         // operands of group g live in buffer g % 3 and are fetched two groups (16 MFMAs = 512 cycles) ahead of their use
-        f32x2 oa[3][4], ov[3][4];
+        f32x4 oa[3][2], ov[3][2];
         auto load_group = [&](auto g_tag) {
             constexpr int g2 = decltype(g_tag)::value;
             constexpr int xz2 = g2 / 3, dx2 = g2 % 3, b = g2 % 3;
             const float* ab = (xz2 < 3) ? a_h0 : a_h1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                oa[b][e] = *reinterpret_cast<const f32x2*>(ab + (((xz2 % 3) * 4 + e) * 3 + dx2) * 256);
-                ov[b][e] = *reinterpret_cast<const f32x2*>(b_dx[dx2] + (xz2 * 4 + e) * 8);
+            for (int q = 0; q < 2; ++q) {
+                oa[b][q] = *reinterpret_cast<const f32x4*>(ab + (((xz2 % 3) * 2 + q) * 3 + dx2) * 512);
+                ov[b][q] = *reinterpret_cast<const f32x4*>(b_dx[dx2] + (xz2 * 2 + q) * 16);
             }
         };
-        if constexpr ((exp & 0x400) != 0) {      // experiment: the staging code alone (no operand reads, no MFMAs)
-            W2_T(t1)
-            barrier();
-            W2_T(t2)
-            return;
-        }
         load_group(std::integral_constant<int, 0>{});
         load_group(std::integral_constant<int, 1>{});
         auto group = [&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
             constexpr int xz = g / 3, b = g % 3;
-#ifdef SE_STAMP2D
-            if constexpr (g == 1) { W2_T(t5) st[10] += t5 - t0; }
-            if constexpr (g == 4) { W2_T(t6) st[11] += t6 - t5; }
-#endif
             if constexpr (g == 7) {
                 // the prefetch below (group 9) is the first read of weight half 1; all reads of half 0 have been issued and are
                 // drained by the barrier's lgkmcnt(0), so the staging group may refill half 0 right behind it
@@ -343,10 +342,20 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
                 W2_T(t2)
             }
             if constexpr (g + 2 < 18) load_group(std::integral_constant<int, g + 2>{});
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[xz * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][e].x, ov[b][e].x, acc[xz * 4 + e], 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[xz * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][e].y, ov[b][e].y, acc[xz * 4 + e], 0, 0, 0);
+            // this wave's global loads for its NEXT step ride inside its own MFMA stream: a vector-memory instruction costs the
+            // issuing wave ~140 cycles wherever it sits, and the staging phase - not the MFMA phase - is the longer one
+            if constexpr (g == 1) vmem_a();
+            if constexpr (g == 9) vmem_b();
+            // xi_y = 2q + e: operand components (x, y) = channels of e = 0, (z, w) = channels of e = 1; first channel of all four
+            // xi_y, then the second (dependent MFMAs on one accumulator stay 4 apart)
+            acc[xz * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][0].x, ov[b][0].x, acc[xz * 4 + 0], 0, 0, 0);
+            acc[xz * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][0].z, ov[b][0].z, acc[xz * 4 + 1], 0, 0, 0);
+            acc[xz * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][1].x, ov[b][1].x, acc[xz * 4 + 2], 0, 0, 0);
+            acc[xz * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][1].z, ov[b][1].z, acc[xz * 4 + 3], 0, 0, 0);
+            acc[xz * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][0].y, ov[b][0].y, acc[xz * 4 + 0], 0, 0, 0);
+            acc[xz * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][0].w, ov[b][0].w, acc[xz * 4 + 1], 0, 0, 0);
+            acc[xz * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][1].y, ov[b][1].y, acc[xz * 4 + 2], 0, 0, 0);
+            acc[xz * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][1].w, ov[b][1].w, acc[xz * 4 + 3], 0, 0, 0);
             if constexpr (g + 2 < 18) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -360,21 +369,18 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         for_each_idx(group, std::make_integer_sequence<int, 18>{});
     };
 
-    // ---- prologue: weights of step 0 (group G stages half G), each group's V tile of step 0, input of step 1 in flight ----
+    // ---- prologue: weights of step 0 (group G stages half G), each group's V tile of step 0 ----
     Unit ucur = decode(u_begin);      // (unit, chunk) of the step this group computes next
     int ccur = 0, icur = 0;
-    Unit unx = ucur;                  // (unit, chunk) of the step whose input is in flight in `raw`
+    Unit unx = ucur;                  // (unit, chunk) of the step after it
     int cnx = 0, inx = 0;
     f32x2 raw[6][2];
-    {
-        f32x4 wreg[9];
-        w_fetch(wreg, ucur, 0, G);
-        fetch(raw, ucur, 0);
-        commit(raw);
-        w_commit(wreg, G);
-    }
+    f32x4 wreg[9];
+    w_fetch(wreg, ucur, 0, G);
+    fetch(raw, ucur, 0);
+    commit(raw);
+    w_commit(wreg, G);
     step_after(unx, cnx, inx);
-    fetch(raw, unx, cnx);
     if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(2);
     barrier();
     if (G == 1) {                     // group 1 runs one phase behind group 0
@@ -384,6 +390,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
 
     for (int i = 0; i < n_steps; ++i) {
         // ------------------------------ MFMA phase of step i = (ucur, ccur) ------------------------------
+        // ... and, inside it, the global loads of step i+1 = (unx, cnx): group G's weight half G and its input rows
         W2_T(t0)
         if (ccur == 0) {
 #pragma unroll
@@ -391,42 +398,51 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         }
         if constexpr ((exp & 0x300) == 0) __builtin_amdgcn_s_setprio(3);          // production
         if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(0);      // experiment: staging wave above the MFMA wave
-        mfma_phase();
+        mfma_phase([&]() { w_fetch(wreg, unx, cnx, G); }, [&]() { fetch(raw, unx, cnx); });
         if constexpr ((exp & 0x300) == 0) __builtin_amdgcn_s_setprio(0);
         if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(2);
         W2_T(t3)
         barrier();                                                // end of the MFMA phase
         W2_T(t4)
         // ------------------------------ staging phase ------------------------------
-        // `raw` holds the input of step i+1 = (unx, cnx), fetched a whole phase ago.  Order inside the phase: what the OTHER
-        // group needs first (its weight half), then this group's V tile, then the output of the finished tile, and last the
-        // fetch of step i+2, which lands during this group's next MFMA phase.
+        // `raw` / `wreg` hold the input rows and the weight half of step i+1, loaded during the MFMA phase.
         const bool epi = ccur == chunks - 1;
-        const Unit udone = ucur;
-        f32x4 wreg[9];
         if (G == 1) {
-            // group 1 stages weight half 1 of step i+1 in the first half of its staging phase (group 0 reads it right after the
-            // mid-phase barrier)
-            w_fetch(wreg, unx, cnx, 1);
-            commit(raw);
+            // group 1 owns weight half 1: written in the first half of its staging phase (group 0 reads it behind the mid-phase
+            // barrier; group 1 itself finished with half 1 of step i before the barrier above)
             w_commit(wreg, 1);
+#ifdef SE_STAMP2D
+            unsigned long long ta = 0;
+            W2_T(ta)
+            st[10] += ta - t4;
+#endif
+            commit(raw);
             W2_T(t5)
+#ifdef SE_STAMP2D
+            st[11] += t5 - ta;
+#endif
             barrier();                                            // mid-phase barrier
             W2_T(t6)
-            if (epi) epilogue(udone);
+            if (epi) epilogue(ucur);
         } else {
-            // group 0 stages weight half 0 of step i+1 in the second half (group 1 reads half 0 of step i in the first half)
-            w_fetch(wreg, unx, cnx, 0);
+            // group 0 owns weight half 0: written in the second half (group 1 reads half 0 of step i in the first half)
             commit(raw);
-            if (epi) epilogue(udone);
+#ifdef SE_STAMP2D
+            unsigned long long ta = 0;
+            W2_T(ta)
+            st[11] += ta - t4;
+#endif
+            if (epi) epilogue(ucur);
             W2_T(t5)
+#ifdef SE_STAMP2D
+            st[12] += t5 - ta;
+#endif
             barrier();                                            // mid-phase barrier
             W2_T(t6)
             w_commit(wreg, 0);
         }
         ucur = unx; ccur = cnx; icur = inx;
         step_after(unx, cnx, inx);
-        fetch(raw, unx, cnx);
         W2_T(t7)
         barrier();                                                // end of the staging phase
         W2_T(t8)
@@ -452,18 +468,19 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
 }  // namespace
 
 // Section G of the packed 3x3x3 weights (appended by se_conv3d_pack_f32): per (32-cout block cb, 8-channel chunk)
-//   [xi_z 6][xi_y 4][dx 3][ct 2][lane 64][e 2] = U[xi_z][xi_y][dx] of cout cb*32 + ct*16 + (lane & 15), cin chunk*8 + 2*(lane >> 4) + e,
-//   U = (G43 (x) G23) g over (dz, dy), times the folded BatchNorm scale.
+//   [xi_z 6][q 2][dx 3][ct 2][lane 64][e 2][c 2] = U[xi_z][xi_y = 2q + e][dx] of cout cb*32 + ct*16 + (lane & 15),
+//   cin chunk*8 + 2*(lane >> 4) + c;  U = (G43 (x) G23) g over (dz, dy), times the folded BatchNorm scale.
 __global__ void pack_k3_wino2d_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
                                       float eps, float* __restrict__ out, int cout, int cin, int cin_pad, long long total) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
-    const int e = (int)(t & 1);
-    const int lane = (int)((t >> 1) & 63);
-    long long r = t >> 7;
+    const int e = (int)(t & 1);                 // channel of the k lane's pair
+    const int exi = (int)((t >> 1) & 1);        // xi_y inside the pair
+    const int lane = (int)((t >> 2) & 63);
+    long long r = t >> 8;
     const int ct = (int)(r % 2); r /= 2;
     const int dx = (int)(r % 3); r /= 3;
-    const int xy = (int)(r % 4); r /= 4;
+    const int xy = (int)(r % 2) * 2 + exi; r /= 2;
     const int xz = (int)(r % 6); r /= 6;
     const int chunks = cin_pad / 8;
     const int chunk = (int)(r % chunks);

@@ -26,4 +26,4 @@ for g, name in ((0, "group A (waves 0-3)"), (1, "group B (waves 4-7)")):
     print(f"{name}: {nm:.0f} MFMA phases, {ns:.0f} staging phases per wave")
     print(f"   MFMA phase   : first half {w[:, :, 0].mean() / nm:7.0f}  mid-barrier wait {w[:, :, 1].mean() / nm:7.0f}  second half {w[:, :, 2].mean() / nm:7.0f}  end-barrier wait {w[:, :, 3].mean() / nm:7.0f}   (ideal 2304 + 2304 cycles of MFMA issue)")
     print(f"   staging phase: first half {w[:, :, 4].mean() / ns:7.0f}  mid-barrier wait {w[:, :, 5].mean() / ns:7.0f}  second half {w[:, :, 6].mean() / ns:7.0f}  end-barrier wait {w[:, :, 7].mean() / ns:7.0f}")
-    print(f"   MFMA phase detail: loop top -> after group 0 {w[:, :, 10].mean() / nm:7.0f}   groups 1-3 {w[:, :, 11].mean() / nm:7.0f}  (ideal 256 / 768)")
+    print(f"   staging first half: w_commit {w[:, :, 10].mean() / ns:7.0f}  commit {w[:, :, 11].mean() / ns:7.0f}  epilogue (1 phase in {cin // 8}) {w[:, :, 12].mean() / ns:7.0f}")
