@@ -381,6 +381,8 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     commit(raw);
     w_commit(wreg, G);
     step_after(unx, cnx, inx);
+    if constexpr ((exp & 0x800) != 0) w_fetch(wreg, unx, cnx, G);
+    if constexpr ((exp & 0x1000) != 0) fetch(raw, unx, cnx);
     if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(2);
     barrier();
     if (G == 1) {                     // group 1 runs one phase behind group 0
@@ -398,7 +400,9 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         }
         if constexpr ((exp & 0x300) == 0) __builtin_amdgcn_s_setprio(3);          // production
         if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(0);      // experiment: staging wave above the MFMA wave
-        mfma_phase([&]() { w_fetch(wreg, unx, cnx, G); }, [&]() { fetch(raw, unx, cnx); });
+        // experiments 0x800 / 0x1000: weight-half loads / input-row loads in the staging phase instead (one phase earlier)
+        mfma_phase([&]() { if constexpr (!(exp & 0x800)) w_fetch(wreg, unx, cnx, G); },
+                   [&]() { if constexpr (!(exp & 0x1000)) fetch(raw, unx, cnx); });
         if constexpr ((exp & 0x300) == 0) __builtin_amdgcn_s_setprio(0);
         if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(2);
         W2_T(t3)
@@ -443,6 +447,8 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         }
         ucur = unx; ccur = cnx; icur = inx;
         step_after(unx, cnx, inx);
+        if constexpr ((exp & 0x800) != 0) w_fetch(wreg, unx, cnx, G);
+        if constexpr ((exp & 0x1000) != 0) fetch(raw, unx, cnx);
         W2_T(t7)
         barrier();                                                // end of the staging phase
         W2_T(t8)
@@ -541,9 +547,9 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
 #ifdef SE_DEVTOOLS
     if (layout == 0 && g_variant >= 41) {
         switch (g_variant) {
-            case 41: W2_LAUNCH(1, 0); break;
-            case 42: W2_LAUNCH(2, 0); break;
-            case 43: W2_LAUNCH(3, 0); break;
+            case 41: W2_LAUNCH(0x800, 0); break;    // weight loads in the staging phase
+            case 42: W2_LAUNCH(0x1000, 0); break;   // input loads in the staging phase
+            case 43: W2_LAUNCH(0x1800, 0); break;   // both
             case 44: W2_LAUNCH(4, 0); break;
             case 47: W2_LAUNCH(7, 0); break;
             case 48: W2_LAUNCH(0x400, 0); break;   // staging alone

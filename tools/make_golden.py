@@ -225,6 +225,22 @@ def main():
 
     RefNet, cfg_mod, op_mod = import_reference()
     metas = []
+    if len(sys.argv) > 1 and sys.argv[1] == "--exr-hashes":
+        # f1: every demo depth map of the reference decoded by the INDEPENDENT brute-force decoder (oracle/exr_oracle.py);
+        # tests compare the product reader (sceneego_amd/exr.py) with these digests and, on the committed file, array by array
+        from oracle import exr_oracle
+        from sceneego_amd import exr
+        d = os.path.join(REF, "data", "demo", "depths")
+        out = {}
+        for f in sorted(os.listdir(d)):
+            y = exr_oracle.read(os.path.join(d, f))["Y"]
+            prod = exr.read_depth_exr(os.path.join(d, f))
+            out[f] = {"shape": list(y.shape), "dtype": str(y.dtype), "sha256_float32": hashlib.sha256(np.ascontiguousarray(y.astype(np.float32)).tobytes()).hexdigest(),
+                      "min": float(y.min()), "max": float(y.max()), "product_reader_equal": bool(np.array_equal(y.astype(np.float32), prod))}
+            print(f, out[f])
+        with open(os.path.join(GOLD, "exr_hashes.json"), "w") as fo:
+            json.dump({"generator": "tools/make_golden.py --exr-hashes (oracle/exr_oracle.py on /root/reference/data/demo/depths)", "files": out}, fo, indent=1)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-features-big":
         # 2nd return value of the reference forward, the literal [B,32,1024,1280] tensor (voxel_net_depth.py:238,275),
         # sub-sampled on a fixed lattice that hits the zero pad columns, block interiors and block edges
