@@ -284,6 +284,17 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
                 continue;
             }
             f32x4 out[4];
+            if constexpr ((exp & 0x2000) != 0) {       // experiment: packed float32 arithmetic (v_pk_add_f32 / v_pk_fma_f32)
+                f32x4 m[6];
+#pragma unroll
+                for (int z = 0; z < 6; ++z)
+                    m[z] = r == 0 ? (acc[z * 4 + 0] + acc[z * 4 + 1]) + acc[z * 4 + 2] : (acc[z * 4 + 1] - acc[z * 4 + 2]) - acc[z * 4 + 3];
+                const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+                out[0] = ((m[0] + s12) + s34) + bias;
+                out[1] = (2.f * d34 + d12) + bias;
+                out[2] = (4.f * s34 + s12) + bias;
+                out[3] = ((8.f * d34 + d12) + m[5]) + bias;
+            } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {      // scalar on purpose, see commit()
                 float m[6];
@@ -296,6 +307,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
                 out[1][c] = fmaf(2.f, d34, d12) + b;
                 out[2][c] = fmaf(4.f, s34, s12) + b;
                 out[3][c] = (fmaf(8.f, d34, d12) + m[5]) + b;
+            }
             }
 #pragma unroll
             for (int z = 0; z < 4; ++z) {
@@ -342,8 +354,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
                 W2_T(t2)
             }
             if constexpr (g + 2 < 18) load_group(std::integral_constant<int, g + 2>{});
-            // this wave's global loads for its NEXT step ride inside its own MFMA stream: a vector-memory instruction costs the
-            // issuing wave ~140 cycles wherever it sits, and the staging phase - not the MFMA phase - is the longer one
+            // this wave's weight-half loads for its NEXT step ride inside its own MFMA stream
             if constexpr (g == 1) vmem_a();
             if constexpr (g == 9) vmem_b();
             // xi_y = 2q + e: operand components (x, y) = channels of e = 0, (z, w) = channels of e = 1; first channel of all four
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     w_commit(wreg, G);
     step_after(unx, cnx, inx);
     if constexpr ((exp & 0x800) != 0) w_fetch(wreg, unx, cnx, G);
-    if constexpr ((exp & 0x1000) != 0) fetch(raw, unx, cnx);
+    if constexpr (!(exp & 0x1000)) fetch(raw, unx, cnx);
     if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(2);
     barrier();
     if (G == 1) {                     // group 1 runs one phase behind group 0
@@ -400,9 +411,11 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         }
         if constexpr ((exp & 0x300) == 0) __builtin_amdgcn_s_setprio(3);          // production
         if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(0);      // experiment: staging wave above the MFMA wave
-        // experiments 0x800 / 0x1000: weight-half loads / input-row loads in the staging phase instead (one phase earlier)
+        // measured (tools/bench_conv.py, one process): weight loads inside the MFMA stream + input-row loads at the end of the
+        // staging phase is the fastest of the four placements (0.491 vs 0.516 / 0.529 / 0.490 ms at 32->32 @64^3);
+        // experiments 0x800: weight loads in the staging phase, 0x1000: input loads in the MFMA stream
         mfma_phase([&]() { if constexpr (!(exp & 0x800)) w_fetch(wreg, unx, cnx, G); },
-                   [&]() { if constexpr (!(exp & 0x1000)) fetch(raw, unx, cnx); });
+                   [&]() { if constexpr ((exp & 0x1000) != 0) fetch(raw, unx, cnx); });
         if constexpr ((exp & 0x300) == 0) __builtin_amdgcn_s_setprio(0);
         if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(2);
         W2_T(t3)
@@ -448,7 +461,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         ucur = unx; ccur = cnx; icur = inx;
         step_after(unx, cnx, inx);
         if constexpr ((exp & 0x800) != 0) w_fetch(wreg, unx, cnx, G);
-        if constexpr ((exp & 0x1000) != 0) fetch(raw, unx, cnx);
+        if constexpr (!(exp & 0x1000)) fetch(raw, unx, cnx);      // input rows of step i+2: land during the next MFMA phase
         W2_T(t7)
         barrier();                                                // end of the staging phase
         W2_T(t8)
@@ -547,7 +560,7 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
 #ifdef SE_DEVTOOLS
     if (layout == 0 && g_variant >= 41) {
         switch (g_variant) {
-            case 41: W2_LAUNCH(0x800, 0); break;    // weight loads in the staging phase
+            case 41: W2_LAUNCH(0x2000, 0); break;   // packed epilogue arithmetic
             case 42: W2_LAUNCH(0x1000, 0); break;   // input loads in the staging phase
             case 43: W2_LAUNCH(0x1800, 0); break;   // both
             case 44: W2_LAUNCH(4, 0); break;
