@@ -24,8 +24,15 @@ from test_gpu_kernels import _ncdhw, _ndhwc, _rand_bn
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 BF = torch.bfloat16
-# accuracy the bf16-storage mode is specified to, against the float32 reference goldens (metres); DESIGN.md 4b
-BF16_JOINT_TOL = 1e-1
+# Accuracy the bf16-storage mode is specified to (evidence: profiles/r02_parity_evidence.txt).
+#   * logits: rms error <= 2 % of the logits' standard deviation (measured 0.9 %: 8-bit mantissas through a 50-layer chain);
+#   * joints: <= 4e-2 m against the float32 reference goldens (measured 0.6 - 2.2 cm).  The synthetic-weight network is a
+#     deliberately sharp soft-argmax (median peak probability 0.05 over 262 144 voxels): iid logit noise of 1e-3 relative already
+#     moves a joint by 5.5 mm (tools/diag/bf16_sensitivity.py), so 3e-3 m is out of reach of ANY bf16-storage program on these
+#     weights, while the float32 program sits at 2e-5 .. 3e-4 m.  The bound below is the measured error with a 2x margin, not a
+#     sanity bound.
+BF16_JOINT_TOL = 4e-2
+BF16_LOGIT_RMS_TOL = 2e-2      # x std of the float32 logits
 
 
 def _r(x):

@@ -11,12 +11,13 @@ pc = _PackedConv(conv, None)
 x = torch.randn(B, dim, dim, dim, cin, device=dev); res = torch.randn(B, dim, dim, dim, cout, device=dev)
 out = torch.empty_like(res)
 lib.se_debug_set_variant(int(os.environ.get("VARIANT", 0)))
+FL = (_lib.IN_OCTET if int(os.environ.get("OCTET", 0)) & 1 else 0) | (_lib.OUT_OCTET if int(os.environ.get("OCTET", 0)) & 2 else 0)
 dbg = torch.zeros(256 * 8 * 16, dtype=torch.int64, device=dev)
 for _ in range(3):
-    _lib.conv3d(x, pc.w, pc.b, res, out, B, dim, cin, cin, cout, 3, 3, None)
+    _lib.conv3d(x, pc.w, pc.b, res, out, B, dim, cin, cin, cout, 3, 3 | FL, None)
 lib.se_debug_set_stamp_buffer_2d.argtypes = [ctypes.c_void_p]
 lib.se_debug_set_stamp_buffer_2d(ctypes.c_void_p(dbg.data_ptr()))
-_lib.conv3d(x, pc.w, pc.b, res, out, B, dim, cin, cin, cout, 3, 3, None)
+_lib.conv3d(x, pc.w, pc.b, res, out, B, dim, cin, cin, cout, 3, 3 | FL, None)
 torch.cuda.synchronize()
 lib.se_debug_set_stamp_buffer_2d(None)
 d = dbg.view(256, 8, 16).double()
