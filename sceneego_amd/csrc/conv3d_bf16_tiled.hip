@@ -25,7 +25,7 @@ constexpr int K3_TX = 4, K3_TY = 8, K3_TZ = 16;
 constexpr int K3_HX = K3_TX + 2, K3_HY = K3_TY + 2, K3_HZ = K3_TZ + 2;
 constexpr int K3_HALO_VOX = K3_HX * K3_HY * K3_HZ;            // 1080
 constexpr int K3_HALO_PIECES = K3_HALO_VOX * 2;               // 2160 x 16 B
-constexpr int K3_HALO_BYTES = K3_HALO_PIECES * 16;            // 34560
+[[maybe_unused]] constexpr int K3_HALO_BYTES = K3_HALO_PIECES * 16;            // 34560
 constexpr int K3_KPC = 14;
 constexpr int K3_W_PIECES = K3_KPC * 2 * 64;                  // 1792 x 16 B
 constexpr int K3_W_BYTES = K3_W_PIECES * 16;                  // 28672
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void conv_bf16_k3_kernel(Conv
     K3_STAMP(6);
 }
 
+#ifdef SE_DEVTOOLS   // retired A/B variant: persistent double-buffered form of the bf16 3x3x3 kernel
 // ------------------------------------------------------------------------------------------------
 // Persistent form of the 3x3x3 kernel (NOT the production path; se_debug_set_variant(3)): one 512-thread workgroup per CU
 // loops over (tile, cout block) items.
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_k3p_kernel(ConvBArgs a, int 
         buf ^= 1;
     }
 }
+#endif  // SE_DEVTOOLS (persistent bf16 3x3x3 kernel)
 
 // ------------------------------------------------------------------------------------------------
 // 7x7x7 front layer, cout = 16, dim % 8 == 0, octet-planar input [B][octs][D^3][8].
@@ -630,6 +632,7 @@ static int launch_k3(const ConvBArgs& a, int batch, hipStream_t s) {
 static bool epi_has_res_host(const ConvBArgs& a) { return a.res && (a.flags & (SE_EPI_RES_PRE_RELU | SE_EPI_RES_POST_RELU)); }
 
 int se_conv3d_bf16_tiled_try(const ConvBArgs& a, int batch, int ksize, hipStream_t s) {
+#ifdef SE_DEVTOOLS
     if (ksize == 3 && a.dim % 16 == 0 && a.cin_pad % 16 == 0 && a.cout % 32 == 0 && a.kpc == K3_KPC && a.total_vox < (1LL << 31) &&
         g_variant == 3) {      // A/B only: the persistent form measured 13-18 % SLOWER than two independent workgroups per CU
         SE_ENSURE_LDS(conv_bf16_k3p_kernel, K3P_LDS_BYTES);
@@ -643,6 +646,7 @@ int se_conv3d_bf16_tiled_try(const ConvBArgs& a, int batch, int ksize, hipStream
             return 0;
         }
     }
+#endif
     if (ksize == 3 && a.dim % 16 == 0 && a.cin_pad % 16 == 0 && a.cout % 32 == 0 && a.kpc == K3_KPC && a.total_vox < (1LL << 31))
         return g_variant == 4 ? launch_k3<4>(a, batch, s) : launch_k3<8>(a, batch, s);   // 4: tile 4x4x16, 3 workgroups per CU (A/B)
     if (ksize == 7 && a.dim % 8 == 0 && a.cout == 16 && a.kpc == SE_K7B_KPC && !epi_has_res_host(a) &&

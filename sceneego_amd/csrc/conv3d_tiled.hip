@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void conv3d_tiled_kernel(ConvArgs a, int tiles
     }
 }
 
+#ifdef SE_DEVTOOLS   // retired A/B variants: persistent direct (non-Winograd) kernels of the 64^3 level
 // ------------------------------------------------------------------------------------------------
 // Persistent 3x3x3 kernel for the 64^3 level (cout = 32, cin = 16 or 32): the workhorse of V2V (10 launches,
 // 46 % of all MACs).  One 512-thread workgroup per CU keeps ALL packed weights of the layer in LDS (54 KB per
@@ -606,6 +607,8 @@ int launch_k7_persistent(const ConvArgs& a, int batch, hipStream_t s) {
     return 0;
 }
 
+#endif  // SE_DEVTOOLS (persistent direct kernels)
+
 template <int KS, int CK, int TZ, int N_T>
 int launch_tiled(const ConvArgs& a, int batch, hipStream_t s) {
     using G = TileGeom<KS, CK, TZ>;
@@ -657,11 +660,11 @@ int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) 
 
 static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s) {
     const int dim = a.dim;
-    if (ksize == 3 && (g_variant == 0 || (g_variant >= 40 && g_variant < 50))) {   // production: 2-D Winograd F(4,3) x F(2,3), register accumulators (se_debug_set_variant(30): 1-D F(4,3))
+    if (ksize == 3 && (g_variant == 0 || (g_variant >= 40 && g_variant < 50))) {   // production: 2-D Winograd F(4,3) x F(2,3), register accumulators
         const int rc = se_conv3d_wino2d_try(a, batch, s);
         if (rc != SE_TILED_NOT_TAKEN) return rc;
     }
-    if (ksize == 3 && (g_variant == 0 || g_variant == 4 || g_variant == 30 || (g_variant >= 10 && g_variant < 20))) {   // 1-D Winograd persistent kernels
+    if (ksize == 3 && (g_variant == 0 || g_variant == 4 || g_variant == 30 || (g_variant >= 10 && g_variant < 20))) {   // 1-D Winograd F(4,3) (se_debug_set_variant(30): instead of the 2-D kernel)
         const int rc = se_conv3d_wino_try(a, batch, s);
         if (rc != SE_TILED_NOT_TAKEN) return rc;
     }
@@ -669,6 +672,7 @@ static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s)
     if (a.cout & 15) return SE_TILED_NOT_TAKEN;               // planar 15-channel output layer: direct kernel
     const int nts = a.nts;
     if (ksize == 3) {
+#ifdef SE_DEVTOOLS
         // BASELINE config 5 (LDS tile-size sweep, tools/bench_conv.py --variants 21,22,23): non-persistent LDS-tiled direct
         // kernel with 8x8x{4,8,16} output tiles = 38 / 64 / 115 KB of halo per 16-channel chunk
         if (g_variant >= 21 && g_variant <= 23 && nts % 2 == 0 && dim % 16 == 0) {
@@ -676,25 +680,27 @@ static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s)
             if (g_variant == 22) return launch_tiled<3, 16, 8, 2>(a, batch, s);
             return launch_tiled<3, 16, 16, 2>(a, batch, s);
         }
-        if (g_variant != 1 && g_variant != 3 && a.cout == 32 && dim >= 32 && (a.cin == 16 || a.cin == 32) && a.cin_pad == a.cin &&
+        if ((g_variant == 2 || g_variant == 3) && a.cout == 32 && dim >= 32 && (a.cin == 16 || a.cin == 32) && a.cin_pad == a.cin &&
             !(a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR))) {
             if (g_variant == 2)
                 return a.cin == 32 ? launch_k3_c32_persistent<2, false>(a, batch, s) : launch_k3_c32_persistent<1, false>(a, batch, s);
             return a.cin == 32 ? launch_k3_c32_persistent<2, true>(a, batch, s) : launch_k3_c32_persistent<1, true>(a, batch, s);
         }
+#endif
+        // shapes no Winograd kernel covers (cout % 32 != 0, cin % 16 != 0): LDS-tiled direct kernel
         if (nts % 4 == 0) return launch_tiled<3, 16, 4, 4>(a, batch, s);
         if (nts % 2 == 0) return launch_tiled<3, 16, 4, 2>(a, batch, s);
         return launch_tiled<3, 16, 4, 1>(a, batch, s);
     }
     if (ksize == 7 && nts == 1) {
-        if (g_variant == 0 || g_variant >= 10) {   // production: F(2,7) Winograd persistent kernel
+        if (g_variant == 0 || g_variant >= 10) {   // production: F(4,7) Winograd persistent kernel
             const int rc = se_conv3d_k7_wino_try(a, batch, s);
             if (rc != SE_TILED_NOT_TAKEN) return rc;
         }
         if (a.flags & SE_IN_PLANAR3) return SE_ERR_BAD_ARG;
-        if (g_variant != 1 && dim >= 32 && a.cout == 16 && !a.res && !(a.flags & SE_EPI_OUT_PLANAR)) {
-            return launch_k7_persistent(a, batch, s);
-        }
+#ifdef SE_DEVTOOLS
+        if (g_variant == 2 && dim >= 32 && a.cout == 16 && !a.res && !(a.flags & SE_EPI_OUT_PLANAR)) return launch_k7_persistent(a, batch, s);
+#endif
         return launch_tiled<7, 4, 4, 1>(a, batch, s);
     }
     return SE_TILED_NOT_TAKEN;

@@ -29,8 +29,8 @@ int se_conv3d_k7_wino47_launch_p3(const ConvArgs& a, int batch, int num_cus, hip
 namespace {
 
 constexpr int HZ = 6, HY = 10, HX = 10, HV = HZ * HY * HX;   // halo voxels of a 4x8x8 tile
-constexpr int TILE_FLOATS = HV * 16;                          // one 16-channel chunk
-constexpr int PF = (HV * 4 + 511) / 512;                      // 16-byte pieces per thread (5)
+[[maybe_unused]] constexpr int TILE_FLOATS = HV * 16;                          // one 16-channel chunk
+[[maybe_unused]] constexpr int PF = (HV * 4 + 511) / 512;                      // 16-byte pieces per thread (5)
 
 template <typename F, int... S>
 __device__ __forceinline__ void for_each_index(F&& f, std::integer_sequence<int, S...>) {
@@ -61,6 +61,7 @@ struct WinoIter {   // uniform walk over this workgroup's items: runs of units w
     bool valid;
 };
 
+#ifdef SE_DEVTOOLS   // retired A/B variants: F(2,3) 3^3 kernel, F(2,7) 7^3 kernels (single-phase and ping-pong)
 template <bool STAMP>
 __global__ __launch_bounds__(512) void conv3d_k3_wino_kernel(ConvArgs a, int tiles_per_dim, int ztiles, int total_tiles,
                                                              int n_cb, int units_per_wg, int diag,
@@ -753,6 +754,7 @@ __global__ __launch_bounds__(512) void conv3d_k7_winopp_kernel(ConvArgs a, int t
     }
 }
 
+#endif  // SE_DEVTOOLS (retired F(2,3) / F(2,7) kernels)
 // ------------------------------------------------------------------------------------------------
 // 3x3x3 convolution with 1-D Winograd F(4,3) along z: 6 multiplies per 4 z-neighbouring outputs instead of 12
 // -> HALF the MFMAs of the direct form (F(2,3) above: 2/3).  Lavin-Gray matrices, points {0, +-1, +-2, inf}:
@@ -765,8 +767,9 @@ __global__ __launch_bounds__(512) void conv3d_k7_winopp_kernel(ConvArgs a, int t
 // fp32 error of the transform ~4e-7 mean / 5e-6 max per 3-tap dot product (tools/wino_matrices.py).
 // ------------------------------------------------------------------------------------------------
 constexpr int W43_FLOATS = SE_WINO43_CHUNK_FLOATS;
-constexpr int V43_FLOATS = 6 * HY * HX * 16;
+[[maybe_unused]] constexpr int V43_FLOATS = 6 * HY * HX * 16;
 
+#ifdef SE_DEVTOOLS   // retired A/B variant: single-phase form of the F(4,3) kernel
 #ifdef SE_STAMP43
 #define SE_ST43(IDX)                                                                           \
     {                                                                                          \
@@ -1031,6 +1034,8 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int t
     }
 #endif
 }
+
+#endif  // SE_DEVTOOLS (single-phase F(4,3) kernel)
 
 // ------------------------------------------------------------------------------------------------
 // F(4,3) kernel, "ping-pong" form (production; 4-7 % faster than the single-phase form in one-process A/B runs): the same arithmetic, weights and work units as conv3d_k3_wino43_kernel,
@@ -1314,55 +1319,57 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino43pp_kernel(ConvArgs a, int
 #endif
 }
 
-unsigned long long* g_wino_dbg = nullptr;
+[[maybe_unused]] unsigned long long* g_wino_dbg = nullptr;
 unsigned long long* g_wino_dbg43 = nullptr;
 
 }  // namespace
 
 // Returns 0 on launch, SE_TILED_NOT_TAKEN if the shape/flags are not covered, else a hipError_t.
+// Production: the ping-pong F(4,3) kernel (shapes the 2-D kernel of conv3d_wino2d.hip does not take, e.g. dim % 16 != 0).
+// Development builds add the retired forms: se_debug_set_variant(4) F(2,3), (19) single-phase F(4,3), stamp builds.
 int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
     const int dim = a.dim;
-    if (!a.wpack_b || dim < 16 || (dim & 7) || (a.cout & 31) || (a.cin & 15) || a.cin_pad != a.cin) return SE_TILED_NOT_TAKEN;
+    if (!a.wpack_b || !a.wpack_e || dim < 16 || (dim & 7) || (a.cout & 31) || (a.cin & 15) || a.cin_pad != a.cin) return SE_TILED_NOT_TAKEN;
     if (a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR | SE_IN_OCTET | SE_OUT_OCTET)) return SE_TILED_NOT_TAKEN;
-    constexpr int LDS_FIXED = (SE_WINO_CHUNK_FLOATS + 2 * TILE_FLOATS) * 4;
-    constexpr int LDS_BYTES = 160 * 1024;                       // fixed part + unit table (16 B per unit)
-    constexpr int MAX_UNITS_PER_WG = (LDS_BYTES - LDS_FIXED) / 16;
-    SE_ENSURE_LDS(conv3d_k3_wino_kernel<false>, LDS_BYTES);
-    SE_ENSURE_LDS(conv3d_k3_wino_kernel<true>, LDS_BYTES);
-    const int g_num_cus_wino = se_num_cus();
+    constexpr int LDS43 = 160 * 1024;
+    constexpr int MAXPP = (LDS43 - (W43_FLOATS + 2 * PP_VH_FLOATS) * 4) / 16;
+    const int num_cus = se_num_cus();
     const int tiles = dim / 8, ztiles = dim / 4;
     const int total_tiles = batch * ztiles * tiles * tiles;
     const int n_cb = a.cout / 32;
     const int n_units = n_cb * total_tiles;
-    const int grid = n_units < g_num_cus_wino ? n_units : g_num_cus_wino;
+    const int grid = n_units < num_cus ? n_units : num_cus;
     const int per = (n_units + grid - 1) / grid;
-    if (per > MAX_UNITS_PER_WG) return SE_TILED_NOT_TAKEN;      // B > ~150 at 64^3: fall back to the tiled kernel
-    if (a.wpack_e && g_variant != 4 && !g_wino_dbg) {            // production: F(4,3)
-        constexpr int LDS43 = 160 * 1024;
+#ifdef SE_DEVTOOLS
+    {
+        constexpr int LDS_FIXED = (SE_WINO_CHUNK_FLOATS + 2 * TILE_FLOATS) * 4;
+        constexpr int MAX_UNITS_PER_WG = (LDS43 - LDS_FIXED) / 16;
         constexpr int MAX43 = (LDS43 - (W43_FLOATS + V43_FLOATS) * 4) / 16;
-        SE_ENSURE_LDS(conv3d_k3_wino43_kernel, LDS43);
-        constexpr int MAXPP = (LDS43 - (W43_FLOATS + 2 * PP_VH_FLOATS) * 4) / 16;
-        SE_ENSURE_LDS(conv3d_k3_wino43pp_kernel, LDS43);
-        if (per <= MAXPP && g_variant != 19) {       // production: ping-pong form; se_debug_set_variant(19) = single-phase form
-            hipLaunchKernelGGL(conv3d_k3_wino43pp_kernel, dim3((n_units + per - 1) / per), dim3(512), LDS43, s, a, tiles, ztiles,
+        if ((g_variant == 4 || g_wino_dbg) && per <= MAX_UNITS_PER_WG) {
+            SE_ENSURE_LDS(conv3d_k3_wino_kernel<false>, LDS43);
+            SE_ENSURE_LDS(conv3d_k3_wino_kernel<true>, LDS43);
+            if (g_wino_dbg)
+                hipLaunchKernelGGL(conv3d_k3_wino_kernel<true>, dim3((n_units + per - 1) / per), dim3(512), LDS43, s, a, tiles, ztiles,
+                                   total_tiles, n_cb, per, 0, g_wino_dbg);
+            else
+                hipLaunchKernelGGL(conv3d_k3_wino_kernel<false>, dim3((n_units + per - 1) / per), dim3(512), LDS43, s, a, tiles, ztiles,
+                                   total_tiles, n_cb, per, 0, nullptr);
+            SE_CHECK_LAUNCH();
+            return 0;
+        }
+        if (g_variant == 19 && per <= MAX43) {
+            SE_ENSURE_LDS(conv3d_k3_wino43_kernel, LDS43);
+            hipLaunchKernelGGL(conv3d_k3_wino43_kernel, dim3((n_units + per - 1) / per), dim3(512), LDS43, s, a, tiles, ztiles,
                                total_tiles, n_cb, per, 0, g_wino_dbg43);
             SE_CHECK_LAUNCH();
             return 0;
         }
-        if (per <= MAX43) {
-            hipLaunchKernelGGL(conv3d_k3_wino43_kernel, dim3((n_units + per - 1) / per), dim3(512), LDS43, s, a, tiles, ztiles,
-                               total_tiles, n_cb, per, g_variant >= 10 ? g_variant - 10 : 0, g_wino_dbg43);
-            SE_CHECK_LAUNCH();
-            return 0;
-        }
     }
-    if (g_wino_dbg) {   // diagnostic stamp build (se_debug_set_stamp_buffer)
-        hipLaunchKernelGGL(conv3d_k3_wino_kernel<true>, dim3((n_units + per - 1) / per), dim3(512), LDS_BYTES, s, a, tiles,
-                           ztiles, total_tiles, n_cb, per, 0, g_wino_dbg);
-    } else {
-        hipLaunchKernelGGL(conv3d_k3_wino_kernel<false>, dim3((n_units + per - 1) / per), dim3(512), LDS_BYTES, s, a, tiles,
-                           ztiles, total_tiles, n_cb, per, g_variant >= 10 ? g_variant - 10 : 0, nullptr);
-    }
+#endif
+    if (per > MAXPP) return SE_TILED_NOT_TAKEN;      // cannot happen behind se_conv3d_tiled_try's unit-budget batch slices
+    SE_ENSURE_LDS(conv3d_k3_wino43pp_kernel, LDS43);
+    hipLaunchKernelGGL(conv3d_k3_wino43pp_kernel, dim3((n_units + per - 1) / per), dim3(512), LDS43, s, a, tiles, ztiles, total_tiles,
+                       n_cb, per, 0, g_wino_dbg43);
     SE_CHECK_LAUNCH();
     return 0;
 }
@@ -1379,32 +1386,36 @@ extern "C" void se_debug_set_stamp_buffer(void* p) {
 #endif
 
 // Returns 0 on launch, SE_TILED_NOT_TAKEN if not covered, else a hipError_t.
+// Production: the F(4,7) kernel of conv3d_wino47.hip.  Development builds add the retired F(2,7) kernels
+// (se_debug_set_variant(17) single-phase, (19) ping-pong).
 int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
     const int dim = a.dim;
-    if (!a.wpack_d || dim < 16 || (dim & 7) || a.cout != 16 || a.res || (a.flags & (SE_EPI_OUT_PLANAR))) return SE_TILED_NOT_TAKEN;
-    constexpr int LDS_FIXED = (K7_W_FLOATS + K7_VT_FLOATS) * 4;
-    constexpr int LDS_BYTES = 160 * 1024;
-    constexpr int MAX_UNITS = (LDS_BYTES - LDS_FIXED) / 16;
-    SE_ENSURE_LDS(conv3d_k7_wino_kernel, LDS_BYTES);
-    SE_ENSURE_LDS(conv3d_k7_winopp_kernel, LDS_BYTES);
+    if (!a.wpack_d || !a.wpack_f || dim < 16 || (dim & 7) || a.cout != 16 || a.res || (a.flags & (SE_EPI_OUT_PLANAR))) return SE_TILED_NOT_TAKEN;
     const int num_cus = se_num_cus();
-    if (a.wpack_f && g_variant != 17 && g_variant != 19) {       // production: F(4,7) (conv3d_wino47.hip); se_debug_set_variant(17) = F(2,7)
-        const int rc = (a.flags & SE_IN_PLANAR3) ? se_conv3d_k7_wino47_launch_p3(a, batch, num_cus, s, g_wino_dbg43)
-                                                 : se_conv3d_k7_wino47_launch_cl(a, batch, num_cus, s, g_wino_dbg43);
-        if (rc != SE_TILED_NOT_TAKEN) return rc;
+#ifdef SE_DEVTOOLS
+    if (g_variant == 17 || g_variant == 19) {
+        if (a.flags & SE_IN_PLANAR3) return SE_ERR_BAD_ARG;   // only the F(4,7) kernel reads the triplet-planar layout
+        constexpr int LDS_BYTES = 160 * 1024;
+        constexpr int MAX_UNITS = (LDS_BYTES - (K7_W_FLOATS + K7_VT_FLOATS) * 4) / 16;
+        const int tiles = dim / 8, ztiles = dim / 4;
+        const int total_tiles = batch * ztiles * tiles * tiles;
+        const int grid = total_tiles < num_cus ? total_tiles : num_cus;
+        const int per = (total_tiles + grid - 1) / grid;
+        if (per > MAX_UNITS) return SE_TILED_NOT_TAKEN;
+        SE_ENSURE_LDS(conv3d_k7_wino_kernel, LDS_BYTES);
+        SE_ENSURE_LDS(conv3d_k7_winopp_kernel, LDS_BYTES);
+        if (g_variant == 17)
+            hipLaunchKernelGGL(conv3d_k7_wino_kernel, dim3((total_tiles + per - 1) / per), dim3(512), LDS_BYTES, s, a, tiles, ztiles,
+                               total_tiles, per);
+        else
+            hipLaunchKernelGGL(conv3d_k7_winopp_kernel, dim3((total_tiles + per - 1) / per), dim3(512), LDS_BYTES, s, a, tiles, ztiles,
+                               total_tiles, per);
+        SE_CHECK_LAUNCH();
+        return 0;
     }
-    if (a.flags & SE_IN_PLANAR3) return SE_ERR_BAD_ARG;   // only the F(4,7) kernel reads the triplet-planar layout
-    const int tiles = dim / 8, ztiles = dim / 4;
-    const int total_tiles = batch * ztiles * tiles * tiles;
-    const int grid = total_tiles < num_cus ? total_tiles : num_cus;
-    const int per = (total_tiles + grid - 1) / grid;
-    if (per > MAX_UNITS) return SE_TILED_NOT_TAKEN;
-    if (g_variant != 19)   // production: single-phase form (the ping-pong form measured 4.35 vs 4.15 ms: se_debug_set_variant(19))
-        hipLaunchKernelGGL(conv3d_k7_wino_kernel, dim3((total_tiles + per - 1) / per), dim3(512), LDS_BYTES, s, a, tiles, ztiles,
-                           total_tiles, per);
-    else
-        hipLaunchKernelGGL(conv3d_k7_winopp_kernel, dim3((total_tiles + per - 1) / per), dim3(512), LDS_BYTES, s, a, tiles, ztiles,
-                           total_tiles, per);
-    SE_CHECK_LAUNCH();
-    return 0;
+#endif
+    const int rc = (a.flags & SE_IN_PLANAR3) ? se_conv3d_k7_wino47_launch_p3(a, batch, num_cus, s, g_wino_dbg43)
+                                             : se_conv3d_k7_wino47_launch_cl(a, batch, num_cus, s, g_wino_dbg43);
+    if (rc == SE_TILED_NOT_TAKEN && (a.flags & SE_IN_PLANAR3)) return SE_ERR_BAD_ARG;   // cannot happen behind the unit-budget batch slices
+    return rc;
 }
