@@ -36,8 +36,8 @@ extern "C" {
                                   * triplet-planar [B][ceil(cin/3)][D][D][D][3] (channel c at triplet c/3,
                                   * slot c%3; slots >= cin must be finite) - see se_unproject_gather_planar3_f32 */
 #define SE_IN_OCTET          32  /* se_conv3d_f32, k = 3 shapes with se_conv3d_f32_algo() == 2 only: `in` is octet-planar          */
-#define SE_OUT_OCTET         64  /* [B][C/8][D][D][D][8] (channel c at octet c/8, slot c%8) / `out` is written that way; the skip  */
-                                 /* tensor `residual` is always channels-last                                                   */
+#define SE_OUT_OCTET         64  /* [B][C/8][D][D][D][8] (channel c at octet c/8, slot c%8) / `out` is written that way /          */
+#define SE_RES_OCTET         128 /* the skip tensor `residual` is read that way                                                 */
 
 /* ABI version; bumped on any signature change. */
 int se_abi_version(void);
@@ -135,6 +135,8 @@ int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const float* bpack
 
 /* F.max_pool3d(kernel 2, stride 2) (network/v2v.py:46-52).  in [B][D]^3[C] -> out [B][D/2]^3[C]. */
 int se_maxpool3d_2_f32(const float* in, float* out, int batch, int dim, int channels, void* stream);
+/* Same with an octet-planar input [B][channels/8][dim^3][8] (the output of an SE_OUT_OCTET convolution); out is channels-last. */
+int se_maxpool3d_2_octin_f32(const float* in, float* out, int batch, int dim, int channels, void* stream);
 
 /* 3D soft-argmax.  Replaces op.integrate_tensor_3d_with_coordinates (utils/op.py:83-96).
  *   vol    [rows][voxels] float32 (rows = B*joints, planar logits, already multiplied by volume_multiplier)

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -22,6 +22,7 @@ EPI_RES_POST_RELU = 4
 EPI_OUT_PLANAR = 8
 IN_OCTET = 32       # se_conv3d_f32, 2-D Winograd 3x3x3 shapes: octet-planar input [B][C/8][D][D][D][8]
 OUT_OCTET = 64      # ... octet-planar output
+RES_OCTET = 128     # ... octet-planar skip tensor
 IN_PLANAR3 = 16     # se_conv3d_f32, k = 7: triplet-planar input [B][ceil(cin/3)][D][D][D][3]
 
 _vp, _i, _f, _d, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong
@@ -43,6 +44,7 @@ SIGNATURES = {
     "se_pointwise_chain3_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "se_deconv3d_k2s2_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_maxpool3d_2_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "se_maxpool3d_2_octin_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "se_softargmax3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "se_softargmax3d_scratch_elems": (_ll, [_i]),
     "se_conv3d_pack_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -348,9 +350,12 @@ def deconv3d_k2s2(inp, wpack, bpack, residual, out, batch, dim, cin, cout, flags
                   cin, cout, flags, _stream()), "se_deconv3d_k2s2")
 
 
-def maxpool3d_2(inp, out, batch, dim, channels):
+def maxpool3d_2(inp, out, batch, dim, channels, in_octet=False):
     require_hip(inp, out)
     fn = load().se_maxpool3d_2_bf16 if inp.dtype == torch.bfloat16 else load().se_maxpool3d_2_f32
+    if in_octet:
+        assert inp.dtype == torch.float32
+        fn = load().se_maxpool3d_2_octin_f32
     assert out.dtype == inp.dtype
     with _timed(("maxpool" + _tag(inp), 2, channels, channels, dim)):
         _check(fn(_ptr(inp), _ptr(out), batch, dim, channels, _stream()), "se_maxpool3d_2")

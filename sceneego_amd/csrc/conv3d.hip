@@ -527,6 +527,31 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__
     *reinterpret_cast<f32x4*>(out + t * 4) = m;
 }
 
+// same, octet-planar input [B][C/8][id^3][8]: thread = (voxel, channel quad); the two quads of an octet are adjacent threads, so a
+// wave reads 32 contiguous bytes per input voxel and octet and still writes 16-byte channels-last pieces
+__global__ __launch_bounds__(256) void maxpool2_octin_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             long long total /* B*od^3*cq */, int od, int cq) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int q = (int)(t % cq);
+    long long r = t / cq;
+    const int x = (int)(r % od); r /= od;
+    const int y = (int)(r % od); r /= od;
+    const int z = (int)(r % od); r /= od;
+    const long long b = r;
+    const int id = od * 2;
+    const long long vox = (long long)id * id * id;
+    const float* p = in + ((b * (cq >> 1) + (q >> 1)) * vox + ((long long)(2 * z) * id + 2 * y) * id + 2 * x) * 8 + (q & 1) * 4;
+    f32x4 m = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const long long off = (((long long)(k >> 2) * id + ((k >> 1) & 1)) * id + (k & 1)) * 8;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + off);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+    *reinterpret_cast<f32x4*>(out + t * 4) = m;
+}
+
 template <int KS>
 int launch_direct(const ConvArgs& a, hipStream_t s) {
     // cout tiles per workgroup: 2 when the layer has an even number of 16-wide cout tiles
@@ -543,7 +568,7 @@ int launch_direct(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int se_abi_version(void) { return 6; }
+extern "C" int se_abi_version(void) { return 7; }
 
 // Mirrors the dispatch of se_conv3d_f32 -> se_conv3d_tiled_try -> se_conv3d_wino_try / se_conv3d_k7_wino_try for the
 // default channels-last call (no SE_EPI_OUT_PLANAR / SE_EPI_RES_POST_RELU flags).
@@ -635,10 +660,10 @@ extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* b
     if (ksize == 3 && (cout % 32)) a.wpack_b = nullptr;
     if (ksize == 1) a.wpack_b = nullptr;
     if ((flags & SE_IN_PLANAR3) && ksize != 7) return SE_ERR_BAD_ARG;
-    if ((flags & (SE_IN_OCTET | SE_OUT_OCTET)) && se_conv3d_f32_algo(dim, cin, cout, ksize) != 2) return SE_ERR_BAD_ARG;
+    if ((flags & (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET)) && se_conv3d_f32_algo(dim, cin, cout, ksize) != 2) return SE_ERR_BAD_ARG;
     const int took = se_conv3d_tiled_try(a, batch, ksize, s);
     if (took != SE_TILED_NOT_TAKEN) return took;
-    if (flags & (SE_IN_OCTET | SE_OUT_OCTET)) return SE_ERR_BAD_ARG;   // only the 2-D Winograd kernel knows the octet-planar forms
+    if (flags & (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET)) return SE_ERR_BAD_ARG;   // only the 2-D Winograd kernel knows the octet-planar forms
     if (flags & SE_IN_PLANAR3) return SE_ERR_BAD_ARG;
     // small volumes with wide channels: split the taps over grid.z when the plain launch would not fill the chip
     if (ksize == 3 && !planar && a.nts % 2 == 0 && a.total_vox >= 2048 && a.total_vox <= 8192 && g_variant_direct != 1) {
@@ -710,6 +735,16 @@ extern "C" int se_pointwise_chain3_f32(const float* in, const float* wpack1, con
     const unsigned grid = (unsigned)((tiles + 3) / 4 < 8192 ? (tiles + 3) / 4 : 8192);
     hipLaunchKernelGGL(pointwise_chain3_kernel, dim3(grid), dim3(256), 0, se_stream(stream), in, wpack1, bpack1, wpack2, bpack2,
                        wpack3, bpack3, out, total, vox_per_b, cout3);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int se_maxpool3d_2_octin_f32(const float* in, float* out, int batch, int dim, int channels, void* stream) {
+    if (batch <= 0 || dim <= 0 || (dim & 1) || channels <= 0 || (channels & 7)) return SE_ERR_BAD_ARG;
+    const int od = dim / 2, cq = channels / 4;
+    const long long total = (long long)batch * od * od * od * cq;
+    hipLaunchKernelGGL(maxpool2_octin_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, se_stream(stream), in, out,
+                       total, od, cq);
     SE_CHECK_LAUNCH();
     return 0;
 }

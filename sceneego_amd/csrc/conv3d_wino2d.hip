@@ -71,14 +71,15 @@ struct Unit {
 
 // EXP: timing experiments of development builds (0 = the real kernel; bit 0: compact input addresses, bit 1: no weight stream,
 // bit 2: no epilogue memory traffic - all three give wrong results and exist only to attribute time)
-// LAYOUT: bit 0 = input is octet-planar [B][cin/8][D][D][D][8] (SE_IN_OCTET), bit 1 = output is octet-planar (SE_OUT_OCTET).
+// LAYOUT: bit 0 = input is octet-planar [B][cin/8][D][D][D][8] (SE_IN_OCTET), bit 1 = output is octet-planar (SE_OUT_OCTET),
+// bit 2 = the skip tensor is octet-planar (SE_RES_OCTET).
 // In the octet-planar form an 8-channel chunk of a halo row is ONE contiguous run (18 positions x 32 B) instead of 18 pieces of
 // 32 B at a 4*cin-byte stride: 4x fewer cache lines per load instruction.
 template <int EXP, int LAYOUT>
 __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const float* __restrict__ wg, int tiles_x, int tiles_y,
                                                                int tiles_z, int total_tiles, int n_units, int units_per_wg, unsigned long long* dbg) {
     constexpr int exp = EXP;
-    constexpr bool in_oct = LAYOUT & 1, out_oct = LAYOUT & 2;
+    constexpr bool in_oct = LAYOUT & 1, out_oct = LAYOUT & 2, res_oct = LAYOUT & 4;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, t8 = 0, st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5; (void)t6; (void)t7; (void)t8; (void)st; (void)dbg;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -262,19 +263,21 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         const long long s00 = (((((long long)u.b * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * a.cout + u.cb * 32 + ct * 16);
         const int voff_cl = px * a.cout + 4 * h;
         const int ystride_cl = dim * a.cout, zstride_cl = dim * dim * a.cout;
-        const float* rb = a.res + s00;
         // octet-planar output: octet (cb*4 + ct*2 + h/2), 16 bytes at (h & 1) * 4 inside the 8-channel record of voxel (z, y, x)
         const long long s00o = (((((long long)u.b * (a.cout >> 3) + u.cb * 4 + ct * 2) * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * 8;
-        const int voff = out_oct ? (h >> 1) * dim * dim * dim * 8 + px * 8 + (h & 1) * 4 : voff_cl;
+        const int voff = out_oct ? (h >> 1) * dim * dim * dim * 8 + px * 8 + (h & 1) * 4 : voff_cl;   // (a.cout == channels of out and of the skip tensor)
         const int ystride = out_oct ? dim * 8 : ystride_cl, zstride = out_oct ? dim * dim * 8 : zstride_cl;
+        const int voff_o = (h >> 1) * dim * dim * dim * 8 + px * 8 + (h & 1) * 4;
         float* ob = a.out + (out_oct ? s00o : s00);
+        const float* rb = a.res + (res_oct ? s00o : s00);
+        const int rvoff = res_oct ? voff_o : voff_cl, rystride = res_oct ? dim * 8 : ystride_cl, rzstride = res_oct ? dim * dim * 8 : zstride_cl;
         const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + co);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             f32x4 resv[4];
             if (use_res && !(exp & 4)) {
 #pragma unroll
-                for (int z = 0; z < 4; ++z) resv[z] = *reinterpret_cast<const f32x4*>(rb + z * zstride_cl + r * ystride_cl + voff_cl);
+                for (int z = 0; z < 4; ++z) resv[z] = *reinterpret_cast<const f32x4*>(rb + z * rzstride + r * rystride + rvoff);
             }
             if constexpr ((exp & 128) != 0) {
 #pragma unroll
@@ -556,7 +559,7 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3((unsigned)((n_units + per - 1) / per)), dim3(512), W2_LDS_BYTES, s, a, a.wpack_g, tx, ty, \
                            tz, (int)total_tiles, (int)n_units, per, dbg);                                                       \
     } while (0)
-    const int layout = ((a.flags & SE_IN_OCTET) ? 1 : 0) | ((a.flags & SE_OUT_OCTET) ? 2 : 0);
+    const int layout = ((a.flags & SE_IN_OCTET) ? 1 : 0) | ((a.flags & SE_OUT_OCTET) ? 2 : 0) | ((a.flags & SE_RES_OCTET) && a.res ? 4 : 0);
 #ifdef SE_DEVTOOLS
     if (layout == 0 && g_variant >= 41) {
         switch (g_variant) {
@@ -577,6 +580,10 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
         case 1: W2_LAUNCH(0, 1); break;
         case 2: W2_LAUNCH(0, 2); break;
         case 3: W2_LAUNCH(0, 3); break;
+        case 4: W2_LAUNCH(0, 4); break;
+        case 5: W2_LAUNCH(0, 5); break;
+        case 6: W2_LAUNCH(0, 6); break;
+        case 7: W2_LAUNCH(0, 7); break;
         default: W2_LAUNCH(0, 0); break;
     }
 #undef W2_LAUNCH

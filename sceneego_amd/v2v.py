@@ -226,20 +226,35 @@ class V2VProgram:
         _lib.conv3d(x, pc.w, pc.b, residual, out, B, dim, pc.cin, pc.cin_pad, pc.cout, pc.k, flags, self.workspace)
         return out
 
-    def _res(self, x, blk, B, dim):
-        """Res3DBlock (v2v.py:40-43): relu(bn(conv(relu(bn(conv(x))))) + skip(x))."""
-        c1, c2, sk = blk
-        # the tensor between the two 3x3x3 convolutions of a block has exactly one producer and one consumer: when both run on
-        # the 2-D Winograd kernel it is kept octet-planar [B][C/8][D][D][D][8] (4x fewer cache lines per halo load of the reader)
-        oct_mid = (self.dtype == torch.float32 and _lib.conv3d_algo(dim, c1.cin_pad, c1.cout, 3) == 2
-                   and _lib.conv3d_algo(dim, c2.cin_pad, c2.cout, 3) == 2)
-        a = self._conv(x, c1, B, dim, _lib.EPI_RELU | (_lib.OUT_OCTET if oct_mid else 0))
-        s = x if sk is None else self._conv(x, sk, B, dim, 0)
-        return self._conv(a, c2, B, dim, _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | (_lib.IN_OCTET if oct_mid else 0), residual=s)
+    def _res(self, x, blk, B, dim, x_oct=False, out_oct=False):
+        """Res3DBlock (v2v.py:40-43): relu(bn(conv(relu(bn(conv(x))))) + skip(x)).
 
-    def _pool(self, x, B, dim, c):
+        Layouts (float32 program, blocks whose two 3x3x3 convolutions run on the 2-D Winograd kernel): the tensor between the two
+        convolutions is always octet-planar [B][C/8][D][D][D][8]; ``x_oct`` says the block input is, ``out_oct`` asks for an
+        octet-planar block output (4x fewer cache lines per halo load of the reader; see run() for who reads what)."""
+        c1, c2, sk = blk
+        w2d = (self.dtype == torch.float32 and _lib.conv3d_algo(dim, c1.cin_pad, c1.cout, 3) == 2
+               and _lib.conv3d_algo(dim, c2.cin_pad, c2.cout, 3) == 2)
+        assert w2d or not (x_oct or out_oct)
+        assert sk is None or not x_oct           # the 1x1x1 skip convolution reads channels-last
+        mid = _lib.OUT_OCTET if w2d else 0
+        a = self._conv(x, c1, B, dim, _lib.EPI_RELU | mid | (_lib.IN_OCTET if x_oct else 0))
+        s = x if sk is None else self._conv(x, sk, B, dim, 0)
+        f2 = _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | (_lib.IN_OCTET if w2d else 0)
+        if x_oct and sk is None:
+            f2 |= _lib.RES_OCTET
+        if out_oct:
+            f2 |= _lib.OUT_OCTET
+        return self._conv(a, c2, B, dim, f2, residual=s)
+
+    def _oct_ok(self, blk, dim):
+        c1, c2, _ = blk
+        return (self.dtype == torch.float32 and _lib.conv3d_algo(dim, c1.cin_pad, c1.cout, 3) == 2
+                and _lib.conv3d_algo(dim, c2.cin_pad, c2.cout, 3) == 2)
+
+    def _pool(self, x, B, dim, c, x_oct=False):
         out = self._new(B, dim // 2, c)
-        _lib.maxpool3d_2(x, out, B, dim, c)
+        _lib.maxpool3d_2(x, out, B, dim, c, in_octet=x_oct)
         return out
 
     def _up(self, x, pc, skip, B, dim):
@@ -262,16 +277,26 @@ class V2VProgram:
         if G % 32:
             raise ValueError("volume_size must be a multiple of 32 (five 2x max-pools), got %d" % G)
         x = self._conv(x, self.front0, B, G, _lib.EPI_RELU | (_lib.IN_PLANAR3 if planar3 else 0))
-        for blk in self.front_res:
-            x = self._res(x, blk, B, G)
+        # Tensor layouts of the float32 program: a Res3DBlock output that is read only by 2-D Winograd convolutions (as input or as
+        # skip tensor) and by a max-pool is kept octet-planar; what the deconvolutions, the 1x1x1 convolutions and the fused tail
+        # read stays channels-last.  x_oct tracks the layout of the running tensor.
+        x_oct = False
+        for i, blk in enumerate(self.front_res):
+            ok = self._oct_ok(blk, G)
+            x = self._res(x, blk, B, G, x_oct=x_oct, out_oct=ok)
+            x_oct = ok
         # encoder (v2v.py:104-119)
         skips = []
         dim = G
         for k in range(5):
-            skips.append(self._res(x, self.skip[k], B, dim))
-            x = self._pool(x, B, dim, x.shape[-1])
+            skips.append(self._res(x, self.skip[k], B, dim, x_oct=x_oct, out_oct=False))    # read by the decoder's deconvolution
+            x = self._pool(x, B, dim, x.numel() // (B * dim ** 3), x_oct=x_oct)
             dim //= 2
-            x = self._res(x, self.enc[k], B, dim)
+            ok = self._oct_ok(self.enc[k], dim)
+            x = self._res(x, self.enc[k], B, dim, x_oct=False, out_oct=ok)
+            x_oct = ok
+        if x_oct:    # cannot happen: the deepest levels are too small for the 2-D kernel
+            raise RuntimeError("octet-planar tensor reached the middle block")
         x = self._res(x, self.mid, B, dim)
         # decoder (v2v.py:121-137)
         for k in range(4, -1, -1):

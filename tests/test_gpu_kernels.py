@@ -494,6 +494,18 @@ def test_conv3d_octet_planar_forms_match_channels_last(B, dim, cin, cout):
     assert torch.equal(out_oct.permute(0, 2, 3, 4, 1, 5).reshape(B, dim, dim, dim, cout), ref)
     _lib.conv3d(x_oct, pc.w, pc.b, res, out_oct, B, dim, cin, cin, cout, 3, flags | _lib.IN_OCTET | _lib.OUT_OCTET)
     assert torch.equal(out_oct.permute(0, 2, 3, 4, 1, 5).reshape(B, dim, dim, dim, cout), ref)
+    if cin == cout:     # octet-planar skip tensor (SE_RES_OCTET): the block input doubles as skip tensor in Res3DBlock
+        res_oct = res.view(B, dim, dim, dim, cout // 8, 8).permute(0, 4, 1, 2, 3, 5).contiguous()
+        _lib.conv3d(x_oct, pc.w, pc.b, res_oct, out_oct, B, dim, cin, cin, cout, 3, flags | _lib.IN_OCTET | _lib.OUT_OCTET | _lib.RES_OCTET)
+        assert torch.equal(out_oct.permute(0, 2, 3, 4, 1, 5).reshape(B, dim, dim, dim, cout), ref)
+        _lib.conv3d(x, pc.w, pc.b, res_oct, out, B, dim, cin, cin, cout, 3, flags | _lib.RES_OCTET)
+        assert torch.equal(out, ref)
+    # max-pool with octet-planar input == max-pool of the channels-last tensor
+    p_ref = torch.empty(B, dim // 2, dim // 2, dim // 2, cin, device=DEV)
+    p_oct = torch.empty_like(p_ref)
+    _lib.maxpool3d_2(x, p_ref, B, dim, cin)
+    _lib.maxpool3d_2(x_oct, p_oct, B, dim, cin, in_octet=True)
+    assert torch.equal(p_ref, p_oct)
     # shapes the 2-D kernel does not take refuse the flags
     small = torch.randn(1, 8, 8, 8, cin, device=DEV)
     with pytest.raises(_lib.HipExtensionError):
