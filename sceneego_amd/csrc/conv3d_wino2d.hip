@@ -256,8 +256,23 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     const bool use_res = (a.flags & SE_EPI_RES_PRE_RELU) && a.res;
 
     // output transform (A^T along y, then along z), bias, residual, ReLU, 8 x 16-byte channels-last stores
-    auto epilogue = [&](const Unit& u) {
+    // skip tensor + bias of a finished tile, issued at the top of the staging phase so that their latency overlaps the V-tile
+    // transform (the loads used to sit inside the epilogue: ~2 k exposed cycles per tile)
+    auto epi_prefetch = [&](const Unit& u, f32x4 (&resv)[2][4], f32x4& bias) {
         const int co = u.cb * 32 + ct * 16 + 4 * h;
+        bias = *reinterpret_cast<const f32x4*>(a.bpack + co);
+        if (!use_res || (exp & 4)) return;
+        const long long s00 = (((((long long)u.b * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * a.cout + u.cb * 32 + ct * 16);
+        const long long s00o = (((((long long)u.b * (a.cout >> 3) + u.cb * 4 + ct * 2) * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * 8;
+        const float* rb = a.res + (res_oct ? s00o : s00);
+        const int rvoff = res_oct ? (h >> 1) * dim * dim * dim * 8 + px * 8 + (h & 1) * 4 : px * a.cout + 4 * h;
+        const int rystride = res_oct ? dim * 8 : dim * a.cout, rzstride = res_oct ? dim * dim * 8 : dim * dim * a.cout;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int z = 0; z < 4; ++z) resv[r][z] = *reinterpret_cast<const f32x4*>(rb + z * rzstride + r * rystride + rvoff);
+    };
+    auto epilogue = [&](const Unit& u, const f32x4 (&resv_all)[2][4], const f32x4 bias) {
         // uniform 64-bit base of the wave's first output row + a 32-bit per-lane offset (global_* saddr form); raw buffer
         // STORES with a scalar offset dropped data here, so stores and skip loads use plain global accesses
         const long long s00 = (((((long long)u.b * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * a.cout + u.cb * 32 + ct * 16);
@@ -267,18 +282,10 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         const long long s00o = (((((long long)u.b * (a.cout >> 3) + u.cb * 4 + ct * 2) * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * 8;
         const int voff = out_oct ? (h >> 1) * dim * dim * dim * 8 + px * 8 + (h & 1) * 4 : voff_cl;   // (a.cout == channels of out and of the skip tensor)
         const int ystride = out_oct ? dim * 8 : ystride_cl, zstride = out_oct ? dim * dim * 8 : zstride_cl;
-        const int voff_o = (h >> 1) * dim * dim * dim * 8 + px * 8 + (h & 1) * 4;
         float* ob = a.out + (out_oct ? s00o : s00);
-        const float* rb = a.res + (res_oct ? s00o : s00);
-        const int rvoff = res_oct ? voff_o : voff_cl, rystride = res_oct ? dim * 8 : ystride_cl, rzstride = res_oct ? dim * dim * 8 : zstride_cl;
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + co);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            f32x4 resv[4];
-            if (use_res && !(exp & 4)) {
-#pragma unroll
-                for (int z = 0; z < 4; ++z) resv[z] = *reinterpret_cast<const f32x4*>(rb + z * rzstride + r * rystride + rvoff);
-            }
+            const f32x4 (&resv)[4] = resv_all[r];
             if constexpr ((exp & 128) != 0) {
 #pragma unroll
                 for (int z = 0; z < 4; ++z) *reinterpret_cast<f32x4*>(ob + z * zstride + r * ystride + voff) = acc[r * 12 + z];
@@ -427,6 +434,8 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         // ------------------------------ staging phase ------------------------------
         // `raw` / `wreg` hold the input rows and the weight half of step i+1, loaded during the MFMA phase.
         const bool epi = ccur == chunks - 1;
+        f32x4 resv[2][4], bias;
+        if (epi) epi_prefetch(ucur, resv, bias);
         if (G == 1) {
             // group 1 owns weight half 1: written in the first half of its staging phase (group 0 reads it behind the mid-phase
             // barrier; group 1 itself finished with half 1 of step i before the barrier above)
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
 #endif
             barrier();                                            // mid-phase barrier
             W2_T(t6)
-            if (epi) epilogue(ucur);
+            if (epi) epilogue(ucur, resv, bias);
         } else {
             // group 0 owns weight half 0: written in the second half (group 1 reads half 0 of step i in the first half)
             commit(raw);
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
             W2_T(ta)
             st[11] += ta - t4;
 #endif
-            if (epi) epilogue(ucur);
+            if (epi) epilogue(ucur, resv, bias);
             W2_T(t5)
 #ifdef SE_STAMP2D
             st[12] += t5 - ta;
@@ -541,6 +550,8 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
     const int dim = a.dim;
     if (!a.wpack_g || dim < 16 || (dim & 15) || (a.cout & 31) || (a.cin & 7) || a.cin_pad != a.cin) return SE_TILED_NOT_TAKEN;
     if (a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR)) return SE_TILED_NOT_TAKEN;
+    // 32-bit byte offsets inside ONE sample (buffer descriptor per sample; bit 31 of the offset marks out-of-volume lanes)
+    if ((long long)dim * dim * dim * (a.cin > a.cout ? a.cin : a.cout) * 4 >= (1LL << 31)) return SE_TILED_NOT_TAKEN;
     const int tx = dim / 16, ty = dim / 8, tz = dim / 4;
     const long long total_tiles = (long long)batch * tx * ty * tz;
     const long long n_units = total_tiles * (a.cout / 32);
