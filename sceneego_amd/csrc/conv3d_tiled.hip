@@ -660,7 +660,7 @@ int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) 
 
 static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s) {
     const int dim = a.dim;
-    if (ksize == 3 && (g_variant == 0 || (g_variant >= 40 && g_variant < 50))) {   // production: 2-D Winograd F(4,3) x F(2,3), register accumulators
+    if (ksize == 3 && (g_variant == 0 || (g_variant >= 40 && g_variant < 70))) {   // production: 2-D Winograd F(4,3) x F(2,3), register accumulators
         const int rc = se_conv3d_wino2d_try(a, batch, s);
         if (rc != SE_TILED_NOT_TAKEN) return rc;
     }

@@ -59,7 +59,8 @@ __device__ __forceinline__ int v_rec_offset(int xx, int p) { return xx * W2_VREC
 
 // cycle stamps of the phase structure (diagnostic builds: build.sh --devtools -DSE_STAMP2D, tools/stamp_w2d.py)
 #ifdef SE_STAMP2D
-#define W2_T(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+// 32-bit stamps (low word of s_memtime) and 32-bit sums: the phase structure lives in scalar registers and 64-bit stamps spill them
+#define W2_T(var) { unsigned long long w2_t64; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w2_t64)::"memory"); var = (unsigned)w2_t64; __builtin_amdgcn_sched_barrier(0); }
 unsigned long long* g_w2d_dbg = nullptr;
 #else
 #define W2_T(var)
@@ -68,6 +69,34 @@ unsigned long long* g_w2d_dbg = nullptr;
 struct Unit {
     int cb, b, z0, y0, x0;
 };
+
+// Rider schedule of the MFMA phase (see mfma_phase): which of the 18 groups of 8 MFMAs of group GG's phase carries
+//   the loads of weight set k (3 x 16 B per thread)  /  its LDS writes, at least three groups (768 cycles) later, at most two sets
+//   in registers at a time, all writes of group 0 in front of the mid-phase barrier (group 7), all of group 1 behind it;
+//   the input-row load j of the next step (12 per phase), thinned out where weight sets are in flight.
+constexpr int W2_WLOAD[2][3] = {{0, 2, 3}, {6, 8, 10}};
+constexpr int W2_WWRITE[2][3] = {{3, 5, 6}, {9, 11, 13}};
+// Loads return in order, so a weight load (L2 hit) issued behind an input-row load (HBM) of the same wave is delivered only after
+// that row: group 0 issues its rows behind its last weight load; group 1, whose weight window lies in the second half of the
+// phase, keeps its row loads at the end of its staging phase (-1: not carried).
+// Group 0's rows go out two per group right behind its weight loads: the V-tile transform needs them as soon as the phase ends,
+// and a row takes ~2 k cycles from HBM.
+constexpr int W2_RAWG[2][12] = {{4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9}, {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}};
+constexpr int rider_w_load(int gg, int g) {
+    for (int k = 0; k < 3; ++k)
+        if (W2_WLOAD[gg][k] == g) return k;
+    return -1;
+}
+constexpr int rider_w_write(int gg, int g) {
+    for (int k = 0; k < 3; ++k)
+        if (W2_WWRITE[gg][k] == g) return k;
+    return -1;
+}
+constexpr int rider_raw_count(int gg, int g) {
+    int n = 0;
+    for (int j = 0; j < 12; ++j) n += W2_RAWG[gg][j] == g;
+    return n;
+}
 
 // EXP: timing experiments of development builds (0 = the real kernel; bit 0: compact input addresses, bit 1: no weight stream,
 // bit 2: no epilogue memory traffic - all three give wrong results and exist only to attribute time)
@@ -80,7 +109,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
                                                                int tiles_z, int total_tiles, int n_units, int units_per_wg, unsigned long long* dbg) {
     constexpr int exp = EXP;
     constexpr bool in_oct = LAYOUT & 1, out_oct = LAYOUT & 2, res_oct = LAYOUT & 4;
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, t8 = 0, st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, t8 = 0, st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5; (void)t6; (void)t7; (void)t8; (void)st; (void)dbg;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;
@@ -169,29 +198,40 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     // positions outside the volume get voffset bit 31 set, which is out of range and reads zero - no branches.
     const unsigned in_bytes = (unsigned)dim * dim * dim * cin * 4u;
     constexpr unsigned OOB = 0x80000000u;
-    auto fetch = [&](f32x2 (&raw)[6][2], const Unit& u, int chunk) {
-        const float* p0 = a.in + (long long)u.b * dim * dim * dim * cin;
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p0), 0, (int)in_bytes, 0x00020000);
+    // Every vector instruction of a staging wave costs ~25 cycles next to the partner wave's float32 MFMA stream (stamps,
+    // DESIGN.md section 4), so the per-chunk part of the address lives in SCALAR registers: the per-lane offsets of the two
+    // rows are computed once per unit (fetch_setup), the chunk and the z slab go into the scalar offset, and a slab outside
+    // the volume is read through a descriptor of zero records (all lanes out of range) instead of masking lanes.
+    unsigned fvoff[2] = {OOB, OOB};
+    auto fetch_setup = [&](const Unit& u) {
         const int gx = u.x0 - 1 + sxx;
         const bool okx = s_on && (unsigned)gx < (unsigned)dim;
         const int gy0 = u.y0 + G * 4 - 1 + 2 * sk;
-        const int gz0 = u.z0 - 1;
-        unsigned voff[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int gy = gy0 + r;
-            voff[r] = (okx && (unsigned)gy < (unsigned)dim) ? (unsigned)(((gy * dim + gx) * ((in_oct || (exp & 1)) ? 8 : cin) + ((in_oct || (exp & 1)) ? 0 : chunk * 8) + sp * 2) * 4) : OOB;
+            fvoff[r] = (okx && (unsigned)gy < (unsigned)dim) ? (unsigned)(((gy * dim + gx) * ((in_oct || (exp & 1)) ? 8 : cin) + sp * 2) * 4) : OOB;
         }
-#pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            const int gz = gz0 + s;
-            const bool okz = (unsigned)gz < (unsigned)dim;       // uniform
-            const unsigned zmask = okz ? 0u : OOB;
-            const int soff = okz ? (in_oct ? (chunk * dim + gz) * dim * dim * 32 : gz * dim * dim * ((exp & 1) ? 8 : cin) * 4) : 0;
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-                raw[s][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(voff[r] | zmask), soff, 0));
+    };
+    auto fetch_one = [&](f32x2 (&raw)[6][2], const Unit& u, int chunk, auto s_tag, auto r_tag) {
+        constexpr int s = decltype(s_tag)::value, r = decltype(r_tag)::value;
+        const float* p0 = a.in + (long long)u.b * dim * dim * dim * cin;
+        const int gz = u.z0 - 1 + s;
+        const bool okz = (unsigned)gz < (unsigned)dim;       // uniform
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p0), 0, okz ? (int)in_bytes : 0, 0x00020000);
+        // (a slab outside the volume is read through the zero-record descriptor: its scalar offset is never used for an access)
+        const int soff = in_oct ? (chunk * dim + gz) * dim * dim * 32 : gz * dim * dim * ((exp & 1) ? 8 : cin) * 4 + ((exp & 1) ? 0 : chunk * 32);
+        if constexpr ((exp & 0x10000) != 0) {
+            raw[s][r] = (f32x2){__builtin_bit_cast(float, fvoff[r]), __builtin_bit_cast(float, soff)};
+        } else {
+            raw[s][r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)fvoff[r], soff, 0));
         }
+    };
+    auto fetch = [&](f32x2 (&raw)[6][2], const Unit& u, int chunk) {       // all twelve at once (prologue)
+        for_each_idx([&](auto j_tag) {
+            constexpr int jj = decltype(j_tag)::value;
+            fetch_one(raw, u, chunk, std::integral_constant<int, jj / 2>{}, std::integral_constant<int, jj % 2>{});
+        }, std::make_integer_sequence<int, 12>{});
     };
     // B^T along z (F(4,3), points 0, +-1, +-2, inf) on the lane's two rows, then along y (F(2,3)) with the neighbour lanes' rows;
     // commit to the group's V buffer.
@@ -228,40 +268,55 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
                 rs[c] = ta - lb;          // xi_y = 2
                 rs[2 + c] = lb - tb;      // xi_y = 3
             }
-            *reinterpret_cast<f32x4*>(v_pq + z * 32) = pq;
-            *reinterpret_cast<f32x4*>(v_rs + z * 32) = rs;
+            if constexpr ((exp & 0x8000) != 0) {
+                asm volatile("" ::"v"(pq), "v"(rs));
+            } else {
+                *reinterpret_cast<f32x4*>(v_pq + z * 32) = pq;
+                *reinterpret_cast<f32x4*>(v_rs + z * 32) = rs;
+            }
         }
     };
 
-    // weight stream: one half chunk (36,864 B = 9 x 16 B per thread of a group), global (L2) -> registers -> LDS.  Plain loads,
-    // not LDS-DMA: an L2-hit load returns in a few hundred cycles, a DMA piece lands ~1 us after issue (MI355X_MICROARCH.md,
-    // ldsdma-fill) and the refill window of a half is half a phase.
-    auto w_fetch = [&](f32x4 (&wreg)[9], const Unit& u, int chunk, int half) {
+    // weight stream: one half chunk (36,864 B = 9 x 16 B per thread of a group), global (L2) -> registers -> LDS, in pieces of
+    // 3 x 16 B per thread.  Plain loads, not LDS-DMA: an L2-hit load returns in a few hundred cycles, a DMA piece lands ~1 us after
+    // issue (MI355X_MICROARCH.md, ldsdma-fill) and the refill window of a half is half a phase.
+    auto w_fetch3 = [&](f32x4 (&wreg)[9], const Unit& u, int chunk, int half, auto k0_tag) {
+        constexpr int k0 = decltype(k0_tag)::value;
         if (exp & 2) return;
         // uniform base in the descriptor, lane offset tg * 16 B, piece offset in the scalar/immediate offset: no address VALU
         const float* src = wg + ((size_t)u.cb * chunks + chunk) * W2_CHUNK_FLOATS + half * W2_HALF_FLOATS;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, W2_HALF_FLOATS * 4, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tg * 16, k * 4096, 0));
+        for (int k = k0; k < k0 + 3; ++k) wreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tg * 16, k * 4096, 0));
     };
-    auto w_commit = [&](const f32x4 (&wreg)[9], int half) {
+    auto w_commit3 = [&](const f32x4 (&wreg)[9], int half, auto k0_tag) {
+        constexpr int k0 = decltype(k0_tag)::value;
         f32x4* dst = reinterpret_cast<f32x4*>(wl + half * W2_HALF_FLOATS);
         if (exp & 2) return;
+        if constexpr ((exp & 0x4000) != 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) dst[tg + k * 256] = wreg[k];
+            for (int k = k0; k < k0 + 3; ++k) asm volatile("" ::"v"(wreg[k]));
+            return;
+        }
+#pragma unroll
+        for (int k = k0; k < k0 + 3; ++k) dst[tg + k * 256] = wreg[k];
     };
 
     f32x4 acc[24];
-    const bool relu = a.flags & SE_EPI_RELU;
+    // ReLU as max(v, 0) / no ReLU as max(v, -inf): one v_max_f32 per element, no per-element select on a run-time flag
+    const float relu_lo = (a.flags & SE_EPI_RELU) ? 0.f : -__builtin_inff();
     const bool use_res = (a.flags & SE_EPI_RES_PRE_RELU) && a.res;
 
     // output transform (A^T along y, then along z), bias, residual, ReLU, 8 x 16-byte channels-last stores
-    // skip tensor + bias of a finished tile, issued at the top of the staging phase so that their latency overlaps the V-tile
-    // transform (the loads used to sit inside the epilogue: ~2 k exposed cycles per tile)
-    auto epi_prefetch = [&](const Unit& u, f32x4 (&resv)[2][4], f32x4& bias) {
-        const int co = u.cb * 32 + ct * 16 + 4 * h;
-        bias = *reinterpret_cast<const f32x4*>(a.bpack + co);
-        if (!use_res || (exp & 4)) return;
+    // skip tensor + bias of a finished tile, issued in front of the staging phase's mid barrier
+    auto epi_prefetch = [&](const Unit& u, f32x4 (&resv)[2][4]) {
+        if (!use_res || (exp & 4)) {          // no skip tensor: add zeros (the epilogue has no per-element selects)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int z = 0; z < 4; ++z) resv[r][z] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            return;
+        }
         const long long s00 = (((((long long)u.b * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * a.cout + u.cb * 32 + ct * 16);
         const long long s00o = (((((long long)u.b * (a.cout >> 3) + u.cb * 4 + ct * 2) * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * 8;
         const float* rb = a.res + (res_oct ? s00o : s00);
@@ -272,7 +327,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
 #pragma unroll
             for (int z = 0; z < 4; ++z) resv[r][z] = *reinterpret_cast<const f32x4*>(rb + z * rzstride + r * rystride + rvoff);
     };
-    auto epilogue = [&](const Unit& u, const f32x4 (&resv_all)[2][4], const f32x4 bias) {
+    auto epilogue = [&](const Unit& u, const f32x4 (&resv_all)[2][4]) {
         // uniform 64-bit base of the wave's first output row + a 32-bit per-lane offset (global_* saddr form); raw buffer
         // STORES with a scalar offset dropped data here, so stores and skip loads use plain global accesses
         const long long s00 = (((((long long)u.b * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * a.cout + u.cb * 32 + ct * 16);
@@ -283,50 +338,44 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         const int voff = out_oct ? (h >> 1) * dim * dim * dim * 8 + px * 8 + (h & 1) * 4 : voff_cl;   // (a.cout == channels of out and of the skip tensor)
         const int ystride = out_oct ? dim * 8 : ystride_cl, zstride = out_oct ? dim * dim * 8 : zstride_cl;
         float* ob = a.out + (out_oct ? s00o : s00);
+        // all eight output vectors first, then the skip tensor (prefetched behind the V-tile transform; its latency also
+        // overlaps this arithmetic), ReLU and the stores
+        f32x4 out[2][4];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const f32x4 (&resv)[4] = resv_all[r];
-            if constexpr ((exp & 128) != 0) {
-#pragma unroll
-                for (int z = 0; z < 4; ++z) *reinterpret_cast<f32x4*>(ob + z * zstride + r * ystride + voff) = acc[r * 12 + z];
-#pragma unroll
-                for (int e = 0; e < 24; ++e) asm volatile("" ::"v"(acc[e]));     // keep every accumulator (and its MFMAs) live
-                continue;
-            }
-            f32x4 out[4];
             if constexpr ((exp & 0x2000) != 0) {       // experiment: packed float32 arithmetic (v_pk_add_f32 / v_pk_fma_f32)
                 f32x4 m[6];
 #pragma unroll
                 for (int z = 0; z < 6; ++z)
                     m[z] = r == 0 ? (acc[z * 4 + 0] + acc[z * 4 + 1]) + acc[z * 4 + 2] : (acc[z * 4 + 1] - acc[z * 4 + 2]) - acc[z * 4 + 3];
                 const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-                out[0] = ((m[0] + s12) + s34) + bias;
-                out[1] = (2.f * d34 + d12) + bias;
-                out[2] = (4.f * s34 + s12) + bias;
-                out[3] = ((8.f * d34 + d12) + m[5]) + bias;
+                out[r][0] = (m[0] + s12) + s34;
+                out[r][1] = 2.f * d34 + d12;
+                out[r][2] = 4.f * s34 + s12;
+                out[r][3] = (8.f * d34 + d12) + m[5];
             } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {      // scalar on purpose, see commit()
-                float m[6];
+                for (int c = 0; c < 4; ++c) {      // scalar on purpose, see commit()
+                    float m[6];
 #pragma unroll
-                for (int z = 0; z < 6; ++z)
-                    m[z] = r == 0 ? (acc[z * 4 + 0][c] + acc[z * 4 + 1][c]) + acc[z * 4 + 2][c] : (acc[z * 4 + 1][c] - acc[z * 4 + 2][c]) - acc[z * 4 + 3][c];
-                const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-                const float b = bias[c];
-                out[0][c] = ((m[0] + s12) + s34) + b;
-                out[1][c] = fmaf(2.f, d34, d12) + b;
-                out[2][c] = fmaf(4.f, s34, s12) + b;
-                out[3][c] = (fmaf(8.f, d34, d12) + m[5]) + b;
+                    for (int z = 0; z < 6; ++z)
+                        m[z] = r == 0 ? (acc[z * 4 + 0][c] + acc[z * 4 + 1][c]) + acc[z * 4 + 2][c] : (acc[z * 4 + 1][c] - acc[z * 4 + 2][c]) - acc[z * 4 + 3][c];
+                    const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+                    out[r][0][c] = (m[0] + s12) + s34;
+                    out[r][1][c] = fmaf(2.f, d34, d12);
+                    out[r][2][c] = fmaf(4.f, s34, s12);
+                    out[r][3][c] = fmaf(8.f, d34, d12) + m[5];
+                }
             }
-            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
 #pragma unroll
             for (int z = 0; z < 4; ++z) {
-                f32x4 v = out[z];
+                f32x4 v = out[r][z];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (use_res && !(exp & 4)) v[c] += resv[z][c];
-                    if (relu) v[c] = fmaxf(v[c], 0.f);
-                }
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c] + resv_all[r][z][c], relu_lo);
                 if (!(exp & 4) || v.x == 12345.f) *reinterpret_cast<f32x4*>(ob + z * zstride + r * ystride + voff) = v;
             }
         }
@@ -334,11 +383,37 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
 
     // Workgroup barrier that waits for this wave's LDS traffic only (lgkmcnt): global loads stay in flight across it (a
     // __syncthreads() also waits for vmcnt(0)).  The "memory" clobber keeps the compiler from moving LDS / global accesses across it.
-    auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // sched_barrier on both sides: register-only arithmetic must not drift across a phase boundary either (hipcc moved half of the
+    // V-tile transform up into the MFMA stream, where it costs the MFMA wave more than it saves the staging wave: 9 % per launch).
+    auto barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
-    // ---- MFMA phase: 18 groups (xi_z, dx) of 4 xi_y x 2 k steps; the workgroup's mid-phase barrier sits in front of the first
-    // access to the second weight half ----
-    auto mfma_phase = [&](auto&& vmem_a, auto&& vmem_b) {
+    // State of the walk: (ucur, ccur) = the step this group computes next, (unx, cnx) = the step after it.
+    Unit ucur = decode(u_begin);
+    int ccur = 0, icur = 0;
+    Unit unx = ucur;
+    int cnx = 0, inx = 0;
+    f32x2 raw[6][2];
+    f32x4 wreg[9];
+    f32x4 bias_next = *reinterpret_cast<const f32x4*>(a.bpack + ucur.cb * 32 + ct * 16 + 4 * h);   // bias of the tile whose first MFMA phase comes next
+
+    // ---- MFMA phase of group GG: 18 groups (xi_z, dx) of 4 xi_y x 2 k steps; the workgroup's mid-phase barrier sits in front of
+    // the first access to the second weight half.
+    // ALL global loads and the weight stream's LDS writes ride inside this instruction stream, a few per group of 8 MFMAs: beside
+    // an MFMA they are nearly free for the issuing wave, while every instruction of a staging wave costs it 10-25 cycles next to
+    // the partner wave's MFMA stream (stamps) - the staging phase keeps only the transform work.
+    //   * the 12 input-row loads of this group's NEXT step (unx, cnx), one per group of MFMAs;
+    //   * the weight stream.  Half 0 (xi_z < 3) is read in the first half of a phase, half 1 in the second, and group 1 runs one
+    //     phase behind group 0, so (half-phases numbered from group 0's step s: 4s, 4s+1 MFMA, 4s+2, 4s+3 staging)
+    //       half 1 of step s   is read at 4s+1 (group 0) and 4s+3 (group 1) -> written at 4s   = group 0's first  MFMA half,
+    //       half 0 of step s+1 is read at 4s+4 (group 0) and 4s+6 (group 1) -> written at 4s+3 = group 1's second MFMA half,
+    //     each by the MFMA waves of that group themselves, in three sets of 3 x 16 B per thread (schedule: W2_WLOAD / W2_WWRITE).
+    auto mfma_phase = [&](auto gg_tag) {
+        constexpr int GG = decltype(gg_tag)::value;
+        constexpr int WH = GG == 0 ? 1 : 0;      // weight half this group's MFMA waves refill
         // operands of group g live in buffer g % 3 and are fetched two groups (16 MFMAs = 512 cycles) ahead of their use
         f32x4 oa[3][2], ov[3][2];
         auto load_group = [&](auto g_tag) {
@@ -351,22 +426,31 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
                 ov[b][q] = *reinterpret_cast<const f32x4*>(b_dx[dx2] + (xz2 * 2 + q) * 16);
             }
         };
-        load_group(std::integral_constant<int, 0>{});
-        load_group(std::integral_constant<int, 1>{});
+        if constexpr (!(exp & 0x400)) {
+            load_group(std::integral_constant<int, 0>{});
+            load_group(std::integral_constant<int, 1>{});
+        }
         auto group = [&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
             constexpr int xz = g / 3, b = g % 3;
             if constexpr (g == 7) {
                 // the prefetch below (group 9) is the first read of weight half 1; all reads of half 0 have been issued and are
-                // drained by the barrier's lgkmcnt(0), so the staging group may refill half 0 right behind it
+                // drained by the barrier's lgkmcnt(0)
                 W2_T(t1)
                 barrier();
                 W2_T(t2)
             }
+            // riders of this group: LDS writes of a weight set first (frees its registers), then loads
+            constexpr int kw = rider_w_write(GG, g), kl = rider_w_load(GG, g), nraw = rider_raw_count(GG, g);
+            if constexpr (kw >= 0) w_commit3(wreg, WH, std::integral_constant<int, 3 * (kw < 0 ? 0 : kw)>{});
+            if constexpr (kl >= 0) w_fetch3(wreg, GG == 0 ? ucur : unx, GG == 0 ? ccur : cnx, WH, std::integral_constant<int, 3 * (kl < 0 ? 0 : kl)>{});
+            if constexpr (nraw > 0)
+                for_each_idx([&](auto j_tag) {
+                    constexpr int jj = decltype(j_tag)::value;
+                    if constexpr (W2_RAWG[GG][jj] == g) fetch_one(raw, unx, cnx, std::integral_constant<int, jj / 2>{}, std::integral_constant<int, jj % 2>{});
+                }, std::make_integer_sequence<int, 12>{});
+            if constexpr ((exp & 0x400) != 0) return;      // attribution: no MFMA stream at all
             if constexpr (g + 2 < 18) load_group(std::integral_constant<int, g + 2>{});
-            // this wave's weight-half loads for its NEXT step ride inside its own MFMA stream
-            if constexpr (g == 1) vmem_a();
-            if constexpr (g == 9) vmem_b();
             // xi_y = 2q + e: operand components (x, y) = channels of e = 0, (z, w) = channels of e = 1; first channel of all four
             // xi_y, then the second (dependent MFMAs on one accumulator stay 4 apart)
             acc[xz * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][0].x, ov[b][0].x, acc[xz * 4 + 0], 0, 0, 0);
@@ -377,103 +461,89 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
             acc[xz * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][0].w, ov[b][0].w, acc[xz * 4 + 1], 0, 0, 0);
             acc[xz * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][1].y, ov[b][1].y, acc[xz * 4 + 2], 0, 0, 0);
             acc[xz * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][1].w, ov[b][1].w, acc[xz * 4 + 3], 0, 0, 0);
-            if constexpr (g + 2 < 18) {
+            // issue order inside the group: per pair of MFMAs one operand read, then one of the riders (global load / LDS write)
+            constexpr int n_vm = ((exp & 2) ? 0 : (kl >= 0 ? 3 : 0)) + ((exp & 0x10000) ? 0 : nraw);
+            constexpr int n_dw = (kw >= 0 && !(exp & 2) && !(exp & 0x4000)) ? 3 : 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                }
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (g + 2 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (e < n_vm) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (e < n_dw) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
         };
         for_each_idx(group, std::make_integer_sequence<int, 18>{});
     };
 
-    // ---- prologue: weights of step 0 (group G stages half G), each group's V tile of step 0 ----
-    Unit ucur = decode(u_begin);      // (unit, chunk) of the step this group computes next
-    int ccur = 0, icur = 0;
-    Unit unx = ucur;                  // (unit, chunk) of the step after it
-    int cnx = 0, inx = 0;
-    f32x2 raw[6][2];
-    f32x4 wreg[9];
-    w_fetch(wreg, ucur, 0, G);
+    // ---- prologue: each group's V tile of step 0; weight half 0 of step 0 (by group 1's threads - half 1 of step 0 is written by
+    // group 0 inside its first MFMA phase) ----
+    fetch_setup(ucur);
     fetch(raw, ucur, 0);
+    if (G == 1) {
+        w_fetch3(wreg, ucur, 0, 0, std::integral_constant<int, 0>{});
+        w_fetch3(wreg, ucur, 0, 0, std::integral_constant<int, 3>{});
+        w_fetch3(wreg, ucur, 0, 0, std::integral_constant<int, 6>{});
+    }
     commit(raw);
-    w_commit(wreg, G);
+    if (G == 1) {
+        w_commit3(wreg, 0, std::integral_constant<int, 0>{});
+        w_commit3(wreg, 0, std::integral_constant<int, 3>{});
+        w_commit3(wreg, 0, std::integral_constant<int, 6>{});
+    }
     step_after(unx, cnx, inx);
-    if constexpr ((exp & 0x800) != 0) w_fetch(wreg, unx, cnx, G);
-    if constexpr (!(exp & 0x1000)) fetch(raw, unx, cnx);
+    if (cnx == 0) fetch_setup(unx);
+    if (G == 1) fetch(raw, unx, cnx);
     if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(2);
     barrier();
-    if (G == 1) {                     // group 1 runs one phase behind group 0
+
+    // The main loop exists once per group (its MFMA phase differs): one uniform branch in front of the loops instead of one inside
+    // every iteration (a join inside the loop made the register allocator spill the accumulators).
+    auto run = [&](auto gg_tag) {
+    constexpr int GG = decltype(gg_tag)::value;
+    if constexpr (GG == 1) {          // group 1 runs one phase behind group 0
         barrier();
         barrier();
     }
-
     for (int i = 0; i < n_steps; ++i) {
         // ------------------------------ MFMA phase of step i = (ucur, ccur) ------------------------------
-        // ... and, inside it, the global loads of step i+1 = (unx, cnx): group G's weight half G and its input rows
         W2_T(t0)
         if (ccur == 0) {
+            // The bias enters through the accumulators: the point (xi_z, xi_y) = (1, 1) has the coefficient 1 in every row of both
+            // output transforms (A^T of F(4,3): column 1 = (1,1,1,1); of F(2,3): column 1 = (1,1)), so starting that accumulator
+            // at b adds exactly b to all eight outputs and the epilogue carries no bias arithmetic (and no load to wait for).
 #pragma unroll
             for (int e = 0; e < 24; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[1 * 4 + 1] = bias_next;        // loaded during the previous staging phase (prologue for the first tile)
         }
         if constexpr ((exp & 0x300) == 0) __builtin_amdgcn_s_setprio(3);          // production
         if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(0);      // experiment: staging wave above the MFMA wave
-        // measured (tools/bench_conv.py, one process): weight loads inside the MFMA stream + input-row loads at the end of the
-        // staging phase is the fastest of the four placements (0.491 vs 0.516 / 0.529 / 0.490 ms at 32->32 @64^3);
-        // experiments 0x800: weight loads in the staging phase, 0x1000: input loads in the MFMA stream
-        mfma_phase([&]() { if constexpr (!(exp & 0x800)) w_fetch(wreg, unx, cnx, G); },
-                   [&]() { if constexpr ((exp & 0x1000) != 0) fetch(raw, unx, cnx); });
+        mfma_phase(gg_tag);
         if constexpr ((exp & 0x300) == 0) __builtin_amdgcn_s_setprio(0);
         if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(2);
         W2_T(t3)
         barrier();                                                // end of the MFMA phase
         W2_T(t4)
         // ------------------------------ staging phase ------------------------------
-        // `raw` / `wreg` hold the input rows and the weight half of step i+1, loaded during the MFMA phase.
+        // `raw` holds the input rows of step i+1, loaded during the MFMA phase: first half = their transform into the group's V
+        // tile, second half = the epilogue of a finished tile and the unit walk.
         const bool epi = ccur == chunks - 1;
-        f32x4 resv[2][4], bias;
-        if (epi) epi_prefetch(ucur, resv, bias);
-        if (G == 1) {
-            // group 1 owns weight half 1: written in the first half of its staging phase (group 0 reads it behind the mid-phase
-            // barrier; group 1 itself finished with half 1 of step i before the barrier above)
-            w_commit(wreg, 1);
+        f32x4 resv[2][4];
+        commit(raw);
+        if (epi) epi_prefetch(ucur, resv);                  // skip tensor + bias of the finished tile: in flight across the barrier
+        W2_T(t5)
+        barrier();                                                // mid-phase barrier
+        W2_T(t6)
+        if (epi) epilogue(ucur, resv);
 #ifdef SE_STAMP2D
-            unsigned long long ta = 0;
-            W2_T(ta)
-            st[10] += ta - t4;
+        unsigned tb = 0;
+        W2_T(tb)
+        st[13] += tb - t6;
 #endif
-            commit(raw);
-            W2_T(t5)
-#ifdef SE_STAMP2D
-            st[11] += t5 - ta;
-#endif
-            barrier();                                            // mid-phase barrier
-            W2_T(t6)
-            if (epi) epilogue(ucur, resv, bias);
-        } else {
-            // group 0 owns weight half 0: written in the second half (group 1 reads half 0 of step i in the first half)
-            commit(raw);
-#ifdef SE_STAMP2D
-            unsigned long long ta = 0;
-            W2_T(ta)
-            st[11] += ta - t4;
-#endif
-            if (epi) epilogue(ucur, resv, bias);
-            W2_T(t5)
-#ifdef SE_STAMP2D
-            st[12] += t5 - ta;
-#endif
-            barrier();                                            // mid-phase barrier
-            W2_T(t6)
-            w_commit(wreg, 0);
-        }
         ucur = unx; ccur = cnx; icur = inx;
+        if (ccur == 0) bias_next = *reinterpret_cast<const f32x4*>(a.bpack + ucur.cb * 32 + ct * 16 + 4 * h);
         step_after(unx, cnx, inx);
-        if constexpr ((exp & 0x800) != 0) w_fetch(wreg, unx, cnx, G);
-        if constexpr (!(exp & 0x1000)) fetch(raw, unx, cnx);      // input rows of step i+2: land during the next MFMA phase
+        if (cnx == 0) fetch_setup(unx);                           // new unit (or, behind the last step, the same one again)
+        if constexpr (GG == 1) fetch(raw, unx, cnx);              // group 1: input rows of step i+2 (group 0: inside its MFMA phase)
         W2_T(t7)
         barrier();                                                // end of the staging phase
         W2_T(t8)
@@ -483,11 +553,14 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         st[8] += 1; st[9] += 1;
 #endif
     }
-    (void)icur;
-    if (G == 0) {                     // group 0 idles through group 1's last two phases
+    if constexpr (GG == 0) {          // group 0 idles through group 1's last two phases
         barrier();
         barrier();
     }
+    };
+    if (G == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+    (void)icur;
 #ifdef SE_STAMP2D
     if (lane == 0 && dbg) {
         unsigned long long* o = dbg + ((size_t)blockIdx.x * 8 + wave) * 16;
@@ -572,17 +645,26 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
     } while (0)
     const int layout = ((a.flags & SE_IN_OCTET) ? 1 : 0) | ((a.flags & SE_OUT_OCTET) ? 2 : 0) | ((a.flags & SE_RES_OCTET) && a.res ? 4 : 0);
 #ifdef SE_DEVTOOLS
-    if (layout == 0 && g_variant >= 41) {
+    if ((layout == 0 || layout == 3) && g_variant >= 41) {
+#define W2_VAR(E) do { if (layout == 3) W2_LAUNCH(E, 3); else W2_LAUNCH(E, 0); } while (0)
         switch (g_variant) {
-            case 41: W2_LAUNCH(0x2000, 0); break;   // packed epilogue arithmetic
-            case 42: W2_LAUNCH(0x1000, 0); break;   // input loads in the staging phase
-            case 43: W2_LAUNCH(0x1800, 0); break;   // both
-            case 44: W2_LAUNCH(4, 0); break;
-            case 47: W2_LAUNCH(7, 0); break;
-            case 48: W2_LAUNCH(0x400, 0); break;   // staging alone
-            case 49: W2_LAUNCH(0x200, 0); break;   // staging wave prioritised
-            default: W2_LAUNCH(0, 0); break;
+            case 41: W2_VAR(0x2000); break;   // packed epilogue arithmetic
+            case 42: W2_VAR(0x1000); break;   // input loads in the staging phase
+            case 43: W2_VAR(0x1800); break;   // both
+            case 44: W2_VAR(4); break;
+            case 47: W2_VAR(7); break;
+            case 48: W2_VAR(0x400); break;   // staging alone
+            case 49: W2_VAR(0x200); break;   // staging wave prioritised
+            case 50: W2_VAR(0x100); break;   // no priorities
+            case 51: W2_VAR(0x4000); break;  // attribution: weight half not written to LDS
+            case 52: W2_VAR(0x8000); break;  // attribution: V tile not written to LDS
+            case 53: W2_VAR(0x10000); break; // attribution: no input loads
+            case 54: W2_VAR(0x1C000); break; // attribution: all three
+            case 55: W2_VAR(0x1C400); break; // ... and no MFMA stream
+            case 56: W2_VAR(0x1C004); break; // all three + no epilogue memory traffic
+            default: W2_VAR(0); break;
         }
+#undef W2_VAR
         SE_CHECK_LAUNCH();
         return 0;
     }

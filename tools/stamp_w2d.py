@@ -27,4 +27,10 @@ for g, name in ((0, "group A (waves 0-3)"), (1, "group B (waves 4-7)")):
     print(f"{name}: {nm:.0f} MFMA phases, {ns:.0f} staging phases per wave")
     print(f"   MFMA phase   : first half {w[:, :, 0].mean() / nm:7.0f}  mid-barrier wait {w[:, :, 1].mean() / nm:7.0f}  second half {w[:, :, 2].mean() / nm:7.0f}  end-barrier wait {w[:, :, 3].mean() / nm:7.0f}   (ideal 2304 + 2304 cycles of MFMA issue)")
     print(f"   staging phase: first half {w[:, :, 4].mean() / ns:7.0f}  mid-barrier wait {w[:, :, 5].mean() / ns:7.0f}  second half {w[:, :, 6].mean() / ns:7.0f}  end-barrier wait {w[:, :, 7].mean() / ns:7.0f}")
-    print(f"   staging first half: w_commit {w[:, :, 10].mean() / ns:7.0f}  commit {w[:, :, 11].mean() / ns:7.0f}  epilogue (1 phase in {cin // 8}) {w[:, :, 12].mean() / ns:7.0f}")
+    print(f"   staging: first half = commit, second half = epilogue (1 phase in {cin // 8}) {w[:, :, 13].mean() / ns:7.0f} + unit walk")
+if os.environ.get("PERWAVE"):
+    names = ["mfma1", "midwait", "mfma2", "endwait", "stg1", "midwait", "stg2", "endwait"]
+    print("per wave (mean over workgroups), cycles per phase:  " + "  ".join(f"{n:>8s}" for n in names))
+    for wv in range(8):
+        row = d[:, wv, :8].mean(0) / d[:, wv, 8].mean()
+        print(f"   wave {wv} (G{wv >> 2} ct{(wv >> 1) & 1} jt{wv & 1}):                          " + "  ".join(f"{float(v):8.0f}" for v in row))
