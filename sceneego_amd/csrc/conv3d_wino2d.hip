@@ -310,7 +310,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     // output transform (A^T along y, then along z), bias, residual, ReLU, 8 x 16-byte channels-last stores
     // skip tensor + bias of a finished tile, issued in front of the staging phase's mid barrier
     auto epi_prefetch = [&](const Unit& u, f32x4 (&resv)[2][4]) {
-        if (!use_res || (exp & 4)) {          // no skip tensor: add zeros (the epilogue has no per-element selects)
+        if (!use_res || (exp & 4) || (exp & 0x20000)) {          // no skip tensor: add zeros (the epilogue has no per-element selects)
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
                 f32x4 v = out[r][z];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c] + resv_all[r][z][c], relu_lo);
-                if (!(exp & 4) || v.x == 12345.f) *reinterpret_cast<f32x4*>(ob + z * zstride + r * ystride + voff) = v;
+                if (!(exp & (4 | 0x40000)) || v.x == 12345.f) *reinterpret_cast<f32x4*>(ob + z * zstride + r * ystride + voff) = v;
             }
         }
     };
@@ -529,7 +529,9 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         const bool epi = ccur == chunks - 1;
         f32x4 resv[2][4];
         commit(raw);
-        if (epi) epi_prefetch(ucur, resv);                  // skip tensor + bias of the finished tile: in flight across the barrier
+        // skip tensor of a finished tile: in flight across the barrier and the output transform (issued in front of the V-tile
+        // transform it measured slower, 0.428 vs 0.415 ms: that transform then waits behind these loads for its input rows)
+        if (epi) epi_prefetch(ucur, resv);
         W2_T(t5)
         barrier();                                                // mid-phase barrier
         W2_T(t6)
@@ -662,6 +664,8 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
             case 54: W2_VAR(0x1C000); break; // attribution: all three
             case 55: W2_VAR(0x1C400); break; // ... and no MFMA stream
             case 56: W2_VAR(0x1C004); break; // all three + no epilogue memory traffic
+            case 57: W2_VAR(0x20000); break; // attribution: no skip-tensor loads
+            case 58: W2_VAR(0x40000); break; // attribution: no output stores
             default: W2_VAR(0); break;
         }
 #undef W2_VAR
