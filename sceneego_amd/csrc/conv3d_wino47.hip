@@ -194,6 +194,11 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino47_kernel(ConvArgs a, int t
     };
     const long long zstride = (long long)dim * dim * 16;
 
+    auto lds_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
     const bool relu = a.flags & SE_EPI_RELU;
     const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + 4 * h);
     const bool lone = n == 1;
@@ -308,8 +313,11 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino47_kernel(ConvArgs a, int t
 #pragma unroll
             for (int z = 0; z < 4; ++z) y[z] += part[z];
         }
-        // single transformed tile: every wave must be done reading it before the next item's columns are committed
-        __syncthreads();
+        // single transformed tile: every wave must be done reading it before the next item's columns are committed.
+        // Barriers inside the loop wait for this wave's LDS traffic only (a __syncthreads() also waits for vmcnt(0): the output
+        // stores of the item would have to be acknowledged before the next MFMA phase may start); register-only arithmetic must
+        // not drift across them either.
+        lds_barrier();
         T47(t2);
         if (has_next) {
             commit();
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino47_kernel(ConvArgs a, int t
         for (int z = 0; z < 4; ++z) *reinterpret_cast<f32x4*>(a.out + o0 + z * zstride) = y[z];
         T47(t3);
         if (!has_next) break;
-        __syncthreads();
+        lds_barrier();
         T47(t4);
 #ifdef SE_STAMP47
         s_mfma += t1 - t0; s_b1 += t2 - t1; s_stage += t3 - t2; s_b2 += t4 - t3;
