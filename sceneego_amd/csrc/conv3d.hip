@@ -277,6 +277,98 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// ConvTranspose3d(k=2, s=2) + folded BN (+skip add) + ReLU (Upsample3DBlock, reference network/v2v.py:55-67), all eight
+// sub-positions of a voxel tile in ONE workgroup.  HBM-bound (2 B of input, 16 B of output + 16 B of skip tensor per
+// input-voxel-channel pair at 64->32): the direct kernel's grid.z form re-reads the input eight times, leaves the two x
+// neighbours of an output line pair to different workgroups and waits for the skip tensor behind its MFMAs; here the input
+// fragments of a tile stay in registers over the eight sub-positions, the (2x, 2x+1) records of all cout tiles are written back to
+// back by the same wave, and the skip records of a sub-position are requested in front of its MFMAs.
+// A wave owns M_T tiles of 16 consecutive voxels; CGS = cin / 16, N_T = cout / 16 (all couts in one workgroup).
+// ------------------------------------------------------------------------------------------------
+template <int CGS, int N_T, int M_T>
+__global__ __launch_bounds__(256) void deconv3d_k2s2_kernel(ConvArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int vl = lane & 15;
+    const int h = lane >> 4;
+    const int dim = a.dim;
+    const long long v_base = ((long long)blockIdx.x * 4 + wave) * (M_T * 16);
+    int vb[M_T], vz[M_T], vy[M_T], vx[M_T];
+    bool vok[M_T];
+    f32x4 xf[M_T][CGS];
+#pragma unroll
+    for (int m = 0; m < M_T; ++m) {
+        const long long vid = v_base + m * 16 + vl;
+        vok[m] = vid < a.total_vox;
+        long long t = vok[m] ? vid : 0;
+        const float* src = a.in + t * a.cin_pad + 4 * h;
+        vx[m] = (int)(t % dim); t /= dim;
+        vy[m] = (int)(t % dim); t /= dim;
+        vz[m] = (int)(t % dim); t /= dim;
+        vb[m] = (int)t;
+#pragma unroll
+        for (int cg = 0; cg < CGS; ++cg) {
+            xf[m][cg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (vok[m]) xf[m][cg] = *reinterpret_cast<const f32x4*>(src + cg * 16);
+        }
+    }
+    const int odim = dim * 2;
+    const long long ovox_per_b = (long long)odim * odim * odim;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack) + lane;
+    const bool relu = a.flags & SE_EPI_RELU;
+    const bool res_pre = (a.flags & SE_EPI_RES_PRE_RELU) && a.res, res_post = (a.flags & SE_EPI_RES_POST_RELU) && a.res;
+    f32x4 bias[N_T];
+#pragma unroll
+    for (int n = 0; n < N_T; ++n) bias[n] = *reinterpret_cast<const f32x4*>(a.bpack + n * 16 + 4 * h);
+#pragma unroll 1
+    for (int sub = 0; sub < 8; ++sub) {
+        // output records of this sub-position; the skip tensor is requested first so that its latency lies under the MFMAs
+        long long ooff[M_T];
+        f32x4 rv[M_T][N_T];
+#pragma unroll
+        for (int m = 0; m < M_T; ++m) {
+            const int oz = 2 * vz[m] + (sub >> 2), oy = 2 * vy[m] + ((sub >> 1) & 1), ox = 2 * vx[m] + (sub & 1);
+            ooff[m] = ((long long)vb[m] * ovox_per_b + ((long long)oz * odim + oy) * odim + ox) * a.cout + 4 * h;
+#pragma unroll
+            for (int n = 0; n < N_T; ++n) {
+                rv[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if ((res_pre || res_post) && vok[m]) rv[m][n] = *reinterpret_cast<const f32x4*>(a.res + ooff[m] + n * 16);
+            }
+        }
+        f32x4 acc[M_T][N_T];
+#pragma unroll
+        for (int m = 0; m < M_T; ++m)
+#pragma unroll
+            for (int n = 0; n < N_T; ++n) acc[m][n] = bias[n];
+#pragma unroll
+        for (int cg = 0; cg < CGS; ++cg) {
+            f32x4 wf[N_T];
+#pragma unroll
+            for (int n = 0; n < N_T; ++n) wf[n] = wp[((size_t)(cg * 8 + sub) * N_T + n) * 64];
+            // k step outer, accumulators inner: consecutive MFMAs never share an accumulator
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int m = 0; m < M_T; ++m)
+#pragma unroll
+                    for (int n = 0; n < N_T; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n][k], xf[m][cg][k], acc[m][n], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < M_T; ++m) {
+            if (!vok[m]) continue;
+#pragma unroll
+            for (int n = 0; n < N_T; ++n) {
+                f32x4 v = acc[m][n];
+                if (res_pre) v += rv[m][n];
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (res_post) v += rv[m][n];
+                *reinterpret_cast<f32x4*>(a.out + ooff[m] + n * 16) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // split-K variant for the small pyramid levels (8^3, 4^3, 2^3: 128 -> 128 channels, a few thousand voxels).
 // There the direct kernel has only a handful of workgroups, each walking all 27 x 8 steps serially
 // (0.24 ms per conv, MFMA-latency-bound on <10 % of the chip).  Here grid.z splits the 27 taps, every
@@ -714,6 +806,25 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
     a.wpack_e = nullptr;
     a.wpack_f = nullptr;
     a.wpack_g = nullptr;
+    // all eight sub-positions per workgroup where that still fills the chip (measured at B=8: 64->32 from 32^3, 2048 workgroups,
+    // 0.241 -> 0.149 ms = 4.05 TB/s; the 128->128 levels, 1..64 workgroups, 0.02 -> 0.14 ms: those keep the grid.z form, whose 8x
+    // more workgroups matter more than the input re-reads there)
+    const unsigned g2 = (unsigned)((a.total_vox + 127) / 128), g1 = (unsigned)((a.total_vox + 63) / 64);
+#define SE_DECONV_CASE(CI, CO, MT, G)                                                                                          \
+    if (cin == CI && cout == CO) {                                                                                             \
+        hipLaunchKernelGGL((deconv3d_k2s2_kernel<CI / 16, CO / 16, MT>), dim3(G), dim3(256), 0, se_stream(stream), a);        \
+        SE_CHECK_LAUNCH();                                                                                                     \
+        return 0;                                                                                                              \
+    }
+    if (g2 >= 4u * (unsigned)se_num_cus()) {
+        SE_DECONV_CASE(64, 32, 2, g2)
+        SE_DECONV_CASE(128, 64, 2, g2)
+        SE_DECONV_CASE(128, 128, 2, g2)
+    } else if (g1 >= 2u * (unsigned)se_num_cus()) {
+        SE_DECONV_CASE(64, 32, 1, g1)
+        SE_DECONV_CASE(128, 64, 1, g1)
+    }
+#undef SE_DECONV_CASE
     const long long vox_per_wg = 4 * 4 * 16;
     const unsigned gx = (unsigned)((a.total_vox + vox_per_wg - 1) / vox_per_wg);
     if (a.nts % 2 == 0) {
