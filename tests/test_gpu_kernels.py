@@ -246,8 +246,11 @@ def test_conv3d_linearity_full_size():
     # and a sampled check against the direct definition at 2 000 random output positions is done in test_v2v_*
 
 
+# the last three run on deconv3d_k2s2_kernel (all eight sub-positions per workgroup): 2 tiles per wave at >= 4 workgroups per CU
+# (the 64^3-level shape at B=8, and a ragged voxel count), 1 tile per wave at >= 2 per CU; the others on the grid.z form
 @pytest.mark.parametrize("B,dim,cin,cout,skip", [(2, 4, 128, 128, True), (1, 8, 128, 64, True), (1, 16, 64, 32, False),
-                                                  (3, 2, 32, 16, True)])
+                                                  (3, 2, 32, 16, True), (8, 32, 64, 32, True), (4, 34, 64, 32, False),
+                                                  (8, 16, 128, 64, True)])
 def test_deconv_vs_torch(B, dim, cin, cout, skip):
     seed = cin + cout + dim
     up = nn.ConvTranspose3d(cin, cout, 2, stride=2)
