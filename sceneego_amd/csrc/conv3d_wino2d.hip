@@ -390,6 +390,35 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
+    // Experiment (exp & 0x100000): no workgroup barriers inside the loop.  Each group synchronises its own four waves with a
+    // monotonic arrival counter in LDS, and the only two cross-group dependencies of the weight halves are waits on the OTHER group's
+    // counter: group 0 may start the first MFMA half of step s+1 when group 1 has finished the MFMA phase of step s (its barrier
+    // number 4s+2: half 1 of step s read, half 0 of step s+1 written), group 1 may enter the second MFMA half of step s when group 0
+    // has passed the mid barrier of its MFMA phase of step s (number 4s+1: half 1 written, half 0 read).  A group that carries an
+    // epilogue then no longer holds the other one at the next barrier.
+    constexpr bool flagsync = (exp & 0x100000) != 0;
+    unsigned* sync_cnt = reinterpret_cast<unsigned*>(lds + W2_CHUNK_FLOATS + 2 * W2_VG_FLOATS + 480);    // [0]: group 0, [1]: group 1
+    int my_barriers = 0;
+    auto wait_ge = [&](int which, int target) {
+        while (true) {
+            const unsigned v = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(sync_cnt + which));
+            if ((int)v >= target) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto group_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(sync_cnt + G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ++my_barriers;
+        wait_ge(G, 4 * my_barriers);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto phase_barrier = [&]() {
+        if constexpr (flagsync) group_barrier();
+        else barrier();
+    };
 
     // State of the walk: (ucur, ccur) = the step this group computes next, (unx, cnx) = the step after it.
     Unit ucur = decode(u_begin);
@@ -398,6 +427,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     int cnx = 0, inx = 0;
     f32x2 raw[6][2];
     f32x4 wreg[9];
+    int step_index = 0;
     f32x4 bias_next = *reinterpret_cast<const f32x4*>(a.bpack + ucur.cb * 32 + ct * 16 + 4 * h);   // bias of the tile whose first MFMA phase comes next
 
     // ---- MFMA phase of group GG: 18 groups (xi_z, dx) of 4 xi_y x 2 k steps; the workgroup's mid-phase barrier sits in front of
@@ -437,7 +467,8 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
                 // the prefetch below (group 9) is the first read of weight half 1; all reads of half 0 have been issued and are
                 // drained by the barrier's lgkmcnt(0)
                 W2_T(t1)
-                barrier();
+                phase_barrier();
+                if constexpr (flagsync && GG == 1) wait_ge(0, 4 * (4 * step_index + 1));     // group 0 past the mid barrier of this step
                 W2_T(t2)
             }
             // riders of this group: LDS writes of a weight set first (frees its registers), then loads
@@ -494,17 +525,22 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     if (cnx == 0) fetch_setup(unx);
     if (G == 1) fetch(raw, unx, cnx);
     if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(2);
+    if (flagsync && tid < 2) sync_cnt[tid] = 0u;
     barrier();
 
     // The main loop exists once per group (its MFMA phase differs): one uniform branch in front of the loops instead of one inside
     // every iteration (a join inside the loop made the register allocator spill the accumulators).
     auto run = [&](auto gg_tag) {
     constexpr int GG = decltype(gg_tag)::value;
-    if constexpr (GG == 1) {          // group 1 runs one phase behind group 0
+    if constexpr (GG == 1 && !flagsync) {          // group 1 runs one phase behind group 0
         barrier();
         barrier();
     }
     for (int i = 0; i < n_steps; ++i) {
+        step_index = i;
+        if constexpr (flagsync && GG == 0) {
+            if (i > 0) wait_ge(1, 4 * (4 * (i - 1) + 2));         // group 1 finished the MFMA phase of step i-1
+        }
         // ------------------------------ MFMA phase of step i = (ucur, ccur) ------------------------------
         W2_T(t0)
         if (ccur == 0) {
@@ -521,7 +557,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         if constexpr ((exp & 0x300) == 0) __builtin_amdgcn_s_setprio(0);
         if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(2);
         W2_T(t3)
-        barrier();                                                // end of the MFMA phase
+        phase_barrier();                                          // end of the MFMA phase
         W2_T(t4)
         // ------------------------------ staging phase ------------------------------
         // `raw` holds the input rows of step i+1, loaded during the MFMA phase: first half = their transform into the group's V
@@ -533,7 +569,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         // transform it measured slower, 0.428 vs 0.415 ms: that transform then waits behind these loads for its input rows)
         if (epi) epi_prefetch(ucur, resv);
         W2_T(t5)
-        barrier();                                                // mid-phase barrier
+        phase_barrier();                                          // mid-phase barrier
         W2_T(t6)
         if (epi) epilogue(ucur, resv);
 #ifdef SE_STAMP2D
@@ -547,7 +583,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         if (cnx == 0) fetch_setup(unx);                           // new unit (or, behind the last step, the same one again)
         if constexpr (GG == 1) fetch(raw, unx, cnx);              // group 1: input rows of step i+2 (group 0: inside its MFMA phase)
         W2_T(t7)
-        barrier();                                                // end of the staging phase
+        phase_barrier();                                          // end of the staging phase
         W2_T(t8)
 #ifdef SE_STAMP2D
         st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2; st[3] += t4 - t3;
@@ -555,7 +591,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         st[8] += 1; st[9] += 1;
 #endif
     }
-    if constexpr (GG == 0) {          // group 0 idles through group 1's last two phases
+    if constexpr (GG == 0 && !flagsync) {          // group 0 idles through group 1's last two phases
         barrier();
         barrier();
     }
@@ -666,6 +702,7 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
             case 56: W2_VAR(0x1C004); break; // all three + no epilogue memory traffic
             case 57: W2_VAR(0x20000); break; // attribution: no skip-tensor loads
             case 58: W2_VAR(0x40000); break; // attribution: no output stores
+            case 60: W2_VAR(0x100000); break; // experiment: LDS-counter group barriers + cross-group waits instead of workgroup barriers
             default: W2_VAR(0); break;
         }
 #undef W2_VAR
