@@ -525,8 +525,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, const fl
     if (t >= a.total_vox * cq) return;
     const long long vid = t / cq;
     const int q = (int)(t - vid * cq);
+    // all partials requested before the first add (splits is 3, 9 or 27; the sum keeps its fixed order): the kernel is pure load
+    // latency, one dependent round trip per split otherwise
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(ws + ((size_t)s * a.total_vox + vid) * a.cout + q * 4);
+    const float* p0 = ws + vid * a.cout + q * 4;
+    const size_t sstride = (size_t)a.total_vox * a.cout;
+    for (int s0 = 0; s0 < splits; s0 += 9) {
+        f32x4 part[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) part[u] = (s0 + u < splits) ? *reinterpret_cast<const f32x4*>(p0 + (size_t)(s0 + u) * sstride) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 9; ++u) v += part[u];
+    }
     const long long per_b = (long long)a.dim * a.dim * a.dim;
     const int b = (int)(vid / per_b);
     conv_epilogue(a, v, b, vid - (long long)b * per_b, per_b, q * 4);
