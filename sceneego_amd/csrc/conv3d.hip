@@ -560,13 +560,28 @@ __global__ __launch_bounds__(256) void pointwise_chain3_kernel(const float* __re
     const f32x4* W1 = reinterpret_cast<const f32x4*>(w1) + lane;   // blocks [cg][tap=0][nt][lane]: index (cg*2 + nt)*64
     const f32x4* W2 = reinterpret_cast<const f32x4*>(w2) + lane;
     const f32x4* W3 = reinterpret_cast<const f32x4*>(w3) + lane;   // nts = 1: index cg*64
-    for (long long tile = (long long)blockIdx.x * 4 + wave; tile * 16 < total_vox; tile += (long long)gridDim.x * 4) {
+    // the next tile's activations are requested before this tile's MFMA chain (three dependent layers = ~40 MFMA latencies)
+    const long long tstride = (long long)gridDim.x * 4;
+    long long tile = (long long)blockIdx.x * 4 + wave;
+    f32x4 xn[2];
+    {
+        const long long v0 = tile * 16 + vl;
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg)
+            xn[cg] = (tile * 16 < total_vox && v0 < total_vox) ? *reinterpret_cast<const f32x4*>(in + v0 * 32 + cg * 16 + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (; tile * 16 < total_vox; tile += tstride) {
         const long long vid = tile * 16 + vl;
         const bool ok = vid < total_vox;
         f32x4 x[2], y[2];
+        x[0] = xn[0]; x[1] = xn[1];
+        {
+            const long long vnext = (tile + tstride) * 16 + vl;
+            const bool okn = vnext < total_vox;
 #pragma unroll
-        for (int cg = 0; cg < 2; ++cg)
-            x[cg] = ok ? *reinterpret_cast<const f32x4*>(in + vid * 32 + cg * 16 + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int cg = 0; cg < 2; ++cg)
+                xn[cg] = okn ? *reinterpret_cast<const f32x4*>(in + vnext * 32 + cg * 16 + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #define SE_PW_LAYER(W, B, X, Y)                                                                 \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                          \
         f32x4 acc = *reinterpret_cast<const f32x4*>(B + nt * 16 + 4 * h);                       \
