@@ -121,6 +121,14 @@ int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const
                   float* out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
                   float* workspace, long long workspace_elems, void* stream);
 
+/* se_conv3d_f32 that also writes max_pool3d(out, kernel 2, stride 2) from the kernel's epilogue: `pool_out` is channels-last
+ * [B][D/2][D/2][D/2][cout] float32.  Stands in for a Res3DBlock's last convolution followed by encoder_pool (reference
+ * network/v2v.py:104-119) without re-reading the block output.  Only shapes with se_conv3d_f32_algo() == 2 (the 2-D Winograd
+ * kernel) and cin_pad == cin; SE_ERR_BAD_ARG otherwise.  `out` is written as by se_conv3d_f32 (either layout). */
+int se_conv3d_pool_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
+                       float* out, float* pool_out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
+                       float* workspace, long long workspace_elems, void* stream);
+
 /* Fused V2V tail: two 1x1x1 32->32 convs (+BN+ReLU) and the 1x1x1 32->cout3 output layer in one pass
  * (network/v2v.py:155-161 back_layers.1/.2 + output_layer :161,169).  in [B][D]^3[32]; out planar [B][cout3][D^3];
  * wpackN / bpackN come from se_conv3d_pack_f32 (ksize 1, cin_pad 32); cout3 <= 16.                           */

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -41,6 +41,7 @@ SIGNATURES = {
     "se_conv3d_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_packed_elems": (_ll, [_i, _i, _i, _i]),
     "se_conv3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
+    "se_conv3d_pool_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
     "se_pointwise_chain3_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "se_deconv3d_k2s2_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_maxpool3d_2_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -311,7 +312,9 @@ def _tag(t):
     return "" if t.dtype == torch.float32 else "_bf16"
 
 
-def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksize, flags, workspace=None):
+def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksize, flags, workspace=None, pool_out=None):
+    """``pool_out`` (float32, 2-D Winograd 3x3x3 shapes only): channels-last [B, D/2, D/2, D/2, cout] tensor that also receives
+    max_pool3d(out, 2, 2) from the kernel's epilogue (se_conv3d_pool_f32)."""
     require_hip(inp, out)
     if _prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -322,6 +325,12 @@ def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksi
         assert residual is None or residual.dtype == torch.bfloat16
         _check(load().se_conv3d_bf16(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim,
                                      cin_pad, cout, ksize, flags, _stream()), "se_conv3d_bf16")
+    elif pool_out is not None:
+        require_hip(pool_out)
+        assert pool_out.dtype == torch.float32 and pool_out.numel() == batch * (dim // 2) ** 3 * cout and pool_out.is_contiguous()
+        _check(load().se_conv3d_pool_f32(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), _ptr(pool_out), batch,
+                                         dim, cin, cin_pad, cout, ksize, flags, _ptr(workspace),
+                                         0 if workspace is None else workspace.numel(), _stream()), "se_conv3d_pool_f32")
     else:
         _check(load().se_conv3d_f32(_ptr(inp), _ptr(wpack), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim, cin,
                                     cin_pad, cout, ksize, flags, _ptr(workspace),

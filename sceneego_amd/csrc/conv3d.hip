@@ -685,7 +685,7 @@ int launch_direct(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int se_abi_version(void) { return 7; }
+extern "C" int se_abi_version(void) { return 8; }
 
 // Mirrors the dispatch of se_conv3d_f32 -> se_conv3d_tiled_try -> se_conv3d_wino_try / se_conv3d_k7_wino_try for the
 // default channels-last call (no SE_EPI_OUT_PLANAR / SE_EPI_RES_POST_RELU flags).
@@ -750,9 +750,9 @@ int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s);
 
 #define g_variant_direct (g_variant == 18 ? 1 : 0)   // se_debug_set_variant(18): A/B, grid-level split-K for every small level
 
-extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
-                             float* out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
-                             float* workspace, long long workspace_elems, void* stream) {
+static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpack, const float* residual, float* out,
+                           float* pool_out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
+                           float* workspace, long long workspace_elems, void* stream) {
     if (batch <= 0 || dim <= 0 || cin <= 0 || cin_pad < cin || (cin_pad & 15) || cout <= 0) return SE_ERR_BAD_ARG;
     if (ksize != 1 && ksize != 3 && ksize != 7) return SE_ERR_BAD_ARG;
     const bool planar = flags & SE_EPI_OUT_PLANAR;
@@ -774,6 +774,8 @@ extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* b
     if (ksize == 3 && cout % 32 == 0) a.wpack_e = a.wpack_b + (long long)(cin_pad / 16) * (cout / 32) * SE_WINO_CHUNK_FLOATS;
     a.wpack_g = nullptr;
     if (ksize == 3 && cout % 32 == 0) a.wpack_g = a.wpack_e + (long long)(cin_pad / 16) * (cout / 32) * SE_WINO43_CHUNK_FLOATS;
+    a.pool_out = pool_out;
+    if (pool_out && ((dim & 1) || se_conv3d_f32_algo(dim, cin, cout, ksize) != 2 || cin_pad != cin)) return SE_ERR_BAD_ARG;   // only the 2-D Winograd kernel pools
     if (ksize == 3 && (cout % 32)) a.wpack_b = nullptr;
     if (ksize == 1) a.wpack_b = nullptr;
     if ((flags & SE_IN_PLANAR3) && ksize != 7) return SE_ERR_BAD_ARG;
@@ -817,6 +819,23 @@ extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* b
     }
 }
 
+extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
+                             float* out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
+                             float* workspace, long long workspace_elems, void* stream) {
+    return conv3d_f32_impl(in, wpack, bpack, residual, out, nullptr, batch, dim, cin, cin_pad, cout, ksize, flags, workspace,
+                           workspace_elems, stream);
+}
+
+// Same convolution; the kernel also writes max_pool3d(out, kernel 2, stride 2) (channels-last) from its epilogue, so the 2x pool
+// of a Res3DBlock output (reference network/v2v.py:104-119: encoder_pool after the front / encoder blocks) does not re-read it.
+extern "C" int se_conv3d_pool_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
+                                  float* out, float* pool_out, int batch, int dim, int cin, int cin_pad, int cout, int ksize,
+                                  int flags, float* workspace, long long workspace_elems, void* stream) {
+    if (!pool_out) return SE_ERR_BAD_ARG;
+    return conv3d_f32_impl(in, wpack, bpack, residual, out, pool_out, batch, dim, cin, cin_pad, cout, ksize, flags, workspace,
+                           workspace_elems, stream);
+}
+
 extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
                                     float* out, int batch, int dim, int cin, int cout, int flags, void* stream) {
     if (batch <= 0 || dim <= 0 || cin <= 0 || (cin & 15) || cout <= 0 || (cout & 15)) return SE_ERR_BAD_ARG;
@@ -831,6 +850,7 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
     a.wpack_e = nullptr;
     a.wpack_f = nullptr;
     a.wpack_g = nullptr;
+    a.pool_out = nullptr;
     // all eight sub-positions per workgroup where that still fills the chip (measured at B=8: 64->32 from 32^3, 2048 workgroups,
     // 0.241 -> 0.149 ms = 4.05 TB/s; the 128->128 levels, 1..64 workgroups, 0.02 -> 0.14 ms: those keep the grid.z form, whose 8x
     // more workgroups matter more than the input re-reads there)

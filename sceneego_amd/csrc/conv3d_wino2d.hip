@@ -101,14 +101,15 @@ constexpr int rider_raw_count(int gg, int g) {
 // EXP: timing experiments of development builds (0 = the real kernel; bit 0: compact input addresses, bit 1: no weight stream,
 // bit 2: no epilogue memory traffic - all three give wrong results and exist only to attribute time)
 // LAYOUT: bit 0 = input is octet-planar [B][cin/8][D][D][D][8] (SE_IN_OCTET), bit 1 = output is octet-planar (SE_OUT_OCTET),
-// bit 2 = the skip tensor is octet-planar (SE_RES_OCTET).
+// bit 2 = the skip tensor is octet-planar (SE_RES_OCTET), bit 3 = also write the 2x2x2 max-pool of the output (se_conv3d_pool_f32;
+// instantiated for the layouts the V2V program pools: 3 and 7).
 // In the octet-planar form an 8-channel chunk of a halo row is ONE contiguous run (18 positions x 32 B) instead of 18 pieces of
 // 32 B at a 4*cin-byte stride: 4x fewer cache lines per load instruction.
 template <int EXP, int LAYOUT>
 __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const float* __restrict__ wg, int tiles_x, int tiles_y,
                                                                int tiles_z, int total_tiles, int n_units, int units_per_wg, unsigned long long* dbg) {
     constexpr int exp = EXP;
-    constexpr bool in_oct = LAYOUT & 1, out_oct = LAYOUT & 2, res_oct = LAYOUT & 4;
+    constexpr bool in_oct = LAYOUT & 1, out_oct = LAYOUT & 2, res_oct = LAYOUT & 4, pool = LAYOUT & 8;
     unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, t8 = 0, st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5; (void)t6; (void)t7; (void)t8; (void)st; (void)dbg;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -377,6 +378,26 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c] + resv_all[r][z][c], relu_lo);
                 if (!(exp & (4 | 0x40000)) || v.x == 12345.f) *reinterpret_cast<f32x4*>(ob + z * zstride + r * ystride + voff) = v;
+                out[r][z] = v;
+            }
+        }
+        // fused 2x2x2 max-pool (se_conv3d_pool_f32): the wave's tile is 4 (z) x 2 (y) x 16 (x) outputs = 2 x 1 x 8 pooled voxels;
+        // z and y pairs sit in this lane's registers, the x neighbour in the adjacent lane (quad_perm swap); even-x lanes store
+        // 16 bytes of the channels-last pooled tensor [B][D/2][D/2][D/2][cout]
+        if constexpr (pool) {
+            const int hd = dim >> 1;
+            float* pb = a.pool_out + ((((long long)u.b * hd + (u.z0 >> 1)) * hd + ((u.y0 + G * 4 + jt * 2) >> 1)) * hd + (u.x0 >> 1) + (px >> 1)) * a.cout
+                        + u.cb * 32 + ct * 16 + 4 * h;
+#pragma unroll
+            for (int pz = 0; pz < 2; ++pz) {
+                f32x4 m;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float m4 = fmaxf(fmaxf(out[0][2 * pz][c], out[0][2 * pz + 1][c]), fmaxf(out[1][2 * pz][c], out[1][2 * pz + 1][c]));
+                    const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m4), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                    m[c] = fmaxf(m4, nb);
+                }
+                if (!(px & 1)) *reinterpret_cast<f32x4*>(pb + (long long)pz * hd * hd * a.cout) = m;
             }
         }
     };
@@ -710,6 +731,13 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
         return 0;
     }
 #endif
+    if (a.pool_out) {
+        if (layout == 3) W2_LAUNCH(0, 11);
+        else if (layout == 7) W2_LAUNCH(0, 15);
+        else return SE_ERR_BAD_ARG;       // pooled output: octet-planar in / out only (what the V2V program uses)
+        SE_CHECK_LAUNCH();
+        return 0;
+    }
     switch (layout) {
         case 1: W2_LAUNCH(0, 1); break;
         case 2: W2_LAUNCH(0, 2); break;

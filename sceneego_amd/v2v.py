@@ -220,13 +220,13 @@ class V2VProgram:
     def _new(self, B, dim, c):
         return torch.empty((B, dim, dim, dim, c), device=self.device, dtype=self.dtype)
 
-    def _conv(self, x, pc, B, dim, flags, residual=None, out=None):
+    def _conv(self, x, pc, B, dim, flags, residual=None, out=None, pool_out=None):
         if out is None:
             out = self._new(B, dim, pc.cout)
-        _lib.conv3d(x, pc.w, pc.b, residual, out, B, dim, pc.cin, pc.cin_pad, pc.cout, pc.k, flags, self.workspace)
+        _lib.conv3d(x, pc.w, pc.b, residual, out, B, dim, pc.cin, pc.cin_pad, pc.cout, pc.k, flags, self.workspace, pool_out=pool_out)
         return out
 
-    def _res(self, x, blk, B, dim, x_oct=False, out_oct=False):
+    def _res(self, x, blk, B, dim, x_oct=False, out_oct=False, pool_out=None):
         """Res3DBlock (v2v.py:40-43): relu(bn(conv(relu(bn(conv(x))))) + skip(x)).
 
         Layouts (float32 program, blocks whose two 3x3x3 convolutions run on the 2-D Winograd kernel): the tensor between the two
@@ -245,7 +245,7 @@ class V2VProgram:
             f2 |= _lib.RES_OCTET
         if out_oct:
             f2 |= _lib.OUT_OCTET
-        return self._conv(a, c2, B, dim, f2, residual=s)
+        return self._conv(a, c2, B, dim, f2, residual=s, pool_out=pool_out)      # pool_out: the block's 2x max-pool, written by the same launch
 
     def _oct_ok(self, blk, dim):
         c1, c2, _ = blk
@@ -280,20 +280,28 @@ class V2VProgram:
         # Tensor layouts of the float32 program: a Res3DBlock output that is read only by 2-D Winograd convolutions (as input or as
         # skip tensor) and by a max-pool is kept octet-planar; what the deconvolutions, the 1x1x1 convolutions and the fused tail
         # read stays channels-last.  x_oct tracks the layout of the running tensor.
+        # A block whose output goes to an encoder max-pool writes the pooled tensor from its last convolution's epilogue when
+        # that convolution runs on the 2-D Winograd kernel (`pooled`); the pool kernel is then not launched.
         x_oct = False
+        pooled = None
         for i, blk in enumerate(self.front_res):
             ok = self._oct_ok(blk, G)
-            x = self._res(x, blk, B, G, x_oct=x_oct, out_oct=ok)
+            if ok and i == len(self.front_res) - 1:
+                pooled = self._new(B, G // 2, blk[1].cout)
+            x = self._res(x, blk, B, G, x_oct=x_oct, out_oct=ok, pool_out=pooled)
             x_oct = ok
         # encoder (v2v.py:104-119)
         skips = []
         dim = G
         for k in range(5):
             skips.append(self._res(x, self.skip[k], B, dim, x_oct=x_oct, out_oct=False))    # read by the decoder's deconvolution
-            x = self._pool(x, B, dim, x.numel() // (B * dim ** 3), x_oct=x_oct)
+            x = pooled if pooled is not None else self._pool(x, B, dim, x.numel() // (B * dim ** 3), x_oct=x_oct)
+            pooled = None
             dim //= 2
             ok = self._oct_ok(self.enc[k], dim)
-            x = self._res(x, self.enc[k], B, dim, x_oct=False, out_oct=ok)
+            if ok and k < 4:
+                pooled = self._new(B, dim // 2, self.enc[k][1].cout)
+            x = self._res(x, self.enc[k], B, dim, x_oct=False, out_oct=ok, pool_out=pooled)
             x_oct = ok
         if x_oct:    # cannot happen: the deepest levels are too small for the 2-D kernel
             raise RuntimeError("octet-planar tensor reached the middle block")

@@ -474,7 +474,8 @@ def test_gather_planar3_other_channel_counts(channels):
     assert float(flat[..., channels:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,dim,cin,cout", [(1, 16, 32, 32), (2, 32, 16, 32), (1, 16, 64, 128)])
+# (34, 16, 32, 32): more samples than one launch takes (slices of 32), so every per-slice pointer is exercised
+@pytest.mark.parametrize("B,dim,cin,cout", [(1, 16, 32, 32), (2, 32, 16, 32), (1, 16, 64, 128), (34, 16, 32, 32)])
 def test_conv3d_octet_planar_forms_match_channels_last(B, dim, cin, cout):
     """The 2-D Winograd 3x3x3 kernel reads / writes the octet-planar layout [B][C/8][D][D][D][8] (SE_IN_OCTET / SE_OUT_OCTET, used
     between the two convolutions of a Res3DBlock): same arithmetic in the same order, so results are bit-identical to the
@@ -509,6 +510,21 @@ def test_conv3d_octet_planar_forms_match_channels_last(B, dim, cin, cout):
     _lib.maxpool3d_2(x, p_ref, B, dim, cin)
     _lib.maxpool3d_2(x_oct, p_oct, B, dim, cin, in_octet=True)
     assert torch.equal(p_ref, p_oct)
+    # fused 2x max-pool of the output (se_conv3d_pool_f32: octet-planar in / out, skip tensor channels-last or octet-planar):
+    # the full-resolution output is unchanged and the pooled tensor equals the max-pool of it, bit for bit
+    p_fused = torch.full((B, dim // 2, dim // 2, dim // 2, cout), float("nan"), device=DEV)
+    _lib.conv3d(x_oct, pc.w, pc.b, res, out_oct, B, dim, cin, cin, cout, 3, flags | _lib.IN_OCTET | _lib.OUT_OCTET, pool_out=p_fused)
+    assert torch.equal(out_oct.permute(0, 2, 3, 4, 1, 5).reshape(B, dim, dim, dim, cout), ref)
+    p_want = torch.empty_like(p_fused)
+    _lib.maxpool3d_2(ref, p_want, B, dim, cout)
+    assert torch.equal(p_fused, p_want)
+    if cin == cout:
+        p_fused.fill_(float("nan"))
+        _lib.conv3d(x_oct, pc.w, pc.b, res_oct, out_oct, B, dim, cin, cin, cout, 3,
+                    flags | _lib.IN_OCTET | _lib.OUT_OCTET | _lib.RES_OCTET, pool_out=p_fused)
+        assert torch.equal(p_fused, p_want)
+    with pytest.raises(_lib.HipExtensionError):      # other layouts are not instantiated with the pooled epilogue
+        _lib.conv3d(x, pc.w, pc.b, res, out, B, dim, cin, cin, cout, 3, flags, pool_out=p_fused)
     # shapes the 2-D kernel does not take refuse the flags
     small = torch.randn(1, 8, 8, 8, cin, device=DEV)
     with pytest.raises(_lib.HipExtensionError):
