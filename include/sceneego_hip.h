@@ -38,6 +38,7 @@ extern "C" {
 #define SE_IN_OCTET          32  /* se_conv3d_f32, k = 3 shapes with se_conv3d_f32_algo() == 2 only: `in` is octet-planar          */
 #define SE_OUT_OCTET         64  /* [B][C/8][D][D][D][8] (channel c at octet c/8, slot c%8) / `out` is written that way /          */
 #define SE_RES_OCTET         128 /* the skip tensor `residual` is read that way                                                 */
+#define SE_EPI_SKIPCONV16    256 /* set by se_conv3d_skip16_f32 only (not a caller flag of se_conv3d_f32)                       */
 
 /* ABI version; bumped on any signature change. */
 int se_abi_version(void);
@@ -128,6 +129,16 @@ int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const
 int se_conv3d_pool_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
                        float* out, float* pool_out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
                        float* workspace, long long workspace_elems, void* stream);
+
+/* 3x3x3 convolution + folded BN with the Res3DBlock's 1x1x1 skip convolution computed in the same launch (reference
+ * network/v2v.py:21-43: res_branch's second convolution and skip_con of a block whose channel count changes):
+ *     out = act( conv3(in; wpack) + skip_w . skip_in + bpack )
+ * `skip_in` is the block input, 16 channels, channels-last [B][D][D][D][16]; `skip_w` its BN-folded weights [cout][16];
+ * `bpack` must hold the SUM of both folded biases.  2-D Winograd shapes (se_conv3d_f32_algo() == 2) with octet-planar `in`
+ * and `out` only (flags must carry SE_IN_OCTET | SE_OUT_OCTET; SE_EPI_RELU optional); SE_ERR_BAD_ARG otherwise.  Saves the
+ * 1x1x1 launch, its output tensor and the skip-tensor read of the 3x3x3 convolution. */
+int se_conv3d_skip16_f32(const float* in, const float* wpack, const float* bpack, const float* skip_in, const float* skip_w,
+                         float* out, int batch, int dim, int cin, int cout, int flags, void* stream);
 
 /* Fused V2V tail: two 1x1x1 32->32 convs (+BN+ReLU) and the 1x1x1 32->cout3 output layer in one pass
  * (network/v2v.py:155-161 back_layers.1/.2 + output_layer :161,169).  in [B][D]^3[32]; out planar [B][cout3][D^3];

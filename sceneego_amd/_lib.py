@@ -42,6 +42,7 @@ SIGNATURES = {
     "se_conv3d_packed_elems": (_ll, [_i, _i, _i, _i]),
     "se_conv3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
     "se_conv3d_pool_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
+    "se_conv3d_skip16_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_pointwise_chain3_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "se_deconv3d_k2s2_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_maxpool3d_2_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -338,6 +339,17 @@ def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksi
     if _prof is not None:
         e1.record()
         _prof.append((("conv3d" if inp.dtype == torch.float32 else "conv3d_bf16", ksize, cin_pad, cout, dim), e0, e1))
+
+
+def conv3d_skip16(inp, wpack, bpack_sum, skip_in, skip_w, out, batch, dim, cin, cout, flags):
+    """3x3x3 convolution (2-D Winograd kernel, octet-planar in / out) + the block's 1x1x1 skip convolution over the 16-channel
+    channels-last ``skip_in`` in one launch (se_conv3d_skip16_f32); ``bpack_sum`` = sum of both folded biases."""
+    require_hip(inp, out, skip_in, skip_w, bpack_sum)
+    _chk_f32(inp, out, skip_in, skip_w, bpack_sum)
+    assert skip_in.shape[-1] == 16 and tuple(skip_w.shape) == (cout, 16) and skip_w.is_contiguous() and skip_in.is_contiguous()
+    with _timed(("conv3d", 3, cin, cout, dim)):
+        _check(load().se_conv3d_skip16_f32(_ptr(inp), _ptr(wpack), _ptr(bpack_sum), _ptr(skip_in), _ptr(skip_w), _ptr(out), batch,
+                                           dim, cin, cout, flags, _stream()), "se_conv3d_skip16_f32")
 
 
 def pointwise_chain3(inp, pc1, pc2, pc3, out, batch, dim):

@@ -751,7 +751,7 @@ int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s);
 #define g_variant_direct (g_variant == 18 ? 1 : 0)   // se_debug_set_variant(18): A/B, grid-level split-K for every small level
 
 static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpack, const float* residual, float* out,
-                           float* pool_out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
+                           float* pool_out, const float* skip_w, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
                            float* workspace, long long workspace_elems, void* stream) {
     if (batch <= 0 || dim <= 0 || cin <= 0 || cin_pad < cin || (cin_pad & 15) || cout <= 0) return SE_ERR_BAD_ARG;
     if (ksize != 1 && ksize != 3 && ksize != 7) return SE_ERR_BAD_ARG;
@@ -775,6 +775,9 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
     a.wpack_g = nullptr;
     if (ksize == 3 && cout % 32 == 0) a.wpack_g = a.wpack_e + (long long)(cin_pad / 16) * (cout / 32) * SE_WINO43_CHUNK_FLOATS;
     a.pool_out = pool_out;
+    a.skip_w = skip_w;
+    if (!skip_w && (flags & SE_EPI_SKIPCONV16)) return SE_ERR_BAD_ARG;
+    if (skip_w && (!residual || se_conv3d_f32_algo(dim, cin, cout, ksize) != 2 || cin_pad != cin)) return SE_ERR_BAD_ARG;
     if (pool_out && ((dim & 1) || se_conv3d_f32_algo(dim, cin, cout, ksize) != 2 || cin_pad != cin)) return SE_ERR_BAD_ARG;   // only the 2-D Winograd kernel pools
     if (ksize == 3 && (cout % 32)) a.wpack_b = nullptr;
     if (ksize == 1) a.wpack_b = nullptr;
@@ -822,7 +825,7 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
 extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
                              float* out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
                              float* workspace, long long workspace_elems, void* stream) {
-    return conv3d_f32_impl(in, wpack, bpack, residual, out, nullptr, batch, dim, cin, cin_pad, cout, ksize, flags, workspace,
+    return conv3d_f32_impl(in, wpack, bpack, residual, out, nullptr, nullptr, batch, dim, cin, cin_pad, cout, ksize, flags, workspace,
                            workspace_elems, stream);
 }
 
@@ -832,8 +835,18 @@ extern "C" int se_conv3d_pool_f32(const float* in, const float* wpack, const flo
                                   float* out, float* pool_out, int batch, int dim, int cin, int cin_pad, int cout, int ksize,
                                   int flags, float* workspace, long long workspace_elems, void* stream) {
     if (!pool_out) return SE_ERR_BAD_ARG;
-    return conv3d_f32_impl(in, wpack, bpack, residual, out, pool_out, batch, dim, cin, cin_pad, cout, ksize, flags, workspace,
+    return conv3d_f32_impl(in, wpack, bpack, residual, out, pool_out, nullptr, batch, dim, cin, cin_pad, cout, ksize, flags, workspace,
                            workspace_elems, stream);
+}
+
+extern "C" int se_conv3d_skip16_f32(const float* in, const float* wpack, const float* bpack, const float* skip_in,
+                                    const float* skip_w, float* out, int batch, int dim, int cin, int cout, int flags,
+                                    void* stream) {
+    if (!skip_in || !skip_w) return SE_ERR_BAD_ARG;
+    if ((flags & (SE_IN_OCTET | SE_OUT_OCTET)) != (SE_IN_OCTET | SE_OUT_OCTET)) return SE_ERR_BAD_ARG;
+    if (flags & ~(SE_IN_OCTET | SE_OUT_OCTET | SE_EPI_RELU)) return SE_ERR_BAD_ARG;
+    return conv3d_f32_impl(in, wpack, bpack, skip_in, out, nullptr, skip_w, batch, dim, cin, cin, cout, 3,
+                           flags | SE_EPI_SKIPCONV16, nullptr, 0, stream);
 }
 
 extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
@@ -851,6 +864,7 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
     a.wpack_f = nullptr;
     a.wpack_g = nullptr;
     a.pool_out = nullptr;
+    a.skip_w = nullptr;
     // all eight sub-positions per workgroup where that still fills the chip (measured at B=8: 64->32 from 32^3, 2048 workgroups,
     // 0.241 -> 0.149 ms = 4.05 TB/s; the 128->128 levels, 1..64 workgroups, 0.02 -> 0.14 ms: those keep the grid.z form, whose 8x
     // more workgroups matter more than the input re-reads there)

@@ -650,7 +650,7 @@ int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) 
         // floats per voxel of the input: channels-last record, or 3 x ceil(cin/3) planes for the triplet-planar 7^3 input
         sl.in = a.in + (long long)b0 * vox * ((a.flags & SE_IN_PLANAR3) ? (a.cin + 2) / 3 * 3 : a.cin_pad);
         sl.out = a.out + (long long)b0 * vox * a.cout;
-        if (a.res) sl.res = a.res + (long long)b0 * vox * a.cout;
+        if (a.res) sl.res = a.res + (long long)b0 * vox * ((a.flags & SE_EPI_SKIPCONV16) ? 16 : a.cout);
         if (a.pool_out) sl.pool_out = a.pool_out + (long long)b0 * (vox / 8) * a.cout;
         sl.total_vox = (long long)nb * vox;
         const int rc = tiled_try_one(sl, nb, ksize, s);

@@ -102,14 +102,15 @@ constexpr int rider_raw_count(int gg, int g) {
 // bit 2: no epilogue memory traffic - all three give wrong results and exist only to attribute time)
 // LAYOUT: bit 0 = input is octet-planar [B][cin/8][D][D][D][8] (SE_IN_OCTET), bit 1 = output is octet-planar (SE_OUT_OCTET),
 // bit 2 = the skip tensor is octet-planar (SE_RES_OCTET), bit 3 = also write the 2x2x2 max-pool of the output (se_conv3d_pool_f32;
-// instantiated for the layouts the V2V program pools: 3 and 7).
+// instantiated for the layouts the V2V program pools: 3 and 7), bit 4 = the skip path is a 1x1x1 convolution over a 16-channel
+// channels-last tensor computed in the epilogue (se_conv3d_skip16_f32; instantiated for layout 3).
 // In the octet-planar form an 8-channel chunk of a halo row is ONE contiguous run (18 positions x 32 B) instead of 18 pieces of
 // 32 B at a 4*cin-byte stride: 4x fewer cache lines per load instruction.
 template <int EXP, int LAYOUT>
 __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const float* __restrict__ wg, int tiles_x, int tiles_y,
                                                                int tiles_z, int total_tiles, int n_units, int units_per_wg, unsigned long long* dbg) {
     constexpr int exp = EXP;
-    constexpr bool in_oct = LAYOUT & 1, out_oct = LAYOUT & 2, res_oct = LAYOUT & 4, pool = LAYOUT & 8;
+    constexpr bool in_oct = LAYOUT & 1, out_oct = LAYOUT & 2, res_oct = LAYOUT & 4, pool = LAYOUT & 8, skc = LAYOUT & 16;
     unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, t8 = 0, st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5; (void)t6; (void)t7; (void)t8; (void)st; (void)dbg;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -310,7 +311,21 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
 
     // output transform (A^T along y, then along z), bias, residual, ReLU, 8 x 16-byte channels-last stores
     // skip tensor + bias of a finished tile, issued in front of the staging phase's mid barrier
+    // fused 1x1x1 skip convolution (skc): `a.res` is its 16-channel channels-last input x, `a.skip_w` its folded weights [cout][16].
+    // The epilogue adds W_skip x to the outputs with 4 MFMAs per output vector: A = weights (row = cout, k lane h carries input
+    // channels 4h..4h+3, one per k step), B = x (column = voxel, same channel split): both operands are one 16-byte load per lane.
+    f32x4 wsk = {0.f, 0.f, 0.f, 0.f};
     auto epi_prefetch = [&](const Unit& u, f32x4 (&resv)[2][4]) {
+        if constexpr (skc) {
+            wsk = *reinterpret_cast<const f32x4*>(a.skip_w + (u.cb * 32 + ct * 16 + px) * 16 + 4 * h);
+            const float* xb = a.res + (((((long long)u.b * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * 16);
+            const int xvoff = px * 16 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int z = 0; z < 4; ++z) resv[r][z] = *reinterpret_cast<const f32x4*>(xb + z * dim * dim * 16 + r * dim * 16 + xvoff);
+            return;
+        }
         if (!use_res || (exp & 4) || (exp & 0x20000)) {          // no skip tensor: add zeros (the epilogue has no per-element selects)
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -370,13 +385,22 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (skc) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)          // k step outer: the eight accumulators alternate (no dependent back-to-back MFMAs)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int z = 0; z < 4; ++z)
+                        out[r][z] = __builtin_amdgcn_mfma_f32_16x16x4f32(wsk[ks], resv_all[r][z][ks], out[r][z], 0, 0, 0);
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
 #pragma unroll
             for (int z = 0; z < 4; ++z) {
                 f32x4 v = out[r][z];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c] + resv_all[r][z][c], relu_lo);
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(skc ? v[c] : v[c] + resv_all[r][z][c], relu_lo);
                 if (!(exp & (4 | 0x40000)) || v.x == 12345.f) *reinterpret_cast<f32x4*>(ob + z * zstride + r * ystride + voff) = v;
                 out[r][z] = v;
             }
@@ -731,6 +755,12 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
         return 0;
     }
 #endif
+    if (a.flags & SE_EPI_SKIPCONV16) {
+        if (layout != 3 || a.pool_out || !a.skip_w || !a.res) return SE_ERR_BAD_ARG;
+        W2_LAUNCH(0, 19);
+        SE_CHECK_LAUNCH();
+        return 0;
+    }
     if (a.pool_out) {
         if (layout == 3) W2_LAUNCH(0, 11);
         else if (layout == 7) W2_LAUNCH(0, 15);

@@ -45,6 +45,7 @@ struct ConvArgs {
     const float* wpack_d;  // k = 7, cout <= 16: Winograd F(2,7) section D [chunk4][g13][xi8][lane][4] (else NULL)
     const float* wpack_f;  // k = 7, cout <= 16: Winograd F(4,7) section F [chunk3][g13][xi10][lane][3] (else NULL)
     const float* wpack_g;  // k = 3, cout % 32 == 0: 2-D Winograd F(4,3) x F(2,3) section G (else NULL)
+    const float* skip_w;   // SE_EPI_SKIPCONV16: folded 1x1x1 skip weights [cout][16]; `res` then is the skip convolution's 16-channel input
     float* pool_out;       // 2-D Winograd kernel only: also write max_pool3d(out, 2, 2), channels-last [B][D/2][D/2][D/2][cout] (else NULL)
     const float* bpack;
     const float* res;

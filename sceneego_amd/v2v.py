@@ -194,6 +194,7 @@ class V2VProgram:
         self.cout = model.output_channels
         self.cin = model.input_channels
         self.cin_pad = _round8(self.cin) if dtype == torch.bfloat16 else _round16(self.cin)
+        self._fused_skip = {}
         fl, ed, bl = model.front_layers, model.encoder_decoder, model.back_layers
         basic = lambda m, cin_pad=None: _PackedConv(m.block[0], m.block[1], cin_pad, dtype)
         self.front0 = basic(fl[0], self.cin_pad)
@@ -214,6 +215,12 @@ class V2VProgram:
         c1 = _PackedConv(m.res_branch[0], m.res_branch[1], None, self.dtype)
         c2 = _PackedConv(m.res_branch[3], m.res_branch[4], None, self.dtype)
         sk = _PackedConv(m.skip_con[0], m.skip_con[1], None, self.dtype) if len(m.skip_con) else None
+        if sk is not None and sk.cin == 16 and self.dtype == torch.float32:
+            # 16-channel skip convolution (front_layers.1): folded weights [cout][16] + summed bias for se_conv3d_skip16_f32, which
+            # computes the skip path inside the second 3x3x3 convolution's launch
+            conv, bn = m.skip_con[0], m.skip_con[1]
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
+            self._fused_skip[id(sk)] = ((conv.weight.detach().float().reshape(sk.cout, 16) * scale[:, None]).contiguous(), (c2.b + sk.b).contiguous())
         return (c1, c2, sk)
 
     # -- primitive launches ------------------------------------------------------------------
@@ -239,6 +246,11 @@ class V2VProgram:
         assert sk is None or not x_oct           # the 1x1x1 skip convolution reads channels-last
         mid = _lib.OUT_OCTET if w2d else 0
         a = self._conv(x, c1, B, dim, _lib.EPI_RELU | mid | (_lib.IN_OCTET if x_oct else 0))
+        fused = self._fused_skip.get(id(sk)) if sk is not None else None
+        if fused is not None and w2d and out_oct and pool_out is None and not x_oct:
+            out = torch.empty((B, dim, dim, dim, c2.cout), device=self.device, dtype=self.dtype)
+            _lib.conv3d_skip16(a, c2.w, fused[1], x, fused[0], out, B, dim, c2.cin, c2.cout, _lib.EPI_RELU | _lib.IN_OCTET | _lib.OUT_OCTET)
+            return out
         s = x if sk is None else self._conv(x, sk, B, dim, 0)
         f2 = _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | (_lib.IN_OCTET if w2d else 0)
         if x_oct and sk is None:

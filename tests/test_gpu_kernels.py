@@ -474,6 +474,35 @@ def test_gather_planar3_other_channel_counts(channels):
     assert float(flat[..., channels:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,dim", [(1, 16), (2, 32), (33, 16)])
+def test_conv3d_fused_skip_convolution(B, dim):
+    """se_conv3d_skip16_f32: the 3x3x3 convolution with the block's 1x1x1 skip convolution (16 -> 32 channels) computed in its
+    epilogue equals conv3(in) + conv1(x) + biases, ReLU (reference network/v2v.py:40-43); the skip path runs on the MFMA in a
+    different summation order than the separate launch, hence a tolerance (2e-5 of the output range)."""
+    torch.manual_seed(dim)
+    cin, cout = 32, 32
+    conv = nn.Conv3d(cin, cout, 3, padding=1).to(DEV)
+    skip = nn.Conv3d(16, cout, 1).to(DEV)
+    bn, bns = _rand_bn(cout, 3).to(DEV), _rand_bn(cout, 4).to(DEV)
+    pc, ps = _PackedConv(conv, bn), _PackedConv(skip, bns)
+    a = torch.randn(B, dim, dim, dim, cin, device=DEV)
+    x = torch.randn(B, dim, dim, dim, 16, device=DEV)
+    s_out = torch.empty(B, dim, dim, dim, cout, device=DEV)
+    _lib.conv3d(x, ps.w, ps.b, None, s_out, B, dim, 16, 16, cout, 1, 0)
+    want = torch.empty_like(s_out)
+    _lib.conv3d(a, pc.w, pc.b, s_out, want, B, dim, cin, cin, cout, 3, _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU)
+    scale = (bns.weight / torch.sqrt(bns.running_var + bns.eps)).detach()
+    w_skip = (skip.weight.detach().reshape(cout, 16) * scale[:, None]).contiguous()
+    a_oct = a.view(B, dim, dim, dim, cin // 8, 8).permute(0, 4, 1, 2, 3, 5).contiguous()
+    got_oct = torch.empty(B, cout // 8, dim, dim, dim, 8, device=DEV)
+    _lib.conv3d_skip16(a_oct, pc.w, (pc.b + ps.b).contiguous(), x, w_skip, got_oct, B, dim, cin, cout,
+                       _lib.EPI_RELU | _lib.IN_OCTET | _lib.OUT_OCTET)
+    got = got_oct.permute(0, 2, 3, 4, 1, 5).reshape(B, dim, dim, dim, cout)
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    with pytest.raises(_lib.HipExtensionError):      # channels-last output is not instantiated for the fused form
+        _lib.conv3d_skip16(a_oct, pc.w, pc.b, x, w_skip, want, B, dim, cin, cout, _lib.EPI_RELU | _lib.IN_OCTET)
+
+
 # (34, 16, 32, 32): more samples than one launch takes (slices of 32), so every per-slice pointer is exercised
 @pytest.mark.parametrize("B,dim,cin,cout", [(1, 16, 32, 32), (2, 32, 16, 32), (1, 16, 64, 128), (34, 16, 32, 32)])
 def test_conv3d_octet_planar_forms_match_channels_last(B, dim, cin, cout):
