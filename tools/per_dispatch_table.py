@@ -14,7 +14,7 @@ import sys
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kind"] == "KERNEL_DISPATCH"]
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-OURS = ("conv3d_", "deconv3d_", "maxpool2", "pointwise_chain3", "softargmax_", "gather_", "voxelize_", "splitk_reduce")
+OURS = ("conv3d_", "deconv3d_", "maxpool2", "pointwise_chain3", "softargmax_", "::gather_", "voxelize_", "splitk_reduce")
 
 
 def short(n):
@@ -25,7 +25,7 @@ def short(n):
 steps, cur = [], None
 for r in rows:
     n = r["Kernel_Name"]
-    if "gather_" in n or "voxelize_kernel" in n:      # first HIP kernel of a forward
+    if "::gather_" in n or "voxelize_kernel" in n:      # first HIP kernel of a forward
         if cur is None or any("conv3d_k7" in x[0] for x in cur):
             cur = []
             steps.append(cur)
