@@ -147,6 +147,15 @@ int se_pointwise_chain3_f32(const float* in, const float* wpack1, const float* b
                             const float* wpack2, const float* bpack2, const float* wpack3, const float* bpack3,
                             float* out, int batch, int dim, int cout3, void* stream);
 
+/* se_pointwise_chain3_f32 with pass 1 of se_softargmax3d_f32 (mode 1: softmax) folded in: the logits are written to `out` as
+ * before and, while still in registers, reduced to the per-chunk partial records in `scratch`
+ * (se_softargmax3d_scratch_elems(batch * cout3) floats).  `coord` = [dim^3][3] voxel-centre coordinates.  Finish with
+ * se_softargmax3d_finish_f32(out, scratch, ...).  Replaces the back_layers / output_layer chain of network/v2v.py:155-161
+ * together with the first half of utils/op.py:83-96. */
+int se_pointwise_chain3_softargmax_f32(const float* in, const float* wpack1, const float* bpack1, const float* wpack2,
+                                       const float* bpack2, const float* wpack3, const float* bpack3, float* out,
+                                       const float* coord, float* scratch, int batch, int dim, int cout3, void* stream);
+
 /* ConvTranspose3d(k=2, s=2) + folded BN + ReLU (+ skip).  Replaces Upsample3DBlock and the decoder
  * adds (network/v2v.py:55-67,124-137).  in [B][D]^3[cin] -> out [B][2D]^3[cout]; residual like out. */
 int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
@@ -165,6 +174,10 @@ int se_maxpool3d_2_octin_f32(const float* in, float* out, int batch, int dim, in
  *   scratch: se_softargmax3d_scratch_elems(rows) floats of workspace.                              */
 int se_softargmax3d_f32(const float* vol, const float* coord, float* out_vol, float* joints,
                         float* scratch, int rows, int voxels, int mode, void* stream);
+
+/* Pass 2 of se_softargmax3d_f32 alone (softmaxed volumes + joints from the partial records in `scratch`). */
+int se_softargmax3d_finish_f32(const float* vol, const float* scratch, float* out_vol, float* joints, int rows, int voxels,
+                               int mode, void* stream);
 long long se_softargmax3d_scratch_elems(int rows);
 
 /* Producers of the triplet-planar float32 V2V input [B][triplets_total][voxels][3] (SE_IN_PLANAR3; the 7^3 front layer

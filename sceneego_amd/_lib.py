@@ -49,6 +49,8 @@ SIGNATURES = {
     "se_maxpool3d_2_octin_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "se_softargmax3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "se_softargmax3d_scratch_elems": (_ll, [_i]),
+    "se_softargmax3d_finish_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "se_pointwise_chain3_softargmax_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "se_conv3d_pack_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_packed_elems_bf16": (_ll, [_i, _i, _i, _i]),
     "se_conv3d_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -352,10 +354,22 @@ def conv3d_skip16(inp, wpack, bpack_sum, skip_in, skip_w, out, batch, dim, cin, 
                                            dim, cin, cout, flags, _stream()), "se_conv3d_skip16_f32")
 
 
-def pointwise_chain3(inp, pc1, pc2, pc3, out, batch, dim):
-    """back_layers.1 -> back_layers.2 -> output_layer in one launch; pc* are packed 1x1x1 convs (32->32, 32->32, 32->J)."""
+def pointwise_chain3(inp, pc1, pc2, pc3, out, batch, dim, softargmax=None):
+    """back_layers.1 -> back_layers.2 -> output_layer in one launch; pc* are packed 1x1x1 convs (32->32, 32->32, 32->J).
+    ``softargmax`` = (coord [dim^3, 3], scratch): float32 only - the launch also writes pass 1 of the soft-argmax (softmax mode) into
+    ``scratch``; finish with softargmax3d_finish."""
     require_hip(inp, out)
     assert out.dtype == torch.float32
+    if softargmax is not None:
+        coord, scratch = softargmax
+        require_hip(coord, scratch)
+        _chk_f32(inp, coord, scratch)
+        assert scratch.numel() >= softargmax3d_scratch_elems(batch * pc3.cout) and coord.numel() == 3 * dim ** 3
+        with _timed(("tail", 1, 32, pc3.cout, dim)):
+            _check(load().se_pointwise_chain3_softargmax_f32(_ptr(inp), _ptr(pc1.w), _ptr(pc1.b), _ptr(pc2.w), _ptr(pc2.b), _ptr(pc3.w),
+                                                             _ptr(pc3.b), _ptr(out), _ptr(coord), _ptr(scratch), batch, dim, pc3.cout,
+                                                             _stream()), "se_pointwise_chain3_softargmax_f32")
+        return
     fn = load().se_pointwise_chain3_bf16 if inp.dtype == torch.bfloat16 else load().se_pointwise_chain3_f32
     with _timed(("tail" + _tag(inp), 1, 32, pc3.cout, dim)):
         _check(fn(_ptr(inp), _ptr(pc1.w), _ptr(pc1.b), _ptr(pc2.w), _ptr(pc2.b), _ptr(pc3.w),
@@ -384,6 +398,14 @@ def maxpool3d_2(inp, out, batch, dim, channels, in_octet=False):
 
 def softargmax3d_scratch_elems(rows) -> int:
     return int(load().se_softargmax3d_scratch_elems(rows))
+
+
+def softargmax3d_finish(vol, scratch, out_vol, joints, rows, voxels, mode):
+    """Pass 2 of the soft-argmax from partial records written by pointwise_chain3(..., softargmax=...)."""
+    require_hip(vol, scratch, out_vol, joints)
+    _chk_f32(vol, scratch, out_vol, joints)
+    _check(load().se_softargmax3d_finish_f32(_ptr(vol), _ptr(scratch), _ptr(out_vol), _ptr(joints), rows, voxels, mode, _stream()),
+           "se_softargmax3d_finish_f32")
 
 
 def softargmax3d(vol, coord, out_vol, joints, rows, voxels, mode, scratch=None):

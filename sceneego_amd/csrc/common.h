@@ -34,6 +34,10 @@ inline int se_current_device() {
     int d = 0;
     return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : 0;
 }
+// soft-argmax pass-1 partials (softargmax.hip, conv3d.hip): chunks per (sample, joint) row and floats per record (m, l, sx, sy, sz, pad)
+#define SE_SA_SPLITS 32
+#define SE_SA_PART 8
+
 inline int se_num_cus() {
     static std::atomic<int> cus[64];
     const int d = se_current_device();

@@ -618,6 +618,122 @@ __global__ __launch_bounds__(256) void pointwise_chain3_kernel(const float* __re
     }
 }
 
+// The same chain with pass 1 of the soft-argmax (reference utils/op.py:83-96) folded in: the workgroup (chunk s, sample b) owns the
+// voxels [s * chunk, (s+1) * chunk) of its sample - the chunking of softargmax_partial_kernel - keeps a running
+// (max, sum exp, sum exp * coord) per lane and joint while the logits are still in registers (online softmax: a new maximum
+// rescales the sums), folds the lanes in a fixed order and writes the SE_SA_PART record softargmax_finish_kernel reads.  The
+// logits are stored as before (forward() returns the softmaxed volumes, pass 2 reads them) but are not read back for pass 1.
+constexpr int PW_SA_WAVES = 16;      // waves per workgroup of pointwise_chain3_sa_kernel (one workgroup per CU: 4 waves per SIMD)
+__global__ __launch_bounds__(PW_SA_WAVES * 64) void pointwise_chain3_sa_kernel(const float* __restrict__ in, const float* __restrict__ w1,
+                                                                  const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                  const float* __restrict__ b2, const float* __restrict__ w3,
+                                                                  const float* __restrict__ b3, float* __restrict__ out,
+                                                                  const float* __restrict__ coord, float* __restrict__ scratch,
+                                                                  int vox_per_b, int chunk, int cout3) {
+    extern __shared__ __attribute__((aligned(16))) float pw_sa_lds[];
+    float (*red)[64][20] = reinterpret_cast<float (*)[64][20]>(pw_sa_lds);        // [PW_SA_WAVES][64][20]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int vl = lane & 15, h = lane >> 4;
+    const int s = blockIdx.x, b = blockIdx.y;
+    const int v0 = s * chunk, v1 = min(v0 + chunk, vox_per_b);
+    const f32x4* W1 = reinterpret_cast<const f32x4*>(w1) + lane;
+    const f32x4* W2 = reinterpret_cast<const f32x4*>(w2) + lane;
+    const f32x4* W3 = reinterpret_cast<const f32x4*>(w3) + lane;
+    const float* inb = in + (long long)b * vox_per_b * 32;
+    float m[4], l[4], sx[4], sy[4], sz[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = sx[r] = sy[r] = sz[r] = 0.f; }
+    f32x4 xn[2];
+    {
+        const int n0 = v0 + wave * 16 + vl;
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg)
+            xn[cg] = n0 < v1 ? *reinterpret_cast<const f32x4*>(inb + (long long)n0 * 32 + cg * 16 + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int t0 = v0 + wave * 16; t0 < v1; t0 += PW_SA_WAVES * 16) {
+        const int n = t0 + vl;
+        const bool ok = n < v1;
+        f32x4 x[2], y[2];
+        x[0] = xn[0]; x[1] = xn[1];
+        {
+            const int nn = n + PW_SA_WAVES * 16;
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg)
+                xn[cg] = nn < v1 ? *reinterpret_cast<const f32x4*>(inb + (long long)nn * 32 + cg * 16 + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        if (ok) { cx = coord[(size_t)n * 3]; cy = coord[(size_t)n * 3 + 1]; cz = coord[(size_t)n * 3 + 2]; }
+#define SE_PW_LAYER(W, B, X, Y)                                                                 \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                          \
+        f32x4 acc = *reinterpret_cast<const f32x4*>(B + nt * 16 + 4 * h);                       \
+        _Pragma("unroll") for (int cg = 0; cg < 2; ++cg) {                                      \
+            const f32x4 wf = W[(cg * 2 + nt) * 64];                                             \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, X[cg].x, acc, 0, 0, 0);            \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, X[cg].y, acc, 0, 0, 0);            \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, X[cg].z, acc, 0, 0, 0);            \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, X[cg].w, acc, 0, 0, 0);            \
+        }                                                                                       \
+        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); \
+        Y[nt] = acc;                                                                            \
+    }
+        SE_PW_LAYER(W1, b1, x, y)
+        SE_PW_LAYER(W2, b2, y, x)
+#undef SE_PW_LAYER
+        f32x4 acc = *reinterpret_cast<const f32x4*>(b3 + 4 * h);
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+            const f32x4 wf = W3[cg * 64];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, x[cg].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, x[cg].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, x[cg].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, x[cg].w, acc, 0, 0, 0);
+        }
+        if (ok) {
+            float* o = out + ((long long)b * cout3 + 4 * h) * vox_per_b + n;
+            const float vv[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (4 * h + r < cout3) {
+                    o[(long long)r * vox_per_b] = vv[r];
+                    if (vv[r] > m[r]) {      // new running maximum (rare after the first tiles): rescale the sums; the first element
+                        const float sc = __expf(m[r] - vv[r]);                            // meets m = -inf: exp(-inf) = 0 clears them
+                        l[r] *= sc; sx[r] *= sc; sy[r] *= sc; sz[r] *= sc;
+                        m[r] = vv[r];
+                    }
+                    const float e = __expf(vv[r] - m[r]);
+                    l[r] += e;
+                    sx[r] = fmaf(e, cx, sx[r]);
+                    sy[r] = fmaf(e, cy, sy[r]);
+                    sz[r] = fmaf(e, cz, sz[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float* e = &red[wave][lane][r * 5];
+        e[0] = m[r]; e[1] = l[r]; e[2] = sx[r]; e[3] = sy[r]; e[4] = sz[r];
+    }
+    __syncthreads();
+    const int j = threadIdx.x;
+    if (j < cout3) {          // joint j: the 16 x PW_SA_WAVES (wave, voxel lane) partials of k lane j / 4, slot j % 4, folded in a fixed order
+        const int hh = j >> 2, rr = (j & 3) * 5;
+        float M = -INFINITY;
+        for (int w = 0; w < PW_SA_WAVES; ++w)
+            for (int q = 0; q < 16; ++q) M = fmaxf(M, red[w][hh * 16 + q][rr]);
+        float L = 0.f, SX = 0.f, SY = 0.f, SZ = 0.f;
+        for (int w = 0; w < PW_SA_WAVES; ++w)
+            for (int q = 0; q < 16; ++q) {
+                const float* e = &red[w][hh * 16 + q][rr];
+                const float f = (e[0] == -INFINITY) ? 0.f : __expf(e[0] - M);     // a lane that saw no voxel contributes nothing
+                L += e[1] * f; SX += e[2] * f; SY += e[3] * f; SZ += e[4] * f;
+            }
+        float* p = scratch + (((size_t)b * cout3 + j) * SE_SA_SPLITS + s) * SE_SA_PART;
+        p[0] = M; p[1] = L; p[2] = SX; p[3] = SY; p[4] = SZ;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // max-pool 2x2x2 stride 2, channels-last, 16 B per lane
 // ------------------------------------------------------------------------------------------------
@@ -905,6 +1021,25 @@ extern "C" int se_pointwise_chain3_f32(const float* in, const float* wpack1, con
     const unsigned grid = (unsigned)((tiles + 3) / 4 < 8192 ? (tiles + 3) / 4 : 8192);
     hipLaunchKernelGGL(pointwise_chain3_kernel, dim3(grid), dim3(256), 0, se_stream(stream), in, wpack1, bpack1, wpack2, bpack2,
                        wpack3, bpack3, out, total, vox_per_b, cout3);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+// se_pointwise_chain3_f32 + pass 1 of se_softargmax3d_f32 (mode 1) in one launch: `scratch` receives the partial records
+// (se_softargmax3d_scratch_elems(batch * cout3) floats); finish with se_softargmax3d_finish_f32.  `coord` [dim^3][3].
+extern "C" int se_pointwise_chain3_softargmax_f32(const float* in, const float* wpack1, const float* bpack1, const float* wpack2,
+                                                  const float* bpack2, const float* wpack3, const float* bpack3, float* out,
+                                                  const float* coord, float* scratch, int batch, int dim, int cout3,
+                                                  void* stream) {
+    if (batch <= 0 || dim <= 0 || cout3 <= 0 || cout3 > 16 || !coord || !scratch) return SE_ERR_BAD_ARG;
+    const long long vox_per_b = (long long)dim * dim * dim;
+    if (vox_per_b >= (1LL << 31) || (vox_per_b & 3)) return SE_ERR_BAD_ARG;
+    const int chunk = (int)((((vox_per_b + SE_SA_SPLITS - 1) / SE_SA_SPLITS) + 3) & ~3LL);      // as softargmax.hip
+    if (chunk & 15) return SE_ERR_BAD_ARG;                                                       // whole 16-voxel tiles per chunk
+    constexpr int LDS = PW_SA_WAVES * 64 * 20 * 4;
+    SE_ENSURE_LDS(pointwise_chain3_sa_kernel, LDS);
+    hipLaunchKernelGGL(pointwise_chain3_sa_kernel, dim3(SE_SA_SPLITS, batch), dim3(PW_SA_WAVES * 64), LDS, se_stream(stream), in, wpack1, bpack1,
+                       wpack2, bpack2, wpack3, bpack3, out, coord, scratch, (int)vox_per_b, chunk, cout3);
     SE_CHECK_LAUNCH();
     return 0;
 }

@@ -8,8 +8,8 @@
 //           (bitwise deterministic), writes exp(v-M)/L; chunk 0 also writes the joint.
 #include "common.h"
 
-#define SE_SA_SPLITS 32
-#define SE_SA_PART 8  // floats per partial record: m, l, sx, sy, sz, pad
+// SE_SA_SPLITS / SE_SA_PART (chunks per row, floats per partial record: m, l, sx, sy, sz, pad): common.h - the fused V2V tail
+// (pointwise_chain3_sa_kernel in conv3d.hip) writes the same records
 
 namespace {
 
@@ -137,6 +137,16 @@ extern "C" int se_softargmax3d_f32(const float* vol, const float* coord, float* 
     hipLaunchKernelGGL(softargmax_partial_kernel, grid, dim3(256), 0, s, vol, coord, scratch, voxels, mode);
     SE_CHECK_LAUNCH();
     hipLaunchKernelGGL(softargmax_finish_kernel, grid, dim3(256), 0, s, vol, scratch, out_vol, joints, voxels, mode);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+// Pass 2 alone: for callers whose pass-1 partials were written by another kernel (se_pointwise_chain3_softargmax_f32).
+extern "C" int se_softargmax3d_finish_f32(const float* vol, const float* scratch, float* out_vol, float* joints, int rows,
+                                          int voxels, int mode, void* stream) {
+    if (rows <= 0 || voxels <= 0 || (voxels & 3) || (mode != 0 && mode != 1)) return SE_ERR_BAD_ARG;
+    hipStream_t s = se_stream(stream);
+    hipLaunchKernelGGL(softargmax_finish_kernel, dim3(SE_SA_SPLITS, rows), dim3(256), 0, s, vol, scratch, out_vol, joints, voxels, mode);
     SE_CHECK_LAUNCH();
     return 0;
 }

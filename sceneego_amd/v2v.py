@@ -276,7 +276,7 @@ class V2VProgram:
         return out
 
     # -- the network -------------------------------------------------------------------------
-    def run(self, x, B, G, out=None):
+    def run(self, x, B, G, out=None, softargmax=None):
         """x: [B,G,G,G,cin_pad] channels-last (channels >= cin zero; bf16: octet-planar [B,cin_pad/8,G,G,G,8]; float32 may
         also be triplet-planar [B,ceil(cin/3),G,G,G,3], which the 7^3 front layer reads with ~5x fewer cache-line requests)
         -> planar logits [B,cout,G^3]."""
@@ -330,7 +330,8 @@ class V2VProgram:
             out = torch.empty((B, self.cout, G * G * G), device=self.device, dtype=torch.float32)
         if self.cout <= 16:
             # back_layers.1 / .2 / output_layer fused: one read of x, one planar write of the logits
-            _lib.pointwise_chain3(x, self.back1, self.back2, self.out, out, B, G)
+            # ``softargmax`` = (coord, scratch): float32 program only - pass 1 of the soft-argmax rides in the same launch
+            _lib.pointwise_chain3(x, self.back1, self.back2, self.out, out, B, G, softargmax=softargmax if self.dtype == torch.float32 else None)
             return out
         x = self._conv(x, self.back1, B, G, _lib.EPI_RELU)
         x = self._conv(x, self.back2, B, G, _lib.EPI_RELU)

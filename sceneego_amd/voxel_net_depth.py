@@ -306,15 +306,23 @@ class VoxelNetwork_depth(nn.Module):
         if xb is not None:
             xb.copy_(x.view(B, G, G, G, prog.cin_pad // 8, 8).permute(0, 4, 1, 2, 3, 5))
             x = xb
+        # float32 V2V with softmax volumes and no logit scaling: pass 1 of the soft-argmax is computed by the V2V tail launch while
+        # the logits are in registers (se_pointwise_chain3_softargmax_f32); otherwise the two-pass kernel reads them back
+        fused_sa = (prog.dtype == torch.float32 and self.volume_softmax and self.volume_multiplier == 1.0 and prog.cout <= 16
+                    and ((N + 31) // 32 + 3) // 4 * 4 % 16 == 0)
+        sa_scratch = torch.empty(_lib.softargmax3d_scratch_elems(B * self.num_joints), device=dev, dtype=torch.float32) if fused_sa else None
         with _lib.stage("v2v"):
-            logits = prog.run(x, B, G)                                           # [B,J,N] planar
+            logits = prog.run(x, B, G, softargmax=(self._coord_flat, sa_scratch) if fused_sa else None)   # [B,J,N] planar
         if self.volume_multiplier != 1.0:
             logits = logits * self.volume_multiplier
         joints = torch.empty((B, self.num_joints, 3), device=dev, dtype=torch.float32)
         volumes = torch.empty_like(logits)
         with _lib.stage("softargmax"):
-            _lib.softargmax3d(logits, self._coord_flat, volumes, joints, B * self.num_joints, N,
-                              1 if self.volume_softmax else 0)
+            if fused_sa:
+                _lib.softargmax3d_finish(logits, sa_scratch, volumes, joints, B * self.num_joints, N, 1)
+            else:
+                _lib.softargmax3d(logits, self._coord_flat, volumes, joints, B * self.num_joints, N,
+                                  1 if self.volume_softmax else 0)
         volumes = volumes.view(B, self.num_joints, G, G, G)
 
         features = feat2d

@@ -355,6 +355,36 @@ def test_pointwise_chain_matches_separate_layers():
     assert float((out.cpu().view(2, 15, 8, 8, 8) - want).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("B,G", [(2, 32), (1, 64)])
+def test_pointwise_chain_with_softargmax_pass1(B, G):
+    """se_pointwise_chain3_softargmax_f32: same logits as the plain chain, bit for bit, and its pass-1 records give the same joints
+    and softmaxed volumes through se_softargmax3d_finish_f32 as the two-pass kernel on those logits (online softmax: a different
+    summation order, hence 1e-5 relative on the volumes and 2e-6 m on the joints)."""
+    torch.manual_seed(G)
+    c1, c2, c3 = nn.Conv3d(32, 32, 1), nn.Conv3d(32, 32, 1), nn.Conv3d(32, 15, 1)
+    with torch.no_grad():
+        c3.weight.mul_(6.0)                       # peaky logits: the running maximum changes often
+    p1 = _PackedConv(c1.to(DEV), _rand_bn(32, 1).to(DEV))
+    p2 = _PackedConv(c2.to(DEV), _rand_bn(32, 2).to(DEV))
+    p3 = _PackedConv(c3.to(DEV), None)
+    N = G ** 3
+    x = torch.randn(B, G, G, G, 32, device=DEV)
+    coord = (torch.rand(N, 3, device=DEV) - 0.5) * 2.0
+    ref = torch.empty(B, 15, N, device=DEV)
+    _lib.pointwise_chain3(x, p1, p2, p3, ref, B, G)
+    vol_ref, j_ref = torch.empty_like(ref), torch.empty(B, 15, 3, device=DEV)
+    _lib.softargmax3d(ref, coord, vol_ref, j_ref, B * 15, N, 1)
+    out = torch.full_like(ref, float("nan"))
+    scratch = torch.full((_lib.softargmax3d_scratch_elems(B * 15),), float("nan"), device=DEV)
+    _lib.pointwise_chain3(x, p1, p2, p3, out, B, G, softargmax=(coord, scratch))
+    assert torch.equal(out, ref)
+    vol, j = torch.empty_like(ref), torch.empty(B, 15, 3, device=DEV)
+    _lib.softargmax3d_finish(out, scratch, vol, j, B * 15, N, 1)
+    assert float((j - j_ref).abs().max()) < 2e-6
+    assert float((vol - vol_ref).abs().max()) <= 1e-5 * float(vol_ref.max())
+    assert abs(float(vol.sum()) - B * 15) < 1e-3
+
+
 def test_voxelize_strided_into_v2v_buffer(voxel_setup):
     """Occupancy written straight into channel 32 of a [B,G^3,48] buffer: bit-exact, channels 33..35 cleared, others untouched."""
     c, tab = voxel_setup
