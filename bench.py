@@ -11,6 +11,9 @@ prints ONE JSON line.  A step = one forward over one batch of synthetic input al
 of the joints when N > 1).  Weak scaling: every rank runs --batch frames (BASELINE.json configs[1]: batch 8, fp32, 64^3).
 Nothing is recorded inside the timed region; per-launch and per-stage durations come from a SEPARATE short pass with HIP
 events on the launch stream (SURVEY.md §8d "Timing").
+Consecutive steps are issued round-robin on `--streams` HIP streams (default 2, sceneego_amd/pipeline.py): each step is still one
+complete forward of --batch frames, the K steps are all inside the timed bracket, and `extra.single_stream` reports the same K
+steps issued on one stream beside the headline; `config.streams` says which form `value` is.
 
 Extra objects on the line:
   roofline     — dominant V2V kernel (3x3x3 conv 32->32 at 64^3, 9 launches/step), bound "mfma":
@@ -65,6 +68,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurement of BASELINE configs[2] (bf16, B=32)")
     ap.add_argument("--dump-kernel-events", action="store_true", help="per-shape launch times to stderr")
     ap.add_argument("--graphs", action="store_true", help="replay the forward as a captured hipGraph")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="consecutive steps are issued round-robin on this many HIP streams (sceneego_amd/pipeline.py: the 2-D backbone of "
+                         "step i+1 runs in the gaps of step i); 1 = every step behind the previous one")
     ap.add_argument("--master-port", type=int, default=29533, help="rendezvous port of the self-started launcher")
     return ap.parse_args()
 
@@ -202,9 +208,27 @@ def main():
     if args.graphs:
         net.enable_graphs(True)
 
-    def step():
+    n_streams = 1 if args.graphs else max(1, args.streams)
+    pipe = None
+    if n_streams > 1:
+        from sceneego_amd.pipeline import PipelinedForward
+        pipe = PipelinedForward(net, n_streams)
+
+    def step_single():
         kp = net(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth)[0]
         return sdist.all_gather_joints(kp)
+
+    def step():
+        if pipe is None:
+            return step_single()
+        # the forward runs on one of the pipeline's streams; the (only) collective stays on the main stream, behind the forward's
+        # event, so every rank issues its all-gathers in step order on one stream
+        out, done = pipe(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth)
+        if world == 1:
+            return out[0]                    # nothing to gather; the caller synchronises the device before reading it
+        torch.cuda.current_stream().wait_event(done)
+        out[0].record_stream(torch.cuda.current_stream())      # allocated on the pipeline stream, read by the collective here
+        return sdist.all_gather_joints(out[0])
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -221,12 +245,27 @@ def main():
         dt = time.perf_counter() - t0
     dt = sdist.max_over_ranks(dt, device)
     assert tuple(out.shape) == (args.batch * world, 15, 3) and bool(torch.isfinite(out).all())
+    # the same K steps with every step behind the previous one on ONE stream (reported beside the headline when it is pipelined)
+    dt_single = None
+    if pipe is not None:
+        with torch.no_grad():
+            step_single()
+            torch.cuda.synchronize()
+            sdist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step_single()
+            torch.cuda.synchronize()
+            sdist.barrier()
+            torch.cuda.synchronize()
+            dt_single = sdist.max_over_ranks(time.perf_counter() - t0, device)
 
     prof = {}
     if not args.no_kernel_events:
         if args.graphs:
             net.enable_graphs(False)             # events cannot be recorded inside a replayed graph
-        prof = timing_pass(step, args.profile_steps)
+        prof = timing_pass(step_single, args.profile_steps)
         if args.graphs:
             net.enable_graphs(True)
     sdist.barrier()
@@ -246,7 +285,7 @@ def main():
                                f"{G}^3 grid, 15 joints, " + ("bf16 V2V (BASELINE configs[2])" if bf16 else "fp32 (BASELINE configs[1])"),
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "volume_size": G,
                    "parallelism": f"dp{world}" + (" + RCCL all_gather of [B,15,3] joints" if world > 1 else ""),
-                   "hipgraph": bool(args.graphs)},
+                   "hipgraph": bool(args.graphs), "streams": n_streams},
     }
     stage_ms = {k[1]: round(statistics.median(v), 4) for k, v in prof.items() if k[0] == "stage"}
     launches = {k: v for k, v in prof.items() if k[0] != "stage"}
@@ -315,6 +354,12 @@ def main():
         line["cpu_baseline"] = cpu_baseline(sd, G)
     if world == 1 and not bf16 and args.backbone_dtype == "fp32" and G == 64 and not args.no_extras:
         line["extra"] = {"config3_bf16_b32": config3_extra(net, rank, device, args.depth_kind)}
+    if dt_single is not None:
+        line.setdefault("extra", {})["single_stream"] = {
+            "value": round(frames / dt_single, 3), "unit": "frames/s", "ms_per_step": round(dt_single / args.steps * 1e3, 4),
+            "note": "the same K steps issued on ONE stream, every step behind the previous one (bench.py --streams 1); the headline "
+                    "issues consecutive steps round-robin on `config.streams` streams (sceneego_amd/pipeline.py), each step still one "
+                    "forward of `batch_per_gpu` frames"}
     print(json.dumps(line))
 
 

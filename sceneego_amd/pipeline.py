@@ -1,0 +1,66 @@
+"""Pipelined inference: consecutive forwards of ``VoxelNetwork_depth`` issued round-robin on several HIP streams.
+
+One forward is a chain of ~170 launches whose big members (the persistent 3-D convolutions: one 512-thread workgroup per CU, all of
+its registers and most of its LDS) own the chip while they run, but 2.1 ms of it is the MIOpen 2-D backbone and another ~1 ms are
+the small pyramid levels and the tail - launches that leave most CUs idle.  Batches are independent (the reference evaluates them
+one after the other, ``network/voxel_net_depth.py:244-275`` has no state across calls), so the backbone of batch i+1 can run in
+those gaps of batch i: two streams give 717 -> 770 frames/s at B = 8 on one MI355X (``tools/diag/two_stream.py``; a third stream
+is not a consistent gain).
+
+Every stream gets its own module replica: the replicas alias the parameters and constant tables of the first module (no second copy
+of the weights as nn.Parameters), but own their packed kernels' scratch, input caches and output buffers, so two forwards in flight
+never share a mutable buffer.  Results equal those of the plain forward to its own run-to-run reproducibility (the MIOpen backbone
+splits K with atomic adds in some layers: ~6e-6 m in the joints between any two runs, tools/diag/stream_determinism.py).
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+
+
+class PipelinedForward:
+    """``pf = PipelinedForward(net, n_streams=2); out, done = pf(img, ..., depth_map_batch=depth)``.
+
+    ``out`` is what ``net(...)`` returns, produced on one of the pipeline's streams; ``done`` is a ``torch.cuda.Event`` recorded
+    behind it.  Make a consumer stream wait with ``torch.cuda.current_stream().wait_event(done)`` (or ``done.synchronize()`` on
+    the host) before reading ``out``.  Inputs: pass ``inputs_ready=<torch.cuda.Event>`` when they are produced asynchronously on
+    another stream; without it the caller guarantees they are complete (the pipeline streams deliberately do NOT wait for the
+    caller's stream - a consumer that waits there for batch i would otherwise hold back batch i+1)."""
+
+    def __init__(self, net, n_streams: int = 2):
+        if n_streams < 1:
+            raise ValueError("n_streams must be >= 1")
+        p = next(net.parameters())
+        if not p.is_cuda:
+            raise RuntimeError("PipelinedForward needs the module on a HIP device")
+        self.nets = [net]
+        for _ in range(n_streams - 1):
+            rep = copy.deepcopy(net)
+            for a, b in zip(rep.parameters(), net.parameters()):
+                a.data = b.data                                   # alias, do not duplicate
+            for a, b in zip(rep.buffers(), net.buffers()):
+                a.data = b.data
+            self.nets.append(rep.eval())
+        self.streams = [torch.cuda.Stream(device=p.device) for _ in range(n_streams)]
+        self._next = 0
+
+    def __len__(self):
+        return len(self.nets)
+
+    @torch.no_grad()
+    def __call__(self, *args, inputs_ready=None, **kwargs):
+        k = self._next
+        self._next = (k + 1) % len(self.nets)
+        s = self.streams[k]
+        if inputs_ready is not None:
+            s.wait_event(inputs_ready)
+        with torch.cuda.stream(s):
+            out = self.nets[k](*args, **kwargs)
+            done = torch.cuda.Event()
+            done.record(s)
+        return out, done
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()

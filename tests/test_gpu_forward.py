@@ -237,3 +237,32 @@ def test_planar3_input_layout_matches_channels_last(net64):
         net64.planar3_input = True
     assert float((kp_p - kp_c).abs().max()) < 5e-5
     assert float((vol_p - vol_c).abs().max()) <= 1e-4 * float(vol_c.max())
+
+
+def test_pipelined_forward_matches_plain_forward(net64):
+    """sceneego_amd.pipeline.PipelinedForward: consecutive forwards issued round-robin on two streams (replicas aliasing the
+    parameters) return what the plain forward returns (to the backbone's run-to-run reproducibility), whichever replica / stream
+    served the call."""
+    from sceneego_amd.pipeline import PipelinedForward
+    img, depth = synth.make_inputs(11, 2, "floor")
+    img2, depth2 = synth.make_inputs(12, 2, "floor")
+    ref = [_forward(net64, i, d) for i, d in ((img, depth), (img2, depth2))]
+    torch.cuda.synchronize()
+    pf = PipelinedForward(net64, 2)
+    assert len(pf) == 2 and pf.nets[1] is not net64
+    assert all(a.data_ptr() == b.data_ptr() for a, b in zip(pf.nets[1].parameters(), net64.parameters()))
+    dev_in = [(i.to(DEV), d.to(DEV)) for i, d in ((img, depth), (img2, depth2))]
+    ready = torch.cuda.Event()
+    ready.record()                                  # the uploads run on the current stream: hand the pipeline their event
+    outs = []
+    for rep in range(2):
+        for i, d in dev_in:
+            outs.append(pf(i, net64.grid_coord_proj_batch, net64.coord_volumes, depth_map_batch=d, inputs_ready=ready))
+    pf.synchronize()
+    diffs = [(float((out[0] - ref[n % 2][0]).abs().max()), float((out[2] - ref[n % 2][2]).abs().max())) for n, (out, _) in enumerate(outs)]
+    print("pipelined vs plain: max |joint diff|, max |volume diff| per call:", diffs)
+    # not bitwise: the MIOpen backbone itself is not reproducible run to run (its igemm "gkgs" kernels split K over workgroups with
+    # atomic adds: two plain forwards on one stream differ by ~6e-6 m in the joints, tools/diag/stream_determinism.py)
+    for n, (out, done) in enumerate(outs):
+        assert done.query()
+        assert diffs[n][0] < 1e-4 and diffs[n][1] < 1e-4, diffs
