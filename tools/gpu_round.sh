@@ -7,7 +7,7 @@ python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1
 tail -2 gpurun_out/bench.log
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/prof_run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --streams 1 > gpurun_out/prof_run.log 2>&1
 tail -2 gpurun_out/prof_run.log
 find gpurun_out/prof -name '*kernel_stats*' | head
 f=$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1)
