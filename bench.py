@@ -212,7 +212,11 @@ def main():
     pipe = None
     if n_streams > 1:
         from sceneego_amd.pipeline import PipelinedForward
-        pipe = PipelinedForward(net, n_streams)
+        try:
+            pipe = PipelinedForward(net, n_streams)
+        except Exception as e:           # never lose the measurement to the throughput mode: fall back to one stream, say so
+            print(f"bench.py: pipelined mode unavailable ({type(e).__name__}: {e}); running --streams 1", file=sys.stderr)
+            pipe, n_streams = None, 1
 
     def step_single():
         kp = net(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth)[0]
