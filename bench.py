@@ -235,6 +235,12 @@ def main():
         return sdist.all_gather_joints(out[0])
 
     with torch.no_grad():
+        if pipe is not None:
+            # set-up, not warm-up: every replica packs its kernels and lets MIOpen pick its solvers on its own stream once, so that
+            # the W warm-up steps (which alternate between the replicas) never meet a cold one, whatever W is
+            for _ in range(len(pipe)):
+                pipe(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth)
+            torch.cuda.synchronize()
         for _ in range(args.warmup):
             out = step()
         torch.cuda.synchronize()
