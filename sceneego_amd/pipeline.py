@@ -6,7 +6,8 @@ the small pyramid levels and the tail - launches that leave most CUs idle.  Batc
 one after the other, ``network/voxel_net_depth.py:244-275`` has no state across calls), so the backbone of batch i+1 can run in
 those gaps of batch i: two streams give 717 -> 770 frames/s at B = 8 on one MI355X (``tools/diag/two_stream.py``; a third stream
 is not a consistent gain; putting each forward's backbone on a low-priority stream and its 3-D part on a high-priority one measured
-slower, 753 vs 780; replaying each replica as a hipGraph adds ~1 %, ``tools/diag/two_stream_graphs.py``).
+slower, 753 vs 780; replaying each replica as a hipGraph adds ~1 %, ``tools/diag/two_stream_graphs.py``; capping the persistent kernels to half the
+CUs so that the two forwards' big kernels run side by side changes nothing, 772.7 vs 772.4).
 
 Every stream gets its own module replica: the replicas alias the parameters and constant tables of the first module (no second copy
 of the weights as nn.Parameters), but own their packed kernels' scratch, input caches and output buffers, so two forwards in flight
