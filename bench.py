@@ -20,10 +20,15 @@ Extra objects on the line:
                  achieved = EXECUTED matrix-core FLOP per launch / mean launch duration, frac = achieved / 157.3 TFLOP/s
                  (<= 1); the Winograd saving over the direct convolution is reported separately as algorithmic_speedup.
                  "hbm" compares the algorithmic bytes of the launch with the rocprofv3 FETCH_SIZE/WRITE_SIZE counters of
-                 the committed PMC pass (profiles/r02_pmc.json; counters cannot be read from inside this process).
+                 the committed PMC pass (profiles/r03_pmc.json; counters cannot be read from inside this process).  The
+                 record carries the ABI version and a hash of sceneego_amd/csrc it was taken on; when either differs from
+                 this checkout `traffic` is null (a stale record is never printed).
                  "stage_ms" = backbone / gather / voxelise / v2v / softargmax (median over the profiling pass).
   cpu_baseline — the CPU oracle (oracle/sceneego_oracle.py: the reference's own ATen CPU ops) on this box's host cores,
-                 B=1 and B=8, 1 warm-up + 3 timed forwards each, median (N = 1 only).
+                 B=1 and B=8, 1 warm-up + 3 timed forwards each, median (N = 1 only), on the SAME seeded frames the GPU ran.
+  parity       — max |joint difference| (metres) between the output of the LAST timed step and the oracle's forward on the
+                 same frames (rank 0's frames; float64 evaluation of the reference's soft-argmax formula as the
+                 platform-stable gate, its float32 value beside it); the process exits with code 3 above `tol` = 1e-3.
 """
 import argparse
 import json
@@ -42,7 +47,8 @@ HBM_PEAK_GBS = 8000.0
 # algorithmic work of V2V + soft-argmax per frame at 64^3 / 128^3, fp32
 V2V_GFLOP_PER_FRAME = {64: 299.1, 128: 2393.0}
 V2V_GB_PER_FRAME = {64: 1.372, 128: 10.98}
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+JOINT_TOL = 1e-3               # BASELINE.json north_star: joints within 1e-3 m of the reference's CPU forward
 # se_conv3d_f32_algo() -> (kernel name, executed MFMA FLOP / direct-convolution FLOP)
 K3_ALGOS = {
     0: ("conv3d_tiled_kernel / conv3d_direct_kernel: direct implicit GEMM", 1.0),
@@ -67,19 +73,27 @@ def parse():
     ap.add_argument("--backbone-dtype", default="fp32", choices=["fp32", "bf16"], help="MIOpen backbone precision (config 3: bf16)")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurement of BASELINE configs[2] (bf16, B=32)")
     ap.add_argument("--dump-kernel-events", action="store_true", help="per-shape launch times to stderr")
+    ap.add_argument("--dump-launch-order", default="", help="write the launch keys of one profiled step, in issue order, to this JSON file")
     ap.add_argument("--graphs", action="store_true", help="replay the forward as a captured hipGraph")
     ap.add_argument("--streams", type=int, default=2,
                     help="consecutive steps are issued round-robin on this many HIP streams (sceneego_amd/pipeline.py: the 2-D backbone of "
                          "step i+1 runs in the gaps of step i); 1 = every step behind the previous one")
-    ap.add_argument("--master-port", type=int, default=29533, help="rendezvous port of the self-started launcher")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-started launcher (0: a free one)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the timed output (profiling runs)")
     return ap.parse_args()
 
 
 def self_launch(args):
     """`python bench.py --gpus N` typed without a launcher: run N ranks as a child job and hand back its exit code.
     The parent has not imported torch and never touches the GPU; it does not exec."""
+    port = args.master_port
+    if not port:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
@@ -96,17 +110,16 @@ def build_network(volume_size, device):
     return net.to(device).eval(), sd
 
 
+def host_inputs(batch, rank, kind):
+    """The seeded synthetic batch of this rank (BASELINE configs[1]: N(0,1) image, U(0.3,3) / floor-plane depth) from the portable
+    counter-based generator (sceneego_amd/synth.py): the SAME frames are given to the GPU and, on rank 0, to the CPU oracle."""
+    from sceneego_amd import synth
+    return synth.make_inputs(1234 + rank, batch, kind)
+
+
 def device_inputs(batch, rank, device, kind):
-    import torch
-    g = torch.Generator(device=device)
-    g.manual_seed(1234 + rank)
-    img = torch.randn((batch, 3, 256, 256), generator=g, device=device, dtype=torch.float32)
-    if kind == "uniform":
-        depth = torch.rand((batch, 1024, 1280), generator=g, device=device, dtype=torch.float32) * 2.7 + 0.3
-    else:
-        from sceneego_amd import synth
-        depth = synth.make_inputs(1234 + rank, batch, "floor")[1].to(device)
-    return img, depth
+    img, depth = host_inputs(batch, rank, kind)
+    return img.to(device), depth.to(device)
 
 
 def effective_cores():
@@ -123,35 +136,57 @@ def effective_cores():
 
 
 def pmc_record(batch, G, algo):
-    """Counters of the dominant kernel from the committed rocprofv3 PMC passes (tools/pmc_round.sh), or None when the
-    file was taken for another shape / kernel."""
+    """Counters of the dominant kernel from the committed rocprofv3 PMC passes (tools/pmc_r03.py), or (None, why) when the
+    record was taken for another shape / kernel family, on another ABI version or on other kernel sources than this checkout."""
+    from sceneego_amd import _lib
     try:
         with open(PMC_FILE) as f:
             d = json.load(f)
-        if d.get("batch") == batch and d.get("volume_size") == G and d.get("algo") == algo:
-            return d
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    except (OSError, ValueError) as e:
+        return None, f"{os.path.relpath(PMC_FILE, ROOT)} unreadable ({type(e).__name__})"
+    if not (d.get("batch") == batch and d.get("volume_size") == G and d.get("algo") == algo):
+        return None, "the committed counter record is for another batch / grid / kernel family"
+    fp = _lib.source_fingerprint()
+    if d.get("abi_version") != _lib.ABI_VERSION or d.get("csrc_sha256_16") != fp:
+        return None, (f"stale counter record: taken on ABI {d.get('abi_version')} / csrc {d.get('csrc_sha256_16')}, this checkout is "
+                      f"ABI {_lib.ABI_VERSION} / csrc {fp}; re-run tools/pmc_r03.py on the GPU box")
+    return d, None
 
 
-def cpu_baseline(sd, volume_size):
-    """the CPU restatement at B=1 and B=8, 1 warm-up + 3 timed forwards, median."""
+class _KeepLogits(dict):
+    """taps sink for the oracle that retains only the V2V logits (the full tap set of a B=8 forward is several GB)."""
+
+    def __setitem__(self, k, v):
+        if k == "logits":
+            super().__setitem__(k, v)
+
+
+def oracle_reference(sd, volume_size, img, depth, timed):
+    """The CPU oracle on the frames the GPU ran: joints of its forward (the reference's float32 soft-argmax, and the float64
+    evaluation of the same formula from the same logits) and, when ``timed``, SURVEY.md §8d's CPU timing: B=1 and the whole batch,
+    1 warm-up + 3 timed forwards each, median."""
     import torch
     from oracle import sceneego_oracle as O
-    from sceneego_amd import synth
     torch.set_num_threads(effective_cores())
     const = O.Constants(os.path.join(ROOT, "sceneego_amd", "calibration", "fisheye.calibration_05_08.json"), G=volume_size)
+    taps = _KeepLogits()
+    j32 = O.forward(sd, const, img, depth, taps=taps)[0]     # also the warm-up at the timed shape (oneDNN primitive creation)
+    j64 = O.integrate(taps["logits"], const.coord, softmax=True, accumulate64=True)[0]
+    taps.clear()
+    if not timed:
+        return j32, j64, None
+    frames_all = img.shape[0]
     per_batch = {}
     stage = {}
-    for frames in (1, 8):
-        img, depth = synth.make_inputs(1234, frames, "uniform")
-        O.forward(sd, const, img, depth)                     # warm-up at the timed shapes (oneDNN primitive creation)
+    for frames in sorted({1, frames_all}):
+        i, d = img[:frames], depth[:frames]
+        if frames != frames_all:
+            O.forward(sd, const, i, d)
         ts = []
         for _ in range(3):
             times = {}
             t0 = time.perf_counter()
-            O.forward(sd, const, img, depth, times=times)
+            O.forward(sd, const, i, d, times=times)
             ts.append(time.perf_counter() - t0)
             stage = times
         med = statistics.median(ts)
@@ -163,11 +198,13 @@ def cpu_baseline(sd, volume_size):
             model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
     except OSError:
         pass
-    return {"value": per_batch["b8"]["frames_per_s"], "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/sceneego_oracle.py forward at B=1 and B=8 ({volume_size}^3, fp32), 1 warm-up + 3 timed each, median; "
-                      "value = the B=8 rate (the headline's batch)",
-            "b1": per_batch["b1"], "b8": per_batch["b8"], "cpu": model,
-            "stage_seconds_b8": {k: round(v, 3) for k, v in stage.items()}}
+    top = per_batch[f"b{frames_all}"]
+    base = {"value": top["frames_per_s"], "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/sceneego_oracle.py forward at B=1 and B={frames_all} ({volume_size}^3, fp32) on the same seeded frames the GPU "
+                      f"ran, 1 warm-up + 3 timed each, median; value = the B={frames_all} rate",
+            "cpu": model, f"stage_seconds_b{frames_all}": {k: round(v, 3) for k, v in stage.items()}}
+    base.update(per_batch)
+    return j32, j64, base
 
 
 def timing_pass(step, steps):
@@ -198,7 +235,8 @@ def main():
     assert world == args.gpus
     lib = _lib.load()
     net, sd = build_network(args.volume_size, device)
-    img, depth = device_inputs(args.batch, rank, device, args.depth_kind)
+    img_h, depth_h = host_inputs(args.batch, rank, args.depth_kind)
+    img, depth = img_h.to(device), depth_h.to(device)
     G = args.volume_size
     bf16 = args.v2v_dtype == "bf16"
     if bf16:
@@ -255,6 +293,7 @@ def main():
         dt = time.perf_counter() - t0
     dt = sdist.max_over_ranks(dt, device)
     assert tuple(out.shape) == (args.batch * world, 15, 3) and bool(torch.isfinite(out).all())
+    timed_joints = out[rank * args.batch:(rank + 1) * args.batch].detach().cpu()     # this rank's frames of the LAST timed step
     # the same K steps with every step behind the previous one on ONE stream (reported beside the headline when it is pipelined)
     dt_single = None
     if pipe is not None:
@@ -313,7 +352,7 @@ def main():
         ach = exec_flop / (avg_ms * 1e-3) / 1e12
         k7 = [v for k, v in launches.items() if k[0] == "conv3d" and k[1] == 7]
         alg_bytes = 4.0 * args.batch * G ** 3 * 32 * 3                  # input + residual read, output written once
-        pmc = pmc_record(args.batch, G, algo)
+        pmc, pmc_why = pmc_record(args.batch, G, algo)
         counter_bytes = pmc["hbm_bytes_per_launch"] if pmc else None
         line["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -327,8 +366,10 @@ def main():
             "hbm": {"algorithmic_bytes": alg_bytes, "counter_bytes": counter_bytes,
                     "ratio": round(counter_bytes / alg_bytes, 3) if counter_bytes else None,
                     "algorithmic_gbs": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
-                    "source": (os.path.relpath(PMC_FILE, ROOT) + ": separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), "
-                               + pmc.get("correction", "")) if pmc else None},
+                    "source": (os.path.relpath(PMC_FILE, ROOT) + ": separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) on these kernel "
+                               f"sources (csrc {pmc.get('csrc_sha256_16')}), " + pmc.get("correction", "")) if pmc else pmc_why,
+                    "counters": {k: pmc.get(k) for k in ("fetch_kib_raw", "write_kib", "mfma_busy_cycles_per_launch",
+                                                         "lds_bank_conflict_cycles", "lds_active_cycles")} if pmc else None},
             "stage": {"v2v_conv_ms_per_step": round(conv_ms_per_step, 3),
                       "v2v_tflops_algorithmic": round(V2V_GFLOP_PER_FRAME.get(G, 0) * args.batch / (conv_ms_per_step * 1e-3) / 1e3, 2)
                       if conv_ms_per_step else None,
@@ -355,22 +396,54 @@ def main():
         }
     if stage_ms:
         line.setdefault("roofline", {})["stage_ms"] = stage_ms
+    if args.dump_launch_order and prof:
+        order = _lib.last_launch_order[:len(_lib.last_launch_order) // psteps]
+        with open(args.dump_launch_order, "w") as f:
+            json.dump([list(k) + [int(lib.se_conv3d_f32_algo(k[4], k[2], k[3], k[1])) if k[0] == "conv3d" else -1] for k in order], f)
     if args.dump_kernel_events:
         for k in sorted(launches, key=lambda k: -sum(launches[k])):
             v = launches[k]
             print(f"{str(k):44s} {len(v) // psteps:3d}/step avg {sum(v) / len(v):8.4f} ms  per-step {sum(v) / psteps:8.4f} ms",
                   file=sys.stderr)
-    if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(sd, G)
+    # ---- parity gate on the timed output + CPU baseline, same frames (rank 0's) -----------------------
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    parity_ok = True
+    if not args.no_parity or want_cpu:
+        nref = args.batch if G <= 64 else 1          # the oracle takes ~1 s per frame at 64^3 and ~10 s at 128^3
+        j32, j64, base = oracle_reference(sd, G, img_h[:nref], depth_h[:nref], timed=want_cpu)
+        if want_cpu:
+            line["cpu_baseline"] = base
+        if not args.no_parity:
+            err64 = float((timed_joints[:nref] - j64).abs().max())
+            err32 = float((timed_joints[:nref] - j32).abs().max())
+            # the bf16-storage mode (BASELINE configs[2]) is specified to 4e-2 m, not to the reference tolerance
+            tol = JOINT_TOL if not bf16 and args.backbone_dtype == "fp32" else 4e-2
+            parity_ok = err64 <= tol
+            line["parity"] = {
+                "max_joint_err_m": round(err64, 9), "tol": tol, "pass": parity_ok, "frames": nref,
+                "max_joint_err_vs_f32_softargmax_m": round(err32, 9),
+                "checked": "joints of the LAST timed step (rank 0's frames) against oracle/sceneego_oracle.py on the same seeded frames; "
+                           "gate = float64 evaluation of the reference's soft-argmax formula on the oracle's logits (the float32 einsum "
+                           "over 262 144 voxels is reduction-order dependent across hosts, DESIGN.md 2), float32 value beside it"}
     if world == 1 and not bf16 and args.backbone_dtype == "fp32" and G == 64 and not args.no_extras:
-        line["extra"] = {"config3_bf16_b32": config3_extra(net, rank, device, args.depth_kind)}
+        line["extra"] = {"config3_bf16_b32": config3_extra(net, rank, device, args.depth_kind),
+                         "no_scene_v2v32_b8": no_scene_extra(device),
+                         "config5_g128_b8": config5_extra(device, args.depth_kind)}
     if dt_single is not None:
-        line.setdefault("extra", {})["single_stream"] = {
+        single = {
             "value": round(frames / dt_single, 3), "unit": "frames/s", "ms_per_step": round(dt_single / args.steps * 1e3, 4),
             "note": "the same K steps issued on ONE stream, every step behind the previous one (bench.py --streams 1); the headline "
                     "issues consecutive steps round-robin on `config.streams` streams (sceneego_amd/pipeline.py), each step still one "
                     "forward of `batch_per_gpu` frames"}
+        line.setdefault("extra", {})["single_stream"] = single
+        line["single_stream_value"] = single["value"]
+        line["latency_ms"] = single["ms_per_step"]      # one forward alone on the chip; ms_per_step = timed wall / K with `streams` in flight
+    else:
+        line["latency_ms"] = line["ms_per_step"]
     print(json.dumps(line))
+    if not parity_ok:
+        print(f"bench.py: PARITY FAILED: {line['parity']['max_joint_err_m']:.3e} m > {line['parity']['tol']} m", file=sys.stderr)
+        sys.exit(3)
 
 
 def config3_extra(net, rank, device, depth_kind):
@@ -398,6 +471,63 @@ def config3_extra(net, rank, device, depth_kind):
     finally:
         net.set_v2v_dtype("fp32")
         net.set_backbone_dtype("fp32")
+
+
+def _time_forward(net, img, depth, steps=5, warm=2):
+    import torch
+    with torch.no_grad():
+        for _ in range(warm):
+            net(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = net(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    assert bool(torch.isfinite(out[0]).all())
+    return dt
+
+
+def config5_extra(device, depth_kind):
+    """BASELINE configs[4] measured beside the headline (never part of `value`): 128^3 grid, batch 8, float32, one stream."""
+    import torch
+    net = None
+    try:
+        net, _ = build_network(128, device)
+        img, depth = device_inputs(8, 0, device, depth_kind)
+        dt = _time_forward(net, img, depth)
+        return {"value": round(8 / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "batch": 8, "volume_size": 128,
+                "dtype": "f32", "streams": 1,
+                "note": "same forward at volume_size 128 (8x the voxels); parity at this size: tests/test_gpu_configs.py::test_config5_g128_b8"}
+    except Exception as e:      # never let the side measurement break the headline line
+        return {"error": repr(e)[:200]}
+    finally:
+        del net
+        torch.cuda.empty_cache()
+
+
+def no_scene_extra(device):
+    """The reference author's own micro-benchmark shape (network/v2v.py:259-270: V2VModel(32, 15) on [8,32,64,64,64]) as it occurs
+    on this path: the `with_scene: False` network (network/voxel_net_depth.py:65-77), batch 8, float32, whole forward."""
+    import torch
+    net = None
+    try:
+        from sceneego_amd import load_config, synth
+        from sceneego_amd.voxel_net_depth import VoxelNetwork_depth
+        cfg = load_config()
+        cfg.model.with_scene = False
+        net = VoxelNetwork_depth(cfg, device="cpu", verbose=False)
+        net.load_state_dict(synth.make_state_dict(net.state_dict(), seed=0), strict=True)
+        net = net.to(device).eval()
+        img, _ = device_inputs(8, 0, device, "uniform")
+        dt = _time_forward(net, img, None)
+        return {"value": round(8 / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "batch": 8, "dtype": "f32",
+                "streams": 1, "note": "with_scene False: V2VModel(32, 15) on the gathered [8,32,64^3] feature volume, no depth input"}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+    finally:
+        del net
+        torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":

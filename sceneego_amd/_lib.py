@@ -102,6 +102,21 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+def source_fingerprint() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.h, build.sh and the C-ABI header), names included, in sorted order.
+    rocprofv3 counter records under profiles/ carry it, so a record taken on other kernels is recognised as stale (bench.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".sh")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "sceneego_hip.h"))
+    for p in files:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def require_hip(*tensors) -> None:
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -257,6 +272,7 @@ def conv3d_pack(w, b, gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_
 # Optional per-launch timing (bench.py's roofline leg): HIP events recorded on the launch stream around every
 # conv launch, keyed by shape.  None = off (the default; nothing is recorded in normal operation).
 _prof = None
+last_launch_order = []      # launch keys of the last profiled pass, in issue order (tools/pmc_r03.py labels rocprofv3 dispatches with it)
 
 
 def start_profile():
@@ -266,11 +282,12 @@ def start_profile():
 
 def stop_profile():
     """-> {key: [ms, ...]} ; caller must have synchronised the device."""
-    global _prof
+    global _prof, last_launch_order
     rec, _prof = _prof, None
     out = {}
     for key, e0, e1 in rec or []:
         out.setdefault(key, []).append(e0.elapsed_time(e1))
+    last_launch_order = [key for key, _, _ in rec or [] if key[0] != "stage"]
     return out
 
 

@@ -123,19 +123,29 @@ def test_config3_b32_bf16_accuracy(golden, golden_meta):
     assert bool(torch.isfinite(vols).all())
 
 
-def test_config5_g128_b2(golden, golden_meta):
-    """configs[4] grid (128^3) at B=2: frame 0 reproduces the reference golden, frame 1 equals its B=1 run."""
+def test_config5_g128_b8(golden, golden_meta):
+    """configs[4] at its stated size (128^3 grid, batch 8): frame 0 reproduces the reference golden, every frame equals its own
+    B=1 run, a batch permutation permutes the result."""
     net = _build(volume_size=128)
     m = next(c for c in golden_meta["cases"] if c["name"] == "b1_g128_floor")
     i1, d1 = case_inputs(m)
-    i2, d2 = synth.make_inputs(909, 1, "uniform")
-    img, depth = torch.cat([i1, i2]), torch.cat([d1, d2])
+    i2, d2 = synth.make_inputs(909, 4, "uniform")
+    i3, d3 = synth.make_inputs(910, 3, "floor")
+    img, depth = torch.cat([i1, i2, i3]), torch.cat([d1, d2, d3])
     kp, _, vols, _ = _forward(net, img, depth)
-    assert tuple(vols.shape) == (2, 15, 128, 128, 128)
+    assert tuple(kp.shape) == (8, 15, 3) and tuple(vols.shape) == (8, 15, 128, 128, 128)
     err = float(np.abs(kp[0:1].cpu().numpy() - golden("b1_g128_floor")["joints"]).max())
+    print(f"128^3 B=8: frame 0 vs reference golden {err:.2e} m")
     assert err <= JOINT_TOL, err
-    one = _forward(net, i2, d2)[0]
-    assert float((one - kp[1:2]).abs().max()) < RUN_NOISE
+    s = vols.reshape(8, 15, -1).sum(dim=2)
+    assert float((s - 1).abs().max()) < 1e-3 and bool(torch.isfinite(kp).all())
+    del vols
+    for b in (1, 4, 7):
+        one = _forward(net, img[b:b + 1], depth[b:b + 1])[0]
+        assert float((one - kp[b:b + 1]).abs().max()) < RUN_NOISE, b
+    perm = torch.randperm(8, generator=torch.Generator().manual_seed(5))
+    kp_perm = _forward(net, img[perm], depth[perm])[0]
+    assert float((kp_perm - kp[perm.to(DEV)]).abs().max()) < RUN_NOISE
 
 
 def test_conv7_planar3_g128_b32_unit_table_budget():
