@@ -146,9 +146,11 @@ def pmc_record(batch, G, algo):
         return None, f"{os.path.relpath(PMC_FILE, ROOT)} unreadable ({type(e).__name__})"
     if not (d.get("batch") == batch and d.get("volume_size") == G and d.get("algo") == algo):
         return None, "the committed counter record is for another batch / grid / kernel family"
-    fp = _lib.source_fingerprint()
+    fp, built = _lib.source_fingerprint(), _lib.built_fingerprint()
+    if built != fp:
+        return None, f"libsceneego_hip.so was built from other sources (csrc {built}) than this checkout (csrc {fp}): rebuild"
     if d.get("abi_version") != _lib.ABI_VERSION or d.get("csrc_sha256_16") != fp:
-        return None, (f"stale counter record: taken on ABI {d.get('abi_version')} / csrc {d.get('csrc_sha256_16')}, this checkout is "
+        return None, (f"stale counter record: taken on ABI {d.get('abi_version')} / csrc {d.get('csrc_sha256_16')}, this build is "
                       f"ABI {_lib.ABI_VERSION} / csrc {fp}; re-run tools/pmc_r03.py on the GPU box")
     return d, None
 
@@ -248,8 +250,8 @@ def main():
 
     n_streams = 1 if args.graphs else max(1, args.streams)
     pipe = None
+    from sceneego_amd.pipeline import PipelinedForward
     if n_streams > 1:
-        from sceneego_amd.pipeline import PipelinedForward
         try:
             pipe = PipelinedForward(net, n_streams)
         except Exception as e:           # never lose the measurement to the throughput mode: fall back to one stream, say so
@@ -265,11 +267,12 @@ def main():
             return step_single()
         # the forward runs on one of the pipeline's streams; the (only) collective stays on the main stream, behind the forward's
         # event, so every rank issues its all-gathers in step order on one stream
-        out, done = pipe(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth)
+        # inputs_ready=False: the resident inputs were complete before the loop; waiting for the main stream here would put step i+1
+        # behind step i's all-gather, i.e. behind step i
+        out, done = pipe(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth, inputs_ready=False)
         if world == 1:
             return out[0]                    # nothing to gather; the caller synchronises the device before reading it
-        torch.cuda.current_stream().wait_event(done)
-        out[0].record_stream(torch.cuda.current_stream())      # allocated on the pipeline stream, read by the collective here
+        PipelinedForward.hand_over(out[0], done)     # main stream waits for the forward; joints recorded on it for the collective
         return sdist.all_gather_joints(out[0])
 
     with torch.no_grad():
@@ -277,7 +280,7 @@ def main():
             # set-up, not warm-up: every replica packs its kernels and lets MIOpen pick its solvers on its own stream once, so that
             # the W warm-up steps (which alternate between the replicas) never meet a cold one, whatever W is
             for _ in range(len(pipe)):
-                pipe(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth)
+                pipe(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth, inputs_ready=False)
             torch.cuda.synchronize()
         for _ in range(args.warmup):
             out = step()

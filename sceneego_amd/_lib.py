@@ -117,6 +117,16 @@ def source_fingerprint() -> str:
     return h.hexdigest()[:16]
 
 
+def built_fingerprint() -> str | None:
+    """source_fingerprint() of the sources the loaded shared library was built from (written by csrc/build.sh next to the .so),
+    or None when the stamp is missing."""
+    try:
+        with open(os.path.splitext(LIB_PATH)[0] + ".srchash") as f:
+            return f.read().strip() or None
+    except OSError:
+        return None
+
+
 def require_hip(*tensors) -> None:
     for t in tensors:
         if t is not None and not t.is_cuda:

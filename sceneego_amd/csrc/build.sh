@@ -18,8 +18,10 @@ pids=()
 newer() {  # source $1 or a shared header newer than object $2
   [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ common.h -nt "$2" ] || [ conv_common.h -nt "$2" ] || [ bf16_common.h -nt "$2" ] || [ ../../include/sceneego_hip.h -nt "$2" ]
 }
+OBJS=()
 for f in voxelize gather softargmax conv3d conv3d_tiled conv3d_wino conv3d_wino2d conv3d_bf16 conv3d_bf16_tiled; do
-  [ -f $f.hip ] || continue
+  [ -f $f.hip ] || { echo "build.sh: source $f.hip is missing" >&2; exit 1; }
+  OBJS+=($OBJ/$f.o)
   extra=""
   [ "$f" = voxelize ] && extra="-ffp-contract=off"
   # no SLP packing of float32 arithmetic into v_pk_*_f32: packed VALU beside an MFMA stream is an anti-lever (see commit() there)
@@ -31,6 +33,7 @@ for f in voxelize gather softargmax conv3d conv3d_tiled conv3d_wino conv3d_wino2
 done
 # the F(4,7) 7^3 kernel: one object per input layout (each takes minutes to compile: 390 unrolled MFMAs under sched_group_barrier)
 for v in 0 1; do
+  OBJS+=($OBJ/conv3d_wino47_$v.o)
   if newer conv3d_wino47.hip $OBJ/conv3d_wino47_$v.o || [ wino47_matrices.h -nt $OBJ/conv3d_wino47_$v.o ]; then
     hipcc $FLAGS -DSE_K7F_PLANAR=$v -c conv3d_wino47.hip -o $OBJ/conv3d_wino47_$v.o &
     pids+=($!)
@@ -39,5 +42,19 @@ done
 rc=0
 for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait $p || rc=1; }; done
 [ $rc -eq 0 ] || { echo "build.sh: compilation failed" >&2; exit 1; }
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/*.o
+# explicit object list: a stale object of a removed / renamed source in the same key directory is never linked
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT "${OBJS[@]}"
+# the hash of the sources this binary was built from (sceneego_amd/_lib.py: built_fingerprint / source_fingerprint): counter records
+# under profiles/ carry it, bench.py prints their traffic figure only for the binary they were taken on
+python3 - "$OUT" <<'PY'
+import hashlib, os, sys
+here = os.getcwd()
+h = hashlib.sha256()
+files = sorted(os.path.join(here, f) for f in os.listdir(here) if f.endswith((".hip", ".h", ".sh")))
+files.append(os.path.join(here, "..", "..", "include", "sceneego_hip.h"))
+for p in files:
+    h.update(os.path.basename(p).encode() + b"\0")
+    h.update(open(p, "rb").read())
+open(os.path.splitext(sys.argv[1])[0] + ".srchash", "w").write(h.hexdigest()[:16] + "\n")
+PY
 echo "built $(realpath $OUT) (objects: $OBJ)"

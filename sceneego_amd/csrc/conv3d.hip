@@ -806,7 +806,7 @@ extern "C" int se_abi_version(void) { return 8; }
 // Mirrors the dispatch of se_conv3d_f32 -> se_conv3d_tiled_try -> se_conv3d_wino_try / se_conv3d_k7_wino_try for the
 // default channels-last call (no SE_EPI_OUT_PLANAR / SE_EPI_RES_POST_RELU flags).
 extern "C" int se_conv3d_f32_algo(int dim, int cin, int cout, int ksize) {
-    if (ksize == 3 && dim >= 16 && (dim & 15) == 0 && (cout & 31) == 0 && (cin & 7) == 0) return 2;
+    if (ksize == 3 && se_wino2d_shape_ok(dim, cin, cout)) return 2;
     if (ksize == 3 && dim >= 16 && (dim & 7) == 0 && (cout & 31) == 0 && (cin & 15) == 0) return 1;
     if (ksize == 7 && dim >= 16 && (dim & 7) == 0 && cout == 16) return 7;
     return 0;

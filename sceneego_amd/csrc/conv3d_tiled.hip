@@ -665,6 +665,10 @@ static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s)
         const int rc = se_conv3d_wino2d_try(a, batch, s);
         if (rc != SE_TILED_NOT_TAKEN) return rc;
     }
+    // octet-planar tensors, the pooled second output and the fused 16-channel skip convolution exist in the 2-D Winograd kernel only:
+    // a launch that asks for one of them and was declined (cin_pad != cin, SE_EPI_RES_POST_RELU / SE_EPI_OUT_PLANAR, ...) is an error -
+    // none of the kernels below would read or write those tensors the way the caller laid them out
+    if ((a.flags & (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET | SE_EPI_SKIPCONV16)) || a.pool_out || a.skip_w) return SE_ERR_BAD_ARG;
     if (ksize == 3 && (g_variant == 0 || g_variant == 4 || g_variant == 30 || (g_variant >= 10 && g_variant < 20))) {   // 1-D Winograd F(4,3) (se_debug_set_variant(30): instead of the 2-D kernel)
         const int rc = se_conv3d_wino_try(a, batch, s);
         if (rc != SE_TILED_NOT_TAKEN) return rc;

@@ -704,10 +704,8 @@ int se_conv3d_pack_wino2d(const float* w, const float* gamma, const float* var, 
 // Returns 0 on launch, SE_TILED_NOT_TAKEN if the shape/flags are not covered, else a hipError_t.
 int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
     const int dim = a.dim;
-    if (!a.wpack_g || dim < 16 || (dim & 15) || (a.cout & 31) || (a.cin & 7) || a.cin_pad != a.cin) return SE_TILED_NOT_TAKEN;
+    if (!a.wpack_g || a.cin_pad != a.cin || !se_wino2d_shape_ok(dim, a.cin, a.cout)) return SE_TILED_NOT_TAKEN;
     if (a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR)) return SE_TILED_NOT_TAKEN;
-    // 32-bit byte offsets inside ONE sample (buffer descriptor per sample; bit 31 of the offset marks out-of-volume lanes)
-    if ((long long)dim * dim * dim * (a.cin > a.cout ? a.cin : a.cout) * 4 >= (1LL << 31)) return SE_TILED_NOT_TAKEN;
     const int tx = dim / 16, ty = dim / 8, tz = dim / 4;
     const long long total_tiles = (long long)batch * tx * ty * tz;
     const long long n_units = total_tiles * (a.cout / 32);

@@ -37,6 +37,14 @@ __host__ __device__ inline float se_wino27_G(int xi, int kz) {
 
 __host__ __device__ inline int round_up16(int v) { return (v + 15) & ~15; }
 
+// Shapes the 2-D Winograd 3x3x3 kernel (conv3d_wino2d.hip) covers - ONE predicate for se_conv3d_f32_algo() (what callers use to
+// choose the octet-planar / pooled / fused-skip forms) and for the launcher.  `cin` is the channel stride of the input tensor (the
+// kernel needs cin_pad == cin).  The last term: 32-bit byte offsets inside one sample (bit 31 marks out-of-volume lanes).
+inline bool se_wino2d_shape_ok(int dim, int cin, int cout) {
+    if (dim < 16 || (dim & 15) || cout <= 0 || (cout & 31) || cin <= 0 || (cin & 7)) return false;
+    return (long long)dim * dim * dim * (cin > cout ? cin : cout) * 4 < (1LL << 31);
+}
+
 struct ConvArgs {
     const float* in;
     const float* wpack;    // section A: [cg][tap][nt][lane][4]

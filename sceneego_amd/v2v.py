@@ -154,7 +154,7 @@ def channels_last_to_octet_planar(x):
 # the launch program
 # ------------------------------------------------------------------------------------------------
 class _PackedConv:
-    __slots__ = ("w", "b", "cin", "cin_pad", "cout", "k", "transposed")
+    __slots__ = ("w", "b", "cin", "cin_pad", "cout", "k", "transposed", "fused")
 
     def __init__(self, conv, bn, cin_pad=None, dtype=torch.float32):
         transposed = isinstance(conv, nn.ConvTranspose3d)
@@ -169,6 +169,7 @@ class _PackedConv:
         bf16 = dtype == torch.bfloat16
         self.cin_pad = cin_pad if cin_pad is not None else (_round8(cin) if bf16 else _round16(cin))
         self.cin, self.cout, self.k, self.transposed = cin, cout, k, transposed
+        self.fused = None     # 16-channel skip convolution only: (folded weights [cout][16], summed bias) for se_conv3d_skip16_f32
         n = _lib.conv3d_packed_elems(cout, self.cin_pad, k, transposed, bf16=bf16)
         self.w = torch.empty(n, device=dev, dtype=dtype)
         self.b = torch.empty(_round16(cout), device=dev, dtype=torch.float32)
@@ -194,7 +195,6 @@ class V2VProgram:
         self.cout = model.output_channels
         self.cin = model.input_channels
         self.cin_pad = _round8(self.cin) if dtype == torch.bfloat16 else _round16(self.cin)
-        self._fused_skip = {}
         fl, ed, bl = model.front_layers, model.encoder_decoder, model.back_layers
         basic = lambda m, cin_pad=None: _PackedConv(m.block[0], m.block[1], cin_pad, dtype)
         self.front0 = basic(fl[0], self.cin_pad)
@@ -220,7 +220,7 @@ class V2VProgram:
             # computes the skip path inside the second 3x3x3 convolution's launch
             conv, bn = m.skip_con[0], m.skip_con[1]
             scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
-            self._fused_skip[id(sk)] = ((conv.weight.detach().float().reshape(sk.cout, 16) * scale[:, None]).contiguous(), (c2.b + sk.b).contiguous())
+            sk.fused = ((conv.weight.detach().float().reshape(sk.cout, 16) * scale[:, None]).contiguous(), (c2.b + sk.b).contiguous())
         return (c1, c2, sk)
 
     # -- primitive launches ------------------------------------------------------------------
@@ -246,7 +246,7 @@ class V2VProgram:
         assert sk is None or not x_oct           # the 1x1x1 skip convolution reads channels-last
         mid = _lib.OUT_OCTET if w2d else 0
         a = self._conv(x, c1, B, dim, _lib.EPI_RELU | mid | (_lib.IN_OCTET if x_oct else 0))
-        fused = self._fused_skip.get(id(sk)) if sk is not None else None
+        fused = sk.fused if sk is not None else None
         if fused is not None and w2d and out_oct and pool_out is None and not x_oct:
             out = torch.empty((B, dim, dim, dim, c2.cout), device=self.device, dtype=self.dtype)
             _lib.conv3d_skip16(a, c2.w, fused[1], x, fused[0], out, B, dim, c2.cin, c2.cout, _lib.EPI_RELU | _lib.IN_OCTET | _lib.OUT_OCTET)

@@ -44,6 +44,9 @@ def test_pure_host_entry_points():
     lib = _lib.load()
     assert lib.se_conv3d_f32_algo(64, 32, 32, 3) in (1, 2) and lib.se_conv3d_f32_algo(64, 33, 16, 7) == 7
     assert lib.se_conv3d_f32_algo(8, 128, 128, 3) == 0 and lib.se_conv3d_f32_algo(64, 32, 15, 1) == 0
+    # the 2-D Winograd family (2) is reported exactly for the shapes its launcher takes: 32-bit offsets inside one sample
+    assert lib.se_conv3d_f32_algo(128, 32, 32, 3) == 2 and lib.se_conv3d_f32_algo(256, 32, 32, 3) != 2
+    assert lib.se_conv3d_f32_algo(256, 8, 32, 3) != 2 and lib.se_conv3d_f32_algo(64, 36, 32, 3) != 2
     # packed weight sizes: taps * cin_pad/16 * ceil(cout/16) * 256 floats
     assert lib.se_conv3d_packed_elems(32, 32, 3, 0) == 27 * 2 * 2 * 256 + 2 * 9 * 4 * 2 * 256 + 2 * 9 * 6 * 2 * 256 + 4 * 24 * 3 * 2 * 128   # + F(2,3), F(4,3), F(4,3)xF(2,3)
     assert lib.se_conv3d_packed_elems(15, 32, 1, 0) == 1 * 2 * 1 * 256

@@ -266,3 +266,23 @@ def test_pipelined_forward_matches_plain_forward(net64):
     for n, (out, done) in enumerate(outs):
         assert done.query()
         assert diffs[n][0] < 1e-4 and diffs[n][1] < 1e-4, diffs
+    # a replica of an ALREADY COMPILED module packs its own program and still takes the fused 16-channel skip path
+    # (the fused weights live on the packed convolution, not in a table keyed by object identity)
+    for rep in pf.nets:
+        prog = rep.volume_net.program
+        assert prog.front_res[0][2] is not None and prog.front_res[0][2].fused is not None
+    assert pf.nets[1].volume_net.program is not net64.volume_net.program
+    # default ordering - the pipeline stream waits for what the caller's stream has queued (here: non-blocking uploads
+    # from pinned memory and an in-place scaling kernel), and the inputs may be dropped right after the call
+    pin = [(i.pin_memory(), d.pin_memory()) for i, d in ((img, depth), (img2, depth2))]
+    outs = []
+    for n in range(4):
+        i, d = pin[n % 2]
+        di = i.to(DEV, non_blocking=True).mul_(1.0)
+        dd = d.to(DEV, non_blocking=True).mul_(1.0)
+        outs.append(pf(di, net64.grid_coord_proj_batch, net64.coord_volumes, depth_map_batch=dd))
+        del di, dd
+    for n, (out, done) in enumerate(outs):
+        PipelinedForward.hand_over(out, done)
+        err = float((out[0] - ref[n % 2][0]).abs().max())
+        assert err < 1e-4, (n, err)

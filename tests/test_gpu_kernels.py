@@ -290,6 +290,17 @@ def test_bad_arguments_are_refused():
     assert lib.se_conv3d_f32(p, p, p, None, p, 1, 8, 40, 32, 16, 3, 0, None, 0, None) == -1  # cin > cin_pad
     assert lib.se_maxpool3d_2_f32(p, p, 1, 7, 16, None) == -1                       # odd volume
     assert lib.se_softargmax3d_f32(p, p, p, p, p, 1, 6, 1, None) == -1              # voxels % 4
+    # the octet-planar / pooled / fused-skip forms exist in the 2-D Winograd kernel only.  Shapes and flag sets that kernel
+    # declines are refused (nothing launched) instead of falling through to a kernel that ignores those layouts:
+    OCT = _lib.IN_OCTET | _lib.OUT_OCTET
+    assert lib.se_conv3d_f32_algo(256, 32, 32, 3) != 2                               # 256^3 x 32 ch x 4 B >= 2^31: not a 2-D Winograd shape
+    assert lib.se_conv3d_f32(p, p, p, None, p, 1, 256, 32, 32, 32, 3, OCT, None, 0, None) == -1
+    assert lib.se_conv3d_pool_f32(p, p, p, None, p, p, 1, 256, 32, 32, 32, 3, OCT, None, 0, None) == -1
+    assert lib.se_conv3d_skip16_f32(p, p, p, p, p, p, 1, 256, 32, 32, OCT | _lib.EPI_RELU, None) == -1
+    assert lib.se_conv3d_f32_algo(64, 32, 32, 3) == 2
+    assert lib.se_conv3d_f32(p, p, p, p, p, 1, 64, 32, 32, 32, 3, OCT | _lib.EPI_RES_POST_RELU, None, 0, None) == -1   # flag the kernel declines
+    assert lib.se_conv3d_f32(p, p, p, None, p, 1, 64, 24, 32, 32, 3, OCT, None, 0, None) == -1                        # cin_pad != cin
+    assert lib.se_conv3d_pool_f32(p, p, p, None, p, p, 1, 64, 24, 32, 32, 3, OCT, None, 0, None) == -1
 
 
 # ------------------------------------------------------------------------------------------------

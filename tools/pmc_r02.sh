@@ -17,6 +17,7 @@ for (k, c), (n, v) in sorted(agg.items()):
     print(f"   {k:60s} {c:30s} launches {n:3d} per-launch {v / n:18.1f}")
 PY
 }
+[ -x tools/diag/copy_calib ] || hipcc -O3 --offload-arch=gfx950 tools/diag/copy_calib.hip -o tools/diag/copy_calib
 echo "== calibration (tools/diag/copy_calib: 1 GiB read + 1 GiB written per copy launch; gather reads 32 of every 128 B)"
 for pass in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pc_$pass

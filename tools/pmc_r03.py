@@ -11,8 +11,8 @@ last step with the launch key bench.py's own profiling pass recorded (--dump-lau
 
 Both carry the ABI version and the hash of sceneego_amd/csrc they were taken on (sceneego_amd/_lib.py: source_fingerprint);
 bench.py refuses a record whose fingerprint differs from the checkout it runs in.
-Unit corrections (guide): FETCH_SIZE is in KiB and reports half of the bytes of wide streaming reads on gfx950 (x2, re-checked by
-tools/diag/copy_calib in the calibration block below when that binary is present); WRITE_SIZE in KiB as is.
+Unit corrections (guide): FETCH_SIZE is in KiB and reports half of the bytes of wide streaming reads on gfx950 (x2, re-checked on every run by
+tools/diag/copy_calib, which is built here when missing); WRITE_SIZE in KiB as is.
 """
 import collections
 import csv
@@ -81,6 +81,36 @@ def run_pass(counters, batch, G):
     return steps[-1] if steps else None
 
 
+def calibrate():
+    """FETCH_SIZE / WRITE_SIZE on copies of a known size (tools/diag/copy_calib: 1 GiB read + 1 GiB written per launch); the
+    binary is built here when missing.  Returns {kernel: {counter: mean per launch}}."""
+    exe = os.path.join(ROOT, "tools", "diag", "copy_calib")
+    if not os.path.isfile(exe):
+        subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", exe + ".hip", "-o", exe], check=False)
+    if not os.path.isfile(exe):
+        return {}
+    res = collections.defaultdict(dict)
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(OUT, "r03cal_" + c)
+        shutil.rmtree(d, ignore_errors=True)
+        subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d, "--", exe],
+                       cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        acc = collections.defaultdict(list)
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            per = collections.defaultdict(float)
+            names = {}
+            for r in csv.DictReader(open(f)):
+                per[int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+                names[int(r["Dispatch_Id"])] = short(r["Kernel_Name"])
+            for k, v in per.items():
+                acc[names[k]].append(v)
+        for k, v in acc.items():
+            if k.startswith(("copy", "gather32")):
+                res[k][c] = round(sum(v) / len(v), 1)
+        shutil.rmtree(d, ignore_errors=True)
+    return dict(res)
+
+
 def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     G = int(sys.argv[2]) if len(sys.argv) > 2 else 64
@@ -97,6 +127,13 @@ def main():
         with open(p, "rb") as f:
             h.update(f.read())
     fingerprint = h.hexdigest()[:16]
+    try:
+        built = open(os.path.join(ROOT, "sceneego_amd", "libsceneego_hip.srchash")).read().strip()
+    except OSError:
+        built = None
+    if built != fingerprint:
+        print(f"libsceneego_hip.so was built from csrc {built}, the checkout is csrc {fingerprint}: rebuild before taking counters", file=sys.stderr)
+        sys.exit(1)
     abi = int(re.search(r"^ABI_VERSION = (\d+)", open(os.path.join(ROOT, "sceneego_amd", "_lib.py")).read(), re.M).group(1))
 
     # launch keys in issue order, from bench.py's own HIP-event pass (no profiler attached)
@@ -167,6 +204,12 @@ def main():
                     "per_launch": [{"pos": t["pos"], "kernel": t["kernel"],
                                     "hbm_bytes": int((2 * t["counters"].get("FETCH_SIZE", 0) + t["counters"].get("WRITE_SIZE", 0)) * 1024)}
                                    for t in dom]})
+    cal = calibrate()
+    if cal:
+        rec["calibration_kib_per_launch"] = dict(cal, note="tools/diag/copy_calib: copy16 / copy8 read and write 1 GiB = 1 048 576 KiB per "
+                                                 "launch, gather32of128 touches every line of 1 GiB and writes 256 MiB")
+        with open(os.path.join(OUT, "r03_pmc_table.txt"), "a") as f:
+            f.write("# calibration (KiB per launch; 1 GiB = 1048576 KiB read and written by copy16 / copy8): " + json.dumps(cal) + "\n")
     if k7:
         c = k7[0]["counters"]
         rec["conv7"] = {"kernel": k7[0]["kernel"], "fetch_kib_raw": c.get("FETCH_SIZE"), "write_kib": c.get("WRITE_SIZE"),
