@@ -111,10 +111,12 @@ class V2VModel(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     # -- execution ---------------------------------------------------------------------------
-    def compile(self, dtype=None) -> "V2VProgram":
+    def compile(self, dtype=None, output_scale=1.0) -> "V2VProgram":
         """(Re)build the HIP launch program from the current parameters (call after loading weights).
-        ``dtype``: torch.float32 (default; parity path) or torch.bfloat16 (bf16 storage, float32 accumulation)."""
-        self._program = V2VProgram(self, dtype or getattr(self, "program_dtype", torch.float32))
+        ``dtype``: torch.float32 (default; parity path) or torch.bfloat16 (bf16 storage, float32 accumulation).
+        ``output_scale``: ``run(..., scaled=True)`` returns output_scale * logits (the caller's ``volume_multiplier``,
+        reference network/voxel_net_depth.py:271, folded into the output layer); ``forward`` / ``run()`` return the plain logits."""
+        self._program = V2VProgram(self, dtype or getattr(self, "program_dtype", torch.float32), output_scale)
         return self._program
 
     @property
@@ -156,9 +158,13 @@ def channels_last_to_octet_planar(x):
 class _PackedConv:
     __slots__ = ("w", "b", "cin", "cin_pad", "cout", "k", "transposed", "fused")
 
-    def __init__(self, conv, bn, cin_pad=None, dtype=torch.float32):
+    def __init__(self, conv, bn, cin_pad=None, dtype=torch.float32, scale=1.0):
+        """``scale``: the packed layer computes scale * conv(x) (weights and bias multiplied before packing)."""
         transposed = isinstance(conv, nn.ConvTranspose3d)
         w = conv.weight.detach().float().contiguous()
+        if scale != 1.0:
+            assert bn is None
+            w = w * float(scale)
         dev = w.device
         if transposed:
             cin, cout = w.shape[0], w.shape[1]
@@ -180,13 +186,17 @@ class _PackedConv:
         else:
             g = be = mu = var = None
             eps = 0.0
-        _lib.conv3d_pack(w, f(conv.bias), g, be, mu, var, eps, self.w, self.b, cout, cin, self.cin_pad, k, transposed)
+        bias = f(conv.bias)
+        if scale != 1.0 and bias is not None:
+            bias = bias * float(scale)
+        _lib.conv3d_pack(w, bias, g, be, mu, var, eps, self.w, self.b, cout, cin, self.cin_pad, k, transposed)
 
 
 class V2VProgram:
-    def __init__(self, model: V2VModel, dtype=torch.float32):
+    def __init__(self, model: V2VModel, dtype=torch.float32, output_scale=1.0):
         assert dtype in (torch.float32, torch.bfloat16)
         self.dtype = dtype
+        self.output_scale = float(output_scale)
         p = next(model.parameters())
         if not p.is_cuda:
             raise _lib.HipExtensionError("V2VModel must live on a HIP device to be compiled (got %s)" % p.device)
@@ -208,6 +218,7 @@ class V2VProgram:
         self.back1 = basic(bl[1])
         self.back2 = basic(bl[2])
         self.out = _PackedConv(model.output_layer, None, None, dtype)
+        self.out_scaled = self.out if self.output_scale == 1.0 else _PackedConv(model.output_layer, None, None, dtype, scale=self.output_scale)
         # scratch for the split-K path of the small pyramid levels (se_conv3d_f32 workspace): 32 Mi floats
         self.workspace = torch.empty(32 << 20, device=self.device, dtype=torch.float32) if dtype == torch.float32 else None
 
@@ -276,11 +287,12 @@ class V2VProgram:
         return out
 
     # -- the network -------------------------------------------------------------------------
-    def run(self, x, B, G, out=None, softargmax=None):
+    def run(self, x, B, G, out=None, softargmax=None, scaled=False):
         """x: [B,G,G,G,cin_pad] channels-last (channels >= cin zero; bf16: octet-planar [B,cin_pad/8,G,G,G,8]; float32 may
         also be triplet-planar [B,ceil(cin/3),G,G,G,3], which the 7^3 front layer reads with ~5x fewer cache-line requests)
-        -> planar logits [B,cout,G^3]."""
+        -> planar logits [B,cout,G^3] (``scaled``: times ``output_scale``)."""
         assert x.is_contiguous() and x.dtype == self.dtype
+        outc = self.out_scaled if scaled else self.out
         planar3 = self.dtype == torch.float32 and x.dim() == 6       # float32 triplet-planar [B,ceil(cin/3),G,G,G,3]
         if planar3:
             assert tuple(x.shape) == (B, (self.cin + 2) // 3, G, G, G, 3)
@@ -331,10 +343,9 @@ class V2VProgram:
         if self.cout <= 16:
             # back_layers.1 / .2 / output_layer fused: one read of x, one planar write of the logits
             # ``softargmax`` = (coord, scratch): float32 program only - pass 1 of the soft-argmax rides in the same launch
-            _lib.pointwise_chain3(x, self.back1, self.back2, self.out, out, B, G, softargmax=softargmax if self.dtype == torch.float32 else None)
+            _lib.pointwise_chain3(x, self.back1, self.back2, outc, out, B, G, softargmax=softargmax if self.dtype == torch.float32 else None)
             return out
         x = self._conv(x, self.back1, B, G, _lib.EPI_RELU)
         x = self._conv(x, self.back2, B, G, _lib.EPI_RELU)
-        _lib.conv3d(x, self.out.w, self.out.b, None, out, B, G, self.out.cin, self.out.cin_pad, self.out.cout, 1,
-                    _lib.EPI_OUT_PLANAR)
+        _lib.conv3d(x, outc.w, outc.b, None, out, B, G, outc.cin, outc.cin_pad, outc.cout, 1, _lib.EPI_OUT_PLANAR)
         return out

@@ -175,7 +175,8 @@ class VoxelNetwork_depth(nn.Module):
         w = pf.weight.detach().to(dtype).contiguous()
         b = pf.bias.detach().to(dtype)
         self._folded = (fb, w, b)
-        self.volume_net.compile(self.v2v_dtype)
+        # volume_multiplier (reference :271 ``volumes * self.volume_multiplier``) is folded into the output layer's packed weights
+        self.volume_net.compile(self.v2v_dtype, output_scale=float(self.volume_multiplier))
         return self
 
     def _device_tables(self, grid_coord_proj_batch, coord_volumes, device):
@@ -273,6 +274,8 @@ class VoxelNetwork_depth(nn.Module):
 
         # lift to the volume: V2V input buffer [B,G,G,G,cin_pad], zero beyond the real channels
         prog = self.volume_net.program
+        if prog.output_scale != float(self.volume_multiplier):      # the attribute was changed after compile()
+            prog = self.volume_net.compile(self.v2v_dtype, output_scale=float(self.volume_multiplier))
         C = FEATURE_CHANNELS
         # V2V input buffer: persistent per batch size, zero-filled once (pad channels stay zero; every call rewrites
         # the real channels), so no per-call clearing pass is needed
@@ -306,15 +309,13 @@ class VoxelNetwork_depth(nn.Module):
         if xb is not None:
             xb.copy_(x.view(B, G, G, G, prog.cin_pad // 8, 8).permute(0, 4, 1, 2, 3, 5))
             x = xb
-        # float32 V2V with softmax volumes and no logit scaling: pass 1 of the soft-argmax is computed by the V2V tail launch while
-        # the logits are in registers (se_pointwise_chain3_softargmax_f32); otherwise the two-pass kernel reads them back
-        fused_sa = (prog.dtype == torch.float32 and self.volume_softmax and self.volume_multiplier == 1.0 and prog.cout <= 16
+        # float32 V2V with softmax volumes: pass 1 of the soft-argmax is computed by the V2V tail launch while the (scaled) logits
+        # are in registers (se_pointwise_chain3_softargmax_f32); otherwise the two-pass kernel reads them back
+        fused_sa = (prog.dtype == torch.float32 and self.volume_softmax and prog.cout <= 16
                     and ((N + 31) // 32 + 3) // 4 * 4 % 16 == 0)
         sa_scratch = torch.empty(_lib.softargmax3d_scratch_elems(B * self.num_joints), device=dev, dtype=torch.float32) if fused_sa else None
         with _lib.stage("v2v"):
-            logits = prog.run(x, B, G, softargmax=(self._coord_flat, sa_scratch) if fused_sa else None)   # [B,J,N] planar
-        if self.volume_multiplier != 1.0:
-            logits = logits * self.volume_multiplier
+            logits = prog.run(x, B, G, softargmax=(self._coord_flat, sa_scratch) if fused_sa else None, scaled=True)   # [B,J,N] planar, x volume_multiplier
         joints = torch.empty((B, self.num_joints, 3), device=dev, dtype=torch.float32)
         volumes = torch.empty_like(logits)
         with _lib.stage("softargmax"):

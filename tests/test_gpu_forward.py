@@ -72,6 +72,92 @@ def test_forward_g128_vs_golden(golden, golden_meta):
     _check_against_golden(_build(volume_size=128), golden("b1_g128_floor"), m)
 
 
+# ---- configuration branches of the reference forward (goldens: tools/make_golden.py --only-branches) --------------------------
+def _build_cfg(**model_overrides):
+    cfg = load_config()
+    for k, v in model_overrides.items():
+        setattr(cfg.model, k, v)
+    net = VoxelNetwork_depth(cfg, device="cpu", verbose=False)
+    net.load_state_dict(synth.make_state_dict(net.state_dict(), seed=0), strict=True)
+    return net.to(DEV).eval()
+
+
+def test_forward_no_scene_vs_golden(golden, golden_meta):
+    """`with_scene: False` (network/voxel_net_depth.py:65-77): V2VModel(32, 15) on the gathered feature volume alone - the shape of the
+    reference author's own benchmark (network/v2v.py:259-270).  The 7^3 front layer then has 32 input channels (channels-last F(4,7)
+    form, ragged last 3-channel chunk)."""
+    m = next(c for c in golden_meta["cases"] if c["name"] == "b1_noscene")
+    g = golden("b1_noscene")
+    net = _build_cfg(with_scene=False)
+    assert net.volume_net.input_channels == 32
+    img, _ = synth.make_inputs(m["input_seed"], m["batch"], m["depth_kind"])
+    with torch.no_grad():
+        kp, feats, vols, _ = net(img.to(DEV), net.grid_coord_proj_batch, net.coord_volumes)      # no scene input needed (:263 not taken)
+    torch.cuda.synchronize()
+    err = float(np.abs(kp.cpu().numpy() - g["joints"]).max())
+    print(f"with_scene False: joints vs reference golden {err:.2e} m")
+    assert err <= JOINT_TOL, err
+    pos = torch.from_numpy(g["sample_pos"]).to(DEV)
+    vs = vols.reshape(1, 15, -1)[:, :, pos].cpu().numpy()
+    assert np.abs(vs - g["volumes_samples"]).max() <= 2e-3 * g["volumes_max"].max() + 1e-7
+    # B=8 (the author's benchmark batch): every frame equals its own B=1 run
+    img8, _ = synth.make_inputs(61, 8, "uniform")
+    with torch.no_grad():
+        kp8 = net(img8.to(DEV), net.grid_coord_proj_batch, net.coord_volumes)[0]
+        one = net(img8[5:6].to(DEV), net.grid_coord_proj_batch, net.coord_volumes)[0]
+    assert float((kp8[5:6] - one).abs().max()) < 5e-5
+
+
+def test_forward_volume_multiplier_vs_golden(golden, golden_meta):
+    """`volume_multiplier: 2.0` (network/voxel_net_depth.py:271): folded into the output layer's packed weights, so the fused
+    soft-argmax pass stays on; the plain V2VModel.forward still returns the unscaled logits."""
+    m = next(c for c in golden_meta["cases"] if c["name"] == "b1_multiplier2")
+    g = golden("b1_multiplier2")
+    net = _build_cfg(volume_multiplier=2.0)
+    img, depth = synth.make_inputs(m["input_seed"], m["batch"], m["depth_kind"])
+    from sceneego_amd import _lib
+    calls = []
+    orig = _lib.softargmax3d_finish
+    _lib.softargmax3d_finish = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        kp, _, vols, _ = _forward(net, img, depth)
+    finally:
+        _lib.softargmax3d_finish = orig
+    assert calls, "the fused soft-argmax path must stay on with volume_multiplier != 1"
+    err = float(np.abs(kp.cpu().numpy() - g["joints"]).max())
+    print(f"volume_multiplier 2: joints vs reference golden {err:.2e} m")
+    assert err <= JOINT_TOL, err
+    pos = torch.from_numpy(g["sample_pos"]).to(DEV)
+    vs = vols.reshape(1, 15, -1)[:, :, pos].cpu().numpy()
+    assert np.abs(vs - g["volumes_samples"]).max() <= 2e-3 * g["volumes_max"].max() + 1e-7
+    prog = net.volume_net.program
+    assert prog.output_scale == 2.0 and prog.out_scaled is not prog.out
+    # changing the attribute after compile() takes effect at the next forward
+    net.volume_multiplier = 1.0
+    kp1 = _forward(net, img, depth)[0]
+    assert net.volume_net.program.output_scale == 1.0 and float((kp1 - kp).abs().max()) > 1e-3
+
+
+def test_forward_relu_volumes_vs_golden(golden, golden_meta):
+    """`volume_softmax: False` (utils/op.py:89-91): ReLU without normalisation, joints = sum relu(v) * coord ~ 1e4..1e6 (not
+    metres).  The reference's float32 einsum of that sum differs from the float64 evaluation of its own logits by 1e-7 relative
+    (META.json: joints_f32_vs_f64_evaluation 0.25 at |joint| 2.3e6), so the bound is relative: 1e-4 of the largest coordinate."""
+    m = next(c for c in golden_meta["cases"] if c["name"] == "b1_relu_volumes")
+    g = golden("b1_relu_volumes")
+    net = _build_cfg(volume_softmax=False)
+    img, depth = synth.make_inputs(m["input_seed"], m["batch"], m["depth_kind"])
+    kp, _, vols, _ = _forward(net, img, depth)
+    scale = float(np.abs(g["joints"]).max())
+    err = float(np.abs(kp.cpu().numpy() - g["joints"]).max())
+    err64 = float(np.abs(kp.cpu().numpy() - g["joints_f64_evaluation"]).max())
+    print(f"volume_softmax False: |joint| up to {scale:.3e}; vs reference float32 {err:.3e}, vs float64 evaluation {err64:.3e}")
+    assert err <= 1e-4 * scale and err64 <= 1e-4 * scale, (err, err64, scale)
+    pos = torch.from_numpy(g["sample_pos"]).to(DEV)
+    vs = vols.reshape(1, 15, -1)[:, :, pos].cpu().numpy()
+    assert float(vs.min()) >= 0.0
+    assert np.abs(vs - g["volumes_samples"]).max() <= 1e-4 * float(np.abs(g["logits_samples"]).max())
+
+
 def test_v2v_stagewise_vs_oracle(net64, oracle_constants):
     """Every stage boundary of the pipeline against the oracle on the same seeded input (B=1)."""
     sd = synthetic_state_dict(False)

@@ -75,6 +75,39 @@ def test_oracle_g128(golden, oracle_constants, golden_meta):
     _check(*_run("b1_g128_floor", golden, oracle_constants, golden_meta))
 
 
+def _branch_state_dict(m):
+    from sceneego_amd import load_config
+    from sceneego_amd.voxel_net_depth import VoxelNetwork_depth
+    cfg = load_config()
+    cfg.model.with_scene = m.get("with_scene", True)
+    net = VoxelNetwork_depth(cfg, device="cpu", verbose=False)
+    return synth.make_state_dict(net.state_dict(), seed=m["weight_seed"])
+
+
+@pytest.mark.parametrize("case", ["b1_noscene", "b1_relu_volumes", "b1_multiplier2"])
+def test_oracle_config_branches(case, golden, oracle_constants, golden_meta):
+    """with_scene False (network/voxel_net_depth.py:65-77), volume_softmax False (utils/op.py:89-91) and volume_multiplier 2
+    (network/voxel_net_depth.py:271) through the whole forward, against goldens of the reference run with those settings."""
+    m = next(c for c in golden_meta["cases"] if c["name"] == case)
+    g = golden(case)
+    sd = _branch_state_dict(m) if not m["with_scene"] else synthetic_state_dict(False, m["weight_seed"])
+    const = oracle_constants(64)
+    img, depth = case_inputs(m)
+    taps = {}
+    joints, _, vols = O.forward(sd, const, img, depth if m["with_scene"] else None, with_scene=m["with_scene"],
+                                volume_softmax=m["volume_softmax"], volume_multiplier=m["volume_multiplier"], taps=taps)
+    pos = g["sample_pos"]
+    lg = taps["logits"].reshape(1, -1, 64 ** 3)[:, :, pos].numpy()
+    assert np.abs(lg - g["logits_samples"]).max() <= 1e-4 * np.abs(g["logits_samples"]).max()
+    scale = max(1.0, float(np.abs(g["joints"]).max()) / 2.0)        # the ReLU mode's joints are un-normalised sums (~1e6)
+    assert np.abs(joints.numpy() - g["joints"]).max() <= JOINT_TOL * scale
+    if m["with_scene"]:
+        occ = taps["occupancy"].reshape(1, -1).numpy().astype(np.uint8)
+        assert np.array_equal(np.packbits(occ[0]), g["occupancy_bits"][0])
+    else:
+        assert taps["feature_volume"].shape[1] == 32 and "occupancy" not in taps
+
+
 def test_oracle_constants_and_kat(golden, oracle_constants):
     g = golden("constants")
     c = oracle_constants(64)

@@ -100,11 +100,14 @@ def sample_positions(n_total, count, seed):
 
 
 def run_case(name, RefNet, cfg_mod, synth, O, *, batch, in_seed, depth_kind, with_intersection=False, volume_size=64,
-             weight_seed=0, extra=None):
+             weight_seed=0, extra=None, with_scene=True, volume_softmax=True, volume_multiplier=1.0):
     print(f"== case {name}")
     config = cfg_mod.load_config("experiments/sceneego/test/sceneego.yaml")
     config.model.with_intersection = with_intersection
     config.model.volume_size = volume_size
+    config.model.with_scene = with_scene                  # network/voxel_net_depth.py:65-77 (False: V2VModel(32, 15), no depth input)
+    config.model.volume_softmax = volume_softmax          # utils/op.py:86-91 (False: ReLU, no normalisation)
+    config.model.volume_multiplier = volume_multiplier    # network/voxel_net_depth.py:271
     t0 = time.time()
     net = RefNet(config, device="cpu").eval()
     sd = synth.make_state_dict(net.state_dict(), seed=weight_seed)
@@ -140,14 +143,15 @@ def run_case(name, RefNet, cfg_mod, synth, O, *, batch, in_seed, depth_kind, wit
             hooks.append(mod.register_forward_hook(_h_layer))
     with torch.no_grad():
         t1 = time.time()
-        kp, feats, vols, cv = net(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth)
+        kp, feats, vols, cv = net(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth if with_scene else None)
         t_fwd = time.time() - t1
     for h in hooks:
         h.remove()
     G = volume_size
     N = G ** 3
     occ_ch = 64 if with_intersection else 32
-    occ = taps["v2v_in"][:, occ_ch]
+    occ = taps["v2v_in"][:, occ_ch] if with_scene else torch.zeros((batch, G, G, G))
+    assert taps["v2v_in"].shape[1] == (65 if with_intersection else 33 if with_scene else 32)
     print(f"   init+load {t1 - t0:.1f}s forward {t_fwd:.1f}s joints[0,0]={kp[0, 0].tolist()} occupied={occ.sum(dim=(1, 2, 3)).tolist()}")
 
     pos = sample_positions(N, 1024, 99)
@@ -170,7 +174,15 @@ def run_case(name, RefNet, cfg_mod, synth, O, *, batch, in_seed, depth_kind, wit
     # ---- oracle on the same inputs: this is the pin -------------------------------------------
     const = O.Constants(os.path.join(ROOT, "sceneego_amd", "calibration", "fisheye.calibration_05_08.json"), G=G)
     otaps = {}
-    oj, obig, ovols = O.forward(sd, const, img, depth, with_intersection=with_intersection, taps=otaps)
+    oj, obig, ovols = O.forward(sd, const, img, depth if with_scene else None, with_scene=with_scene, with_intersection=with_intersection,
+                                volume_softmax=volume_softmax, volume_multiplier=volume_multiplier, taps=otaps)
+    if not with_scene:
+        otaps["occupancy"] = occ
+    # the same formula with float64 sums, from the REFERENCE's logits: what a platform-independent evaluation gives (the float32
+    # einsum over G^3 terms is reduction-order dependent; for the un-normalised ReLU mode the sums are ~1e5 and the float32 noise
+    # is correspondingly large) - recorded so the GPU tests can state their tolerance against both
+    kp64 = O.integrate(taps["logits"] * volume_multiplier, const.coord, softmax=volume_softmax, accumulate64=True)[0]
+    gold["joints_f64_evaluation"] = kp64.numpy().astype(np.float32)
     diffs = {
         "joints": float((oj - kp).abs().max()),
         "features64": float((otaps["features64"] - taps["features64"]).abs().max()),
@@ -179,13 +191,16 @@ def run_case(name, RefNet, cfg_mod, synth, O, *, batch, in_seed, depth_kind, wit
         "logits": float((otaps["logits"] - taps["logits"]).abs().max()),
         "volumes": float((ovols - vols).abs().max()),
         "features_big": float((obig - feats).abs().max()),
+        "joints_f32_vs_f64_evaluation": float((kp64 - kp).abs().max()),
+        "joints_absmax": float(kp.abs().max()),
     }
     print("   oracle vs reference:", diffs)
     if extra is not None:
         extra(net, gold)
     np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **gold)
     meta = dict(name=name, batch=batch, input_seed=in_seed, depth_kind=depth_kind, with_intersection=with_intersection,
-                volume_size=volume_size, weight_seed=weight_seed, oracle_vs_reference=diffs,
+                volume_size=volume_size, weight_seed=weight_seed, with_scene=with_scene, volume_softmax=volume_softmax,
+                volume_multiplier=volume_multiplier, oracle_vs_reference=diffs,
                 reference_forward_s=round(t_fwd, 2))
     return meta, net
 
@@ -268,6 +283,21 @@ def main():
         meta["cases"] = [c for c in meta["cases"] if c["name"] != m["name"]] + [m]
         with open(os.path.join(GOLD, "META.json"), "w") as f:
             json.dump(meta, f, indent=1)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-branches":
+        # round 3: the configuration branches of the reference forward no golden covered yet
+        new = [
+            run_case("b1_noscene", RefNet, cfg_mod, synth, O, batch=1, in_seed=606, depth_kind="floor", with_scene=False)[0],
+            run_case("b1_relu_volumes", RefNet, cfg_mod, synth, O, batch=1, in_seed=707, depth_kind="floor", volume_softmax=False)[0],
+            run_case("b1_multiplier2", RefNet, cfg_mod, synth, O, batch=1, in_seed=808, depth_kind="uniform", volume_multiplier=2.0)[0],
+        ]
+        with open(os.path.join(GOLD, "META.json")) as f:
+            meta = json.load(f)
+        names = {m["name"] for m in new}
+        meta["cases"] = [c for c in meta["cases"] if c["name"] not in names] + new
+        with open(os.path.join(GOLD, "META.json"), "w") as f:
+            json.dump(meta, f, indent=1)
+        assert not any(d == "__pycache__" for _, ds, _ in os.walk(REF) for d in ds), "reference tree was modified!"
         return
     m, net = run_case("b2_uniform", RefNet, cfg_mod, synth, O, batch=2, in_seed=1234, depth_kind="uniform")
     metas.append(m)
