@@ -410,24 +410,31 @@ def test_voxelize_strided_into_v2v_buffer(voxel_setup):
     assert float(got[..., :32].min()) == 5.0 and float(got[..., 36:].min()) == 5.0
 
 
-def test_preprocess_image_device_matches_host():
-    """f1: crop 128 / exact quarter resize / BGR normalisation on the device == the host restatement, bit for bit."""
+def test_preprocess_image_device_matches_reference_fixture(golden):
+    """f1: crop 128 / exact quarter resize / BGR normalisation on the device (se_preprocess_image_u8) against the output of the
+    REFERENCE's DemoDataset.__getitem__ + Normalize + ToTensor on the same seeded frames (tests/golden/preprocess.npz, captured by
+    tools/make_golden.py --only-preprocess), bit for bit; the half-size depth upload + device clamp + the voxeliser's own nearest
+    lookup against the oracle's voxeliser fed with the reference's depth tensor (whose hash tests/test_host_logic.py pins)."""
     from sceneego_amd import preprocess as pp
-    rng = np.random.default_rng(5)
-    frames = rng.integers(0, 256, size=(2, 1024, 1280, 3), dtype=np.uint8)
-    got = pp.preprocess_image_device(torch.from_numpy(frames).to(DEV)).cpu()
-    want = torch.stack([pp.preprocess_image(f) for f in frames])
-    assert got.shape == (2, 3, 256, 256) and torch.equal(got, want)
+    g = golden("preprocess")
+    frame = lambda seed: (synth.uniform01(seed, "f1/frame", 1024 * 1280 * 3) * 256.0).astype(np.uint8).reshape(1024, 1280, 3)
+    frames = np.stack([frame(31), frame(33)])
+    got = pp.preprocess_image_device(torch.from_numpy(frames).to(DEV)).cpu().numpy()
+    assert got.shape == (2, 3, 256, 256)
+    assert np.array_equal(got[0], g["synth_a_image"]) and np.array_equal(got[1], g["synth_b_image"])
     with pytest.raises(ValueError):
         pp.preprocess_image_device(torch.zeros((1, 512, 640, 3), dtype=torch.uint8, device=DEV))
-    # half-size depth map: the voxeliser's own nearest lookup == the reference's two nearest resizes (host prepare_depth)
+    # half-size depth map (seed 32, [512,640], values up to 12 m): device clamp + the voxeliser's nearest lookup == the oracle's
+    # voxeliser on the reference's [1024,1280] depth tensor (nearest resize + clamp done by the reference's code)
     c = O.Constants(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sceneego_amd", "calibration",
                                  "fisheye.calibration_05_08.json"), G=64)
     tab = torch.from_numpy(op.build_voxelizer_ray_table(c.ray, 1280, 1024)).to(DEV)
-    d = (rng.random((1, 512, 640), dtype=np.float32) * 12).astype(np.float32)
+    d = (synth.uniform01(32, "f1/depth", 512 * 640) * 12.0).astype(np.float32).reshape(1, 512, 640)
     a = _hip_voxelize(torch.from_numpy(d).to(DEV).clamp_(max=10.0), tab)
-    b = _hip_voxelize(pp.prepare_depth(d[0])[None].to(DEV), tab)
-    assert torch.equal(a, b)
+    ref_depth = pp.prepare_depth(d[0])                                   # == the reference's tensor (hash-pinned on the CPU side)
+    assert np.array_equal(ref_depth.numpy()[::16, ::16], g["synth_a_depth_sub"])
+    want = O.depth_to_voxel(ref_depth.numpy(), c.ray, 64, 2)
+    assert torch.equal(a[0].cpu(), want)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -237,6 +237,44 @@ def test_exr_piz_demo_depth_map():
     assert tuple(out.shape) == (1024, 1280) and float(out.max()) == 10.0
 
 
+def _f1_frame(seed):
+    return (synth.uniform01(seed, "f1/frame", 1024 * 1280 * 3) * 256.0).astype(np.uint8).reshape(1024, 1280, 3)
+
+
+def _f1_depth(seed, shape):
+    return (synth.uniform01(seed, "f1/depth", int(np.prod(shape))) * 12.0).astype(np.float32).reshape(shape)
+
+
+def test_preprocessing_matches_reference_dataset_code(golden):
+    """f1 pin: sceneego_amd/preprocess.py against outputs of the reference's own DemoDataset.__getitem__ + Normalize + ToTensor
+    (dataset/demo_dataset.py:67-98, utils/data_transforms.py:38-72), captured by tools/make_golden.py --only-preprocess on seeded
+    arrays and on the reference's demo frame.  Bit-exact.  (Unpinned, and said so in DESIGN.md: JPEG decoding, cv2.resize
+    INTER_LINEAR / INTER_NEAREST, OpenEXR decoding - the three OpenCV calls were stubs when the fixture was captured.)"""
+    import hashlib
+    import json
+    from sceneego_amd import preprocess as pp
+    from conftest import GOLD
+    g = golden("preprocess")
+    with open(os.path.join(GOLD, "preprocess.json")) as f:
+        rec = json.load(f)["outputs"]
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    for name, fs, ds, dshape in (("synth_a", 31, 32, (512, 640)), ("synth_b", 33, 34, (1024, 1280, 3))):
+        img = pp.preprocess_image(_f1_frame(fs))
+        assert img.dtype == torch.float32 and np.array_equal(img.numpy(), g[name + "_image"]), name
+        assert sha(img.numpy()) == rec[name]["image_sha256"]
+        d = _f1_depth(ds, dshape)
+        d = d[:, :, 0] if d.ndim == 3 else d                      # load_depth's channel rule (demo_dataset.py:88-89)
+        out = pp.prepare_depth(d).numpy()
+        assert out.dtype == np.float32 and sha(out) == rec[name]["depth_sha256"], name
+        assert np.array_equal(out[::16, ::16], g[name + "_depth_sub"]) and int((out == 10.0).sum()) == rec[name]["depth_clamped_pixels"]
+    # the reference's demo frame: the committed 256x256 uint8 fixture normalises to exactly what the reference produced from the
+    # JPEG, and the committed EXR goes through the product reader + prepare_depth to exactly the reference's depth tensor
+    small = np.load(os.path.join(GOLD, "demo", "img_001000_256_bgr_u8.npz"))["img"]
+    assert np.array_equal(pp.normalize_u8(small).numpy(), g["img_001000_image"])
+    depth = pp.prepare_depth(pp.load_depth(os.path.join(GOLD, "demo", "img_001000.jpg.exr"))).numpy()
+    assert sha(depth) == rec["img_001000"]["depth_sha256"] and np.array_equal(depth[::16, ::16], g["img_001000_depth_sub"])
+
+
 def test_metrics_against_reference_umeyama(golden):
     """f4: MPJPE / PA-MPJPE on the reference's Umeyama alignment (goldens from tools/make_golden_metrics.py) + properties."""
     import importlib.util

@@ -205,6 +205,88 @@ def run_case(name, RefNet, cfg_mod, synth, O, *, batch, in_seed, depth_kind, wit
     return meta, net
 
 
+def preprocess_case(synth):
+    """f1 pin: the REAL ``DemoDataset.__getitem__`` (dataset/demo_dataset.py:67-98) with the real ``Normalize`` / ``ToTensor``
+    (utils/data_transforms.py:38-72) run on known arrays.  Only the three OpenCV calls are stubs (no cv2 in this image):
+    ``cv2.imread`` hands over a prepared array (PIL's libjpeg-turbo decode for the demo JPEG, oracle/exr_oracle.py for the demo
+    EXR, seeded arrays otherwise), ``cv2.resize`` INTER_LINEAR is the restated exact-quarter mapping, INTER_NEAREST the restated
+    floor mapping - those stay "parity unpinned".  Everything between them is the reference's own code: the 128-column crop, /255,
+    mean / std in BGR order, HWC->CHW, float(); ``[:, :, 0]``, the 10 m clamp, float()."""
+    import tempfile
+    from dataset.demo_dataset import DemoDataset
+    from utils import cfg as cfg_mod
+    import cv2 as cv2_stub
+    from oracle import exr_oracle
+    from PIL import Image
+
+    def frame_u8(seed):        # portable seeded full frame [1024,1280,3] uint8 (what tests regenerate on any box)
+        return (synth.uniform01(seed, "f1/frame", 1024 * 1280 * 3) * 256.0).astype(np.uint8).reshape(1024, 1280, 3)
+
+    def depth_f32(seed, shape):  # seeded depth in [0, 12) m: about 1/6 of the pixels exceed the 10 m clamp
+        return (synth.uniform01(seed, "f1/depth", int(np.prod(shape))) * 12.0).astype(np.float32).reshape(shape)
+
+    with Image.open(os.path.join(REF, "data", "demo", "imgs", "img_001000.jpg")) as im:
+        demo_bgr = np.ascontiguousarray(np.asarray(im.convert("RGB"))[:, :, ::-1])
+    demo_depth = exr_oracle.read(os.path.join(REF, "data", "demo", "depths", "img_001000.jpg.exr"))["Y"].astype(np.float32)
+    arrays = {
+        "synth_a.png": frame_u8(31), "synth_a.png.exr": depth_f32(32, (512, 640)),            # native half-size depth, 1 channel
+        "synth_b.png": frame_u8(33), "synth_b.png.exr": depth_f32(34, (1024, 1280, 3)),       # full size, 3 channels
+        "img_001000.jpg": demo_bgr, "img_001000.jpg.exr": demo_depth,
+    }
+    calls = []
+
+    def _imread(path, flags=None):
+        calls.append(("imread", os.path.basename(path), flags))
+        return arrays[os.path.basename(path)].copy()
+
+    def _resize(src, dsize, interpolation=1):
+        calls.append(("resize", tuple(src.shape), tuple(dsize), interpolation))
+        w, h = dsize
+        if interpolation == 0:
+            ys = np.minimum((np.arange(h) * (src.shape[0] / h)).astype(np.int64), src.shape[0] - 1)
+            xs = np.minimum((np.arange(w) * (src.shape[1] / w)).astype(np.int64), src.shape[1] - 1)
+            return src[ys][:, xs]
+        assert src.dtype == np.uint8 and src.shape[0] == 4 * h and src.shape[1] == 4 * w      # INTER_LINEAR at exactly 1/4
+        a = src.astype(np.uint16)
+        return ((a[1::4, 1::4] + a[1::4, 2::4] + a[2::4, 1::4] + a[2::4, 2::4] + 2) >> 2).astype(np.uint8)
+
+    cv2_stub.imread, cv2_stub.resize = _imread, _resize
+    import dataset.demo_dataset as dd
+    dd.cv2.imread, dd.cv2.resize = _imread, _resize
+    config = cfg_mod.load_config("experiments/sceneego/test/sceneego.yaml")
+    gold = {}
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    info = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        idir, ddir = os.path.join(tmp, "imgs"), os.path.join(tmp, "depths")
+        os.makedirs(idir); os.makedirs(ddir)
+        for name in ("synth_a.png", "synth_b.png", "img_001000.jpg"):
+            open(os.path.join(idir, name), "wb").close()
+            open(os.path.join(ddir, name + ".exr"), "wb").close()
+        ds = DemoDataset(config, idir, ddir, voxel_output=False)
+        for i in range(len(ds)):
+            img_t, img_rgb_t, depth_t, path = ds[i]
+            name = os.path.splitext(os.path.basename(path))[0]
+            assert img_t.dtype == torch.float32 and tuple(img_t.shape) == (3, 256, 256)
+            assert depth_t.dtype == torch.float32 and tuple(depth_t.shape) == (1024, 1280)
+            d = depth_t.numpy()
+            info[name] = {"image_sha256": sha(img_t.numpy()), "image_rgb_sha256": sha(img_rgb_t.numpy()), "depth_sha256": sha(d),
+                          "depth_max": float(d.max()), "depth_clamped_pixels": int((d == 10.0).sum())}
+            gold[name + "_image"] = img_t.numpy()
+            gold[name + "_depth_sub"] = d[::16, ::16].copy()
+            print("  ", name, info[name])
+    gold["seeds"] = np.array([31, 32, 33, 34])
+    np.savez_compressed(os.path.join(GOLD, "preprocess.npz"), **gold)
+    with open(os.path.join(GOLD, "preprocess.json"), "w") as f:
+        json.dump({"generator": "tools/make_golden.py --only-preprocess: reference DemoDataset.__getitem__ + Normalize + ToTensor on known "
+                                "arrays; cv2.imread / cv2.resize are stubs (see preprocess_case)",
+                   "inputs": {"synth_a": "frame synth.uniform01(31, 'f1/frame') * 256 -> uint8 [1024,1280,3]; depth uniform01(32, 'f1/depth') * 12 -> float32 [512,640]",
+                              "synth_b": "frame seed 33; depth seed 34, float32 [1024,1280,3] (channel 0 is the map)",
+                              "img_001000": "reference data/demo/imgs/img_001000.jpg decoded by PIL (libjpeg-turbo) + data/demo/depths/img_001000.jpg.exr decoded by oracle/exr_oracle.py"},
+                   "cv2_calls_made_by_the_reference": [list(map(str, c)) for c in calls], "outputs": info}, f, indent=1)
+    print("wrote preprocess.npz / preprocess.json")
+
+
 def constants_case(net, op_mod):
     """Init-time constants + the reference's own soft-argmax known-answer case (voxel_net_depth.py:302-320)."""
     gold = {}
@@ -283,6 +365,10 @@ def main():
         meta["cases"] = [c for c in meta["cases"] if c["name"] != m["name"]] + [m]
         with open(os.path.join(GOLD, "META.json"), "w") as f:
             json.dump(meta, f, indent=1)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-preprocess":
+        preprocess_case(synth)
+        assert not any(d == "__pycache__" for _, ds, _ in os.walk(REF) for d in ds), "reference tree was modified!"
         return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-branches":
         # round 3: the configuration branches of the reference forward no golden covered yet
