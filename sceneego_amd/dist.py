@@ -25,13 +25,19 @@ def init_from_env(backend: str | None = None, device_type: str = "cuda"):
     """Initialise ``torch.distributed`` from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*; returns (rank, world, device)."""
     rank, local_rank, world = env_world()
     if device_type == "cuda":
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
+        index = local_rank
+        if os.environ.get("SCENEEGO_SHARE_GPU") == "1":
+            # readiness runs on a box with fewer GPUs than ranks (tests): ranks share devices.  RCCL refuses two ranks on one
+            # device, so such a run also sets SCENEEGO_DIST_BACKEND=gloo; everything else (sharding, stream ordering) is the N-GPU code
+            index = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(index)
+        device = torch.device("cuda", index)
     else:
         device = torch.device("cpu")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        backend = backend or os.environ.get("SCENEEGO_DIST_BACKEND") or None
         if backend is None:
             backend = "nccl" if device_type == "cuda" else "gloo"
         kw = {}
@@ -54,6 +60,13 @@ def all_gather_joints(joints: torch.Tensor) -> torch.Tensor:
         return joints
     world = dist.get_world_size()
     joints = joints.contiguous()
+    if joints.is_cuda and dist.get_backend() == "gloo":
+        # shared-GPU readiness mode only (init_from_env): gloo moves host memory, so the shard goes through the host behind the
+        # producing stream; the production backend (RCCL) gathers device tensors in place, stream-ordered
+        host = joints.cpu()           # synchronises with the current stream, which the caller made wait for the forward
+        out = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host)
+        return out.to(joints.device)
     out = torch.empty((world * joints.shape[0],) + tuple(joints.shape[1:]), dtype=joints.dtype, device=joints.device)
     dist.all_gather_into_tensor(out, joints)
     return out
@@ -83,6 +96,6 @@ def barrier():
 def max_over_ranks(value: float, device) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
