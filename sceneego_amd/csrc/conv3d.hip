@@ -433,83 +433,120 @@ __global__ __launch_bounds__(256) void conv3d_k3_splitk_kernel(ConvArgs a, float
     for (int n = 0; n < N_T; ++n) *reinterpret_cast<f32x4*>(o + (nt0 + n) * 16 + 4 * h) = acc[n];
 }
 
-// In-workgroup split-K for the deepest levels (4^3, 2^3): the 4 waves of a workgroup share ONE set of N_T voxel tiles x 2 cout
-// tiles and split the 27 x cin/16 (tap, channel group) steps between them; every wave issues the loads of 4 steps before
-// their MFMAs; the partial sums meet in LDS in a fixed order (deterministic) and the epilogue runs in the same launch — no
-// workspace round trip, no second kernel.
-template <int N_T>
-__global__ __launch_bounds__(256) void conv3d_k3_wavesplit_kernel(ConvArgs a) {
-    __shared__ f32x4 red[4][2 * N_T][64];
+// In-workgroup split-K for the small pyramid levels (8^3, 4^3, 2^3; 128 -> 128 channels): the WAVES waves of a workgroup share ONE
+// set of N_T voxel tiles x 2 cout tiles and split the 27 x cin/16 (tap, channel group) steps between them; the partial sums meet
+// in LDS in a fixed order (deterministic) and the epilogue runs in the same launch - no workspace round trip, no second kernel.
+//
+// Round 3: the float32 MFMA runs on the vector ALUs (64 FLOP/clk/SIMD = the VALU rate; tools/diag/mfma_selfmix.hip: one VALU
+// instruction per MFMA costs 17 % of the matrix rate), so the per-step address arithmetic of the first form - tap decomposition,
+// three bounds compares, 64-bit address adds and a branch per load: ~6 VALU instructions per MFMA - took as long as the MFMAs.
+// Now the whole k-step walk lives in scalar registers (the wave index goes through readfirstlane), loads are raw buffer loads
+// whose uniform part (tap shift, channel group, weight block) sits in the descriptor base / scalar offset, a lane's voxel offset
+// is computed once, and a neighbour outside the volume is one bit of a 27-bit per-lane mask that turns the voxel offset into an
+// out-of-range one (the load returns zeros; no branch): 2 VALU instructions per activation load, none per weight load.
+// Loads of block i+1 (U steps) are in flight under the MFMAs of block i (two named register sets).
+template <int N_T, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void conv3d_k3_wavesplit_kernel(ConvArgs a) {
+    __shared__ f32x4 red[WAVES][2 * N_T][64];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int vl = lane & 15;
     const int h = lane >> 4;
     const int dim = a.dim;
     const int cgs = (a.cin + 15) >> 4;
     const int nt0 = blockIdx.y * 2;
-    long long vid[N_T];
-    int vx[N_T], vy[N_T], vz[N_T];
+    constexpr unsigned OOB = 0x80000000u;
+    // per lane, once: byte offset of the voxel's record (+ this k lane's channel quad) and the mask of taps that leave the volume
+    unsigned voff[N_T], bad[N_T];
 #pragma unroll
     for (int n = 0; n < N_T; ++n) {
-        vid[n] = ((long long)blockIdx.x * N_T + n) * 16 + vl;
-        long long t = vid[n] < a.total_vox ? vid[n] : 0;
-        vx[n] = (int)(t % dim); t /= dim;
-        vy[n] = (int)(t % dim); t /= dim;
-        vz[n] = (int)(t % dim);
+        const long long vid = ((long long)blockIdx.x * N_T + n) * 16 + vl;
+        const bool vok = vid < a.total_vox;
+        long long t = vok ? vid : 0;
+        const int vx = (int)(t % dim); t /= dim;
+        const int vy = (int)(t % dim); t /= dim;
+        const int vz = (int)(t % dim);
+        voff[n] = (unsigned)((vok ? vid : 0) * a.cin_pad + 4 * h) * 4u;
+        unsigned m = 0;
+        for (int tap = 0; tap < 27; ++tap) {
+            const int zz = vz + tap / 9 - 1, yy = vy + (tap / 3) % 3 - 1, xx = vx + tap % 3 - 1;
+            const bool ok = vok && (unsigned)zz < (unsigned)dim && (unsigned)yy < (unsigned)dim && (unsigned)xx < (unsigned)dim;
+            m |= (ok ? 0u : 1u) << tap;
+        }
+        bad[n] = m;
     }
+    const unsigned in_bytes = (unsigned)(a.total_vox * a.cin_pad * 4);       // launcher: total_vox <= 8192, fits 32 bits
+    const unsigned w_bytes = (unsigned)(27 * cgs * a.nts * 1024);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, (int)w_bytes, 0x00020000);
+    const int woff = lane * 16;
+
     f32x4 acc[2][N_T];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < N_T; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack);
     const int steps = 27 * cgs;
     constexpr int U = 4;
-    for (int s0 = wave; s0 < steps; s0 += 4 * U) {
-        f32x4 wf[U][2], xf[U][N_T];
+    struct Ops { f32x4 wf[U][2], xf[U][N_T]; };
+    // the wave's k steps: s = wave, wave + WAVES, ...; (tap, cg) of the next step to LOAD, advanced incrementally (scalar)
+    int ld_s = wave, ld_tap = wave / cgs, ld_cg = wave - (wave / cgs) * cgs;
+    auto load_block = [&](Ops& o) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int s = s0 + 4 * u;
-            const bool live = s < steps;
-            const int ss = live ? s : 0;
-            const int tap = ss / cgs, cg = ss - tap * cgs;
+            const bool live = ld_s < steps;                                   // uniform
+            const int tap = live ? ld_tap : 0, cg = live ? ld_cg : 0;
             const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
-            const f32x4* wrow = wp + ((size_t)(cg * 27 + tap) * a.nts + nt0) * 64 + lane;
-            wf[u][0] = wrow[0];
-            wf[u][1] = wrow[64];
+            // activations: descriptor base = in + (tap shift, channel group); a dead step reads through a zero-record descriptor
+            const float* xb = a.in + ((long long)(dz * dim + dy) * dim + dx) * a.cin_pad + cg * 16;
+            const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, live ? (int)in_bytes : 0, 0x00020000);
 #pragma unroll
             for (int n = 0; n < N_T; ++n) {
-                const int zz = vz[n] + dz, yy = vy[n] + dy, xx = vx[n] + dx;
-                const bool ok = live && vid[n] < a.total_vox && (unsigned)zz < (unsigned)dim && (unsigned)yy < (unsigned)dim &&
-                                (unsigned)xx < (unsigned)dim;
-                xf[u][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (ok) xf[u][n] = *reinterpret_cast<const f32x4*>(a.in + (vid[n] + ((long long)dz * dim + dy) * dim + dx) * a.cin_pad + cg * 16 + 4 * h);
+                const unsigned sel = (unsigned)__builtin_amdgcn_sbfe(bad[n], tap, 1);      // all ones when the tap leaves the volume
+                o.xf[u][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(voff[n] | (sel & OOB)), 0, 0));
             }
+            const int wso = live ? ((cg * 27 + tap) * a.nts + nt0) * 1024 : 0;
+            o.wf[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff, wso, 0));
+            o.wf[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff, wso + 1024, 0));
+            ld_s += WAVES;
+            ld_cg += WAVES;
+            while (ld_cg >= cgs) { ld_cg -= cgs; ++ld_tap; }
         }
+    };
+    auto mfma_block = [&](const Ops& o) {      // a dead k step carries zero activations: it adds exact zeros
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+            const float wv[2][4] = {{o.wf[u][0].x, o.wf[u][0].y, o.wf[u][0].z, o.wf[u][0].w}, {o.wf[u][1].x, o.wf[u][1].y, o.wf[u][1].z, o.wf[u][1].w}};
 #pragma unroll
-            for (int n = 0; n < N_T; ++n)
+            for (int c = 0; c < 4; ++c)        // component outer: consecutive MFMAs go to different accumulators
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][m].x, xf[u][n].x, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][m].y, xf[u][n].y, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][m].z, xf[u][n].z, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][m].w, xf[u][n].w, acc[m][n], 0, 0, 0);
+                for (int n = 0; n < N_T; ++n) {
+                    const float xv[4] = {o.xf[u][n].x, o.xf[u][n].y, o.xf[u][n].z, o.xf[u][n].w};
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[m][c], xv[c], acc[m][n], 0, 0, 0);
                 }
+        }
+    };
+    Ops oa, ob;
+    load_block(oa);
+    for (int s0 = wave; s0 < steps; s0 += 2 * U * WAVES) {
+        load_block(ob);                         // beyond the last block: dead steps (zero-record descriptor, zero operands)
+        mfma_block(oa);
+        if (s0 + U * WAVES >= steps) break;
+        load_block(oa);
+        mfma_block(ob);
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < N_T; ++n) red[wave][m * N_T + n][lane] = acc[m][n];
     __syncthreads();
-    // 2 * N_T fragments, 4 waves: wave w finishes fragments w, w + 4, ...
+    // 2 * N_T fragments, WAVES waves: wave w finishes fragments w, w + WAVES, ... (partials added in wave order: deterministic)
     const long long per_b = (long long)dim * dim * dim;
-    for (int f = wave; f < 2 * N_T; f += 4) {
+    for (int f = wave; f < 2 * N_T; f += WAVES) {
         const int m = f / N_T, n = f - m * N_T;
         f32x4 v = red[0][f][lane];
 #pragma unroll
-        for (int w2 = 1; w2 < 4; ++w2) v += red[w2][f][lane];
+        for (int w2 = 1; w2 < WAVES; ++w2) v += red[w2][f][lane];
         const long long ov = ((long long)blockIdx.x * N_T + n) * 16 + vl;
         if (ov < a.total_vox) {
             const int b = (int)(ov / per_b);
@@ -864,7 +901,7 @@ extern "C" int se_conv3d_pack_f32(const float* w, const float* b, const float* g
 // implemented in conv3d_tiled.hip; returns 1 if it took the launch, 0 if the shape is not covered, <0 / hipError on failure
 int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s);
 
-#define g_variant_direct (g_variant == 18 ? 1 : 0)   // se_debug_set_variant(18): A/B, grid-level split-K for every small level
+#define g_variant_direct (g_variant == 18 ? 1 : g_variant == 19 ? 2 : 0)   // se_debug_set_variant(18): A/B, grid-level split-K for every small level; (19): in-workgroup split-K for every small level
 
 static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpack, const float* residual, float* out,
                            float* pool_out, const float* skip_w, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
@@ -904,11 +941,16 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
     if (flags & (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET)) return SE_ERR_BAD_ARG;   // only the 2-D Winograd kernel knows the octet-planar forms
     if (flags & SE_IN_PLANAR3) return SE_ERR_BAD_ARG;
     // small volumes with wide channels: split the taps over grid.z when the plain launch would not fill the chip
-    if (ksize == 3 && !planar && a.nts % 2 == 0 && a.total_vox >= 2048 && a.total_vox <= 8192 && g_variant_direct != 1) {
-        // 8^3-sized levels: in-workgroup split-K, single launch (measured 0.063 vs 0.077 ms for grid split-K + reduce at B = 8;
-        // at 4^3 / 2^3 there are too few workgroups and the grid-level split below stays faster)
+    if (ksize == 3 && !planar && a.nts % 2 == 0 && a.total_vox <= 8192 && (a.total_vox * cin_pad * 4LL) < (1LL << 31) && g_variant_direct != 1 &&
+        (a.total_vox >= 2048 || g_variant_direct == 2)) {
+        // 8^3-sized levels: in-workgroup split-K, single launch (round 2: 0.063 vs 0.077 ms for grid split-K + reduce at B = 8)
         const long long tiles = (a.total_vox + 15) / 16;
-        hipLaunchKernelGGL((conv3d_k3_wavesplit_kernel<2>), dim3((unsigned)((tiles + 1) / 2), a.nts / 2), dim3(256), 0, s, a);
+        if (a.total_vox >= 2048)
+            hipLaunchKernelGGL((conv3d_k3_wavesplit_kernel<2, 4>), dim3((unsigned)((tiles + 1) / 2), a.nts / 2), dim3(256), 0, s, a);
+        else if (a.total_vox >= 256)
+            hipLaunchKernelGGL((conv3d_k3_wavesplit_kernel<1, 8>), dim3((unsigned)tiles, a.nts / 2), dim3(512), 0, s, a);
+        else
+            hipLaunchKernelGGL((conv3d_k3_wavesplit_kernel<1, 16>), dim3((unsigned)tiles, a.nts / 2), dim3(1024), 0, s, a);
         SE_CHECK_LAUNCH();
         return 0;
     }

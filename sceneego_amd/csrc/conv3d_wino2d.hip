@@ -22,7 +22,7 @@
 // The weights of a chunk are re-streamed from L2 for every (unit, chunk) - 8 B/clk/CU - into ONE chunk buffer: its halves (xi_z < 3
 // / >= 3) are consumed a quarter step apart, so the half a group has finished with is refilled while the other half is in use;
 // two workgroup barriers per phase (start / middle) order this.
-// LDS reads are conflict-free: W is lane-linear; V records are 196 floats apart (see v_rec_offset).
+// LDS operand reads are conflict-free: W is lane-linear; V records are 216 floats apart (see v_rec_offset).
 #include "common.h"
 
 #include "conv_common.h"
@@ -37,12 +37,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int W2_HALF_FLOATS = 3 * 4 * 3 * 2 * 128;      // xi_z 0..2 (or 3..5): 9216 floats = 36,864 B
 constexpr int W2_CHUNK_FLOATS = SE_WINO2D_CHUNK_FLOATS;  // 18,432 floats = 73,728 B
-constexpr int W2_VREC = 200;                             // floats per x record: 24 xi x 8 channels + 8 pad (bank spread, see below)
-constexpr int W2_VTILE = 18 * W2_VREC;                   // one y-tile: 18 x records
-constexpr int W2_VG_FLOATS = 2 * W2_VTILE;               // 7056 floats = 28,224 B per group
-constexpr int W2_DUMMY_FLOATS = 512;                     // 64 lanes x 4 floats + 6 x 32 floats of xi_z offsets                     // landing zone of the masked-off y-transform outputs (see commit())
-constexpr int W2_LDS_BYTES = (W2_CHUNK_FLOATS + 2 * W2_VG_FLOATS + W2_DUMMY_FLOATS) * 4;   // 132,224 B
+constexpr int W2_VREC = 216;                             // floats per x record: 24 xi x 8 channels + 24 pad (bank spread, see below)
+constexpr int W2_VTILE = 18 * W2_VREC + 8;               // one y-tile: 18 x records (+ 8: see v_rec_offset)
+constexpr int W2_VG_FLOATS = 2 * W2_VTILE;               // 7792 floats = 31,168 B per group
+constexpr int W2_DUMMY_FLOATS = 512;                     // landing zone of the lanes without a y-transform output: 8 slots x 4 floats + 6 x 32 floats of xi_z offsets
+constexpr int W2_LDS_BYTES = (W2_CHUNK_FLOATS + 2 * W2_VG_FLOATS + W2_DUMMY_FLOATS) * 4;   // 138,112 B
 static_assert(W2_CHUNK_FLOATS == 2 * W2_HALF_FLOATS, "chunk = two halves");
+static_assert(W2_VREC % 64 == 24 && (W2_CHUNK_FLOATS + 2 * W2_VG_FLOATS) % 32 == 0, "bank layout of the V tiles, see v_rec_offset");
 
 template <typename F, int... S>
 __device__ __forceinline__ void for_each_idx(F&& f, std::integer_sequence<int, S...>) {
@@ -52,9 +53,14 @@ __device__ __forceinline__ void for_each_idx(F&& f, std::integer_sequence<int, S
 // LDS operand layouts are built for ds_read_b128 (4 LDS cycles per KiB; the two-address ds_read2_b64 hipcc forms from adjacent
 // 8-byte reads takes 8): a lane's 16 bytes carry the channel pair of its k lane for TWO transform points xi_y = 2q, 2q+1.
 //   W [xi_z][q][dx][ct][lane][e][c]        lane-linear: conflict-free
-//   V [y-tile][x record][xi_z][q][k lane h][e][c], 200 floats per x record (= 8 mod 64): the 16 lanes of a ds_read_b128 pass
+//   V [y-tile][x record][xi_z][q][k lane h][e][c], 216 floats per x record (= 24 mod 64): the 16 lanes of a ds_read_b128 pass
 //     (k lane h, positions per MI355X_MICROARCH.md's b128 lane groups) fall on 64 different banks for all three x-shifted windows;
 //     all 24 xi of a position sit within 768 B of one base address (immediate offsets, no address arithmetic in the MFMA stream).
+//   The STORES of the V-tile transform are ds_write_b128 (8 lanes per LDS pass, bank = dword mod 32, i.e. eight 16-byte slots): a
+//   lane's slot is 6 sxx + sp + 6 sk (+ 4 for the xi_y 2, 3 pair) mod 8 with 24 mod 32 floats per record and 3896 = 24 mod 32 floats
+//   per y-tile, which keeps the eight lanes of a pass on different slots for all but two of the 32 passes of a wave (the round-2
+//   layout, 200 floats per record and lanes without an output parked at lane * 16 B, had every store at twice its LDS cycles:
+//   SQ_LDS_BANK_CONFLICT 18 % of SQ_LDS_IDX_ACTIVE, all of it from these stores - tools/lds_conflicts_w2d.py).
 __device__ __forceinline__ int v_rec_offset(int xx, int p) { return xx * W2_VREC + p * 4; }
 
 // cycle stamps of the phase structure (diagnostic builds: build.sh --devtools -DSE_STAMP2D, tools/stamp_w2d.py)
@@ -157,9 +163,28 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     // this lane's y-transform outputs: P, Q -> (y-tile sk, xi_y 0, 1) when sk < 2;  R, S -> (y-tile sk - 1, xi_y 2, 3) when sk > 0
     // (lanes without that output write into a per-lane slot of a dummy area instead of being masked off: no EXEC toggling in the
     // transform code, and distinct banks inside every store instruction)
-    float* v_dummy = lds + W2_CHUNK_FLOATS + 2 * W2_VG_FLOATS + lane * 4;
-    float* v_pq = (s_on && sk < 2) ? vt + sk * W2_VTILE + v_rec_offset(sxx, sp) : v_dummy;
-    float* v_rs = (s_on && sk > 0) ? vt + (sk - 1) * W2_VTILE + v_rec_offset(sxx, sp) + 16 : v_dummy;
+    const int pq_off = W2_CHUNK_FLOATS + G * W2_VG_FLOATS + sk * W2_VTILE + v_rec_offset(sxx, sp);               // floats from the LDS base
+    const int rs_off = W2_CHUNK_FLOATS + G * W2_VG_FLOATS + (sk - 1) * W2_VTILE + v_rec_offset(sxx, sp) + 16;
+    const bool has_pq = s_on && sk < 2, has_rs = s_on && sk > 0;
+    // lanes without an output park their store in a dummy area - on a 16-byte slot no other lane of their 8-lane LDS pass uses
+    // (a ds_write_b128 pass covers lanes 8k..8k+7; slot = bits 2..4 of the dword address)
+    auto dummy_slot = [&](bool has, int off) {
+        const int mine = has ? (off >> 2) & 7 : -1;
+        unsigned used = 0;
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = __shfl(mine, (lane & ~7) + j);
+            if (o >= 0) used |= 1u << o;
+            else if (j < (lane & 7)) ++rank;
+        }
+        unsigned free_slots = ~used & 0xffu;
+        for (int r = 0; r < rank && (free_slots & (free_slots - 1)); ++r) free_slots &= free_slots - 1;
+        return free_slots ? __builtin_ctz(free_slots) : (lane & 7);
+    };
+    float* v_dummy = lds + W2_CHUNK_FLOATS + 2 * W2_VG_FLOATS;              // = 0 mod 32 floats: slot k of the area is slot k of the LDS
+    float* v_pq = has_pq ? lds + pq_off : v_dummy + dummy_slot(has_pq, pq_off) * 4;
+    float* v_rs = has_rs ? lds + rs_off : v_dummy + dummy_slot(has_rs, rs_off) * 4;
 
     auto decode = [&](int u) {
         Unit r;
@@ -504,6 +529,11 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         if constexpr (!(exp & 0x400)) {
             load_group(std::integral_constant<int, 0>{});
             load_group(std::integral_constant<int, 1>{});
+            // pin these eight reads in FRONT of the pipeline below.  Without this group the scheduler fills the "one DS read per
+            // pair of MFMAs" slots of groups 0, 1, ... with exactly these reads first, every later read slides two groups down
+            // with them, and each operand read ends up right in front of its MFMAs behind an s_waitcnt lgkmcnt(0) (round-3
+            // disassembly: the first 56 MFMAs of every phase waited for a just-issued ds_read_b128 every 4 MFMAs)
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
         }
         auto group = [&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
