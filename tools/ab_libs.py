@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--octet", type=int, default=3, help="2-D Winograd shapes: 1 IN_OCTET, 2 OUT_OCTET, 3 both, 0 channels-last")
     ap.add_argument("--no-res", action="store_true")
+    ap.add_argument("--planar3", action="store_true", help="7^3 shapes: triplet-planar input (SE_IN_PLANAR3)")
     args = ap.parse_args()
     dev = "cuda:0"
     libs = [load(p) for p in args.libs]
@@ -63,9 +64,16 @@ def main():
         x = torch.randn(B, dim, dim, dim, cin_pad, device=dev)
         if cin_pad > cin:
             x[..., cin:] = 0
+        if k == 7 and args.planar3:          # triplet-planar input [B][ceil(cin/3)][D][D][D][3] of the production 7^3 layer
+            nt = (cin + 2) // 3
+            xp = torch.zeros(B, nt * 3, dim, dim, dim, device=dev)
+            xp[:, :cin] = x[..., :cin].permute(0, 4, 1, 2, 3)
+            x = xp.view(B, nt, 3, dim, dim, dim).permute(0, 1, 3, 4, 5, 2).contiguous()
         no_res = args.no_res or k == 7
         res = None if no_res else torch.randn(B, dim, dim, dim, cout, device=dev)
         flags = _lib.EPI_RELU | (0 if no_res else _lib.EPI_RES_PRE_RELU)
+        if k == 7 and args.planar3:
+            flags |= _lib.IN_PLANAR3
         if k == 3 and libs[0].se_conv3d_f32_algo(dim, cin_pad, cout, 3) == 2:
             flags |= (_lib.IN_OCTET if args.octet & 1 else 0) | (_lib.OUT_OCTET if args.octet & 2 else 0)
         outs = [torch.empty(B, dim, dim, dim, cout, device=dev) for _ in libs]
