@@ -1,8 +1,8 @@
 #!/bin/bash
 # Builds libsceneego_hip.so for gfx950 (cross-compiles without a GPU).
 # Usage: build.sh [--devtools] [extra hipcc flags]
-#   --devtools  builds ../libsceneego_hip_dev.so instead (tools/ load it through SCENEEGO_HIP_LIB) with -DSE_DEVTOOLS: the A/B kernel selector (se_debug_set_variant), the retired kernel variants it selects and the
-#               cycle-stamp hooks used by tools/.  The production library is built WITHOUT it.
+#   --devtools  builds ../libsceneego_hip_dev.so instead (tools/ load it through SCENEEGO_HIP_LIB) with -DSE_DEVTOOLS: the A/B kernel selector (se_debug_set_variant), the retired kernel variants it selects
+#               (devtools/*.inc, included only under SE_DEVTOOLS) and the cycle-stamp hooks used by tools/.  The production library is built WITHOUT it.
 # Objects live in _obj/<key>/ where <key> hashes the compiler version and the flag line, so objects of another compiler or
 # another flag set are never reused; inside a key a source is rebuilt when it or a shared header is newer than its object.
 set -euo pipefail
@@ -15,8 +15,10 @@ KEY=$( (hipcc --version 2>/dev/null; echo "$FLAGS") | sha256sum | cut -c1-12)
 OBJ=_obj/$KEY
 mkdir -p "$OBJ"
 pids=()
-newer() {  # source $1 or a shared header newer than object $2
-  [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ common.h -nt "$2" ] || [ conv_common.h -nt "$2" ] || [ bf16_common.h -nt "$2" ] || [ ../../include/sceneego_hip.h -nt "$2" ]
+newer() {  # source $1, a shared header or (development builds) a devtools/ include newer than object $2
+  [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ common.h -nt "$2" ] || [ conv_common.h -nt "$2" ] || [ bf16_common.h -nt "$2" ] || [ ../../include/sceneego_hip.h -nt "$2" ] && return 0
+  if [ -n "$DEV" ]; then for i in devtools/*.inc; do [ "$i" -nt "$2" ] && return 0; done; fi
+  return 1
 }
 OBJS=()
 for f in voxelize gather softargmax conv3d conv3d_tiled conv3d_wino conv3d_wino2d conv3d_bf16 conv3d_bf16_tiled; do

@@ -209,203 +209,7 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void conv_bf16_k3_kernel(Conv
 }
 
 #ifdef SE_DEVTOOLS   // retired A/B variant: persistent double-buffered form of the bf16 3x3x3 kernel
-// ------------------------------------------------------------------------------------------------
-// Persistent form of the 3x3x3 kernel (NOT the production path; se_debug_set_variant(3)): one 512-thread workgroup per CU
-// loops over (tile, cout block) items.
-// The LDS holds TWO stage buffers (halo + weight chunk, 2 x 62 KB), so a stage is committed while the other is being read
-// and there is ONE barrier per stage; the loads of stage q+2 are issued as soon as stage q+1 is committed, the skip tensor
-// and bias of an item are fetched under its last chunk, and the next item's first stage is already in flight during the
-// epilogue.  Wave w owns x = w >> 1 and the 4 y rows 4 (w & 1) .. +3 of the 4x8x16 tile.
-// Measured 0.177 ms vs 0.154 ms (32->32 @64^3, B=8) for conv_bf16_k3_kernel: the 8 waves of the single workgroup meet at
-// every stage barrier, so their commit / issue phases coincide and the MFMA pipe idles through them, whereas two independent
-// 4-wave workgroups per CU drift apart and fill each other's gaps.  Kept as a documented negative result.
-// ------------------------------------------------------------------------------------------------
-constexpr int K3P_HP = (K3_HALO_PIECES + 511) / 512;          // 5 halo pieces per thread
-constexpr int K3P_WP = (K3_W_PIECES + 511) / 512;             // 4 weight pieces per thread
-constexpr int K3P_STAGE_BYTES = K3_HALO_BYTES + K3_W_BYTES;   // 63232
-constexpr int K3P_LDS_BYTES = 2 * K3P_STAGE_BYTES;            // 126464
-constexpr int K3P_NT = 4;
-
-struct K3PStage {
-    u16x8 h[K3P_HP];
-    u16x8 w[K3P_WP];
-};
-
-struct K3PItem { int b, x0, y0, z0, mb; };
-
-__device__ __forceinline__ K3PItem k3p_decode(int item, int nmb, int tiles_x, int tiles_y, int tiles_z) {
-    K3PItem it;
-    it.mb = item % nmb;
-    int t = item / nmb;
-    it.z0 = (t % tiles_z) * K3_TZ; t /= tiles_z;
-    it.y0 = (t % tiles_y) * K3_TY; t /= tiles_y;
-    it.x0 = (t % tiles_x) * K3_TX;
-    it.b = t / tiles_x;
-    return it;
-}
-
-__device__ __forceinline__ void k3p_compute(f32x4 (&acc)[2][K3P_NT], const unsigned char* brow, const unsigned char* arow, int g) {
-    u16x8 A0, A1, Bf[K3P_NT];
-    {
-        const int tap = g >> 1;
-        const unsigned char* bp = brow + (((tap / 9) * K3_HY + (tap / 3) % 3) * K3_HZ + tap % 3) * 32;
-        A0 = lds_read16(arow);
-        A1 = lds_read16(arow + K3_KPC * 1024);
-#pragma unroll
-        for (int n = 0; n < K3P_NT; ++n) Bf[n] = lds_read16(bp + n * (K3_HZ * 32));
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 + K3P_NT, 0);
-    }
-#pragma unroll
-    for (int sl = 0; sl < K3_KPC; ++sl) {
-        u16x8 nA0 = A0, nA1 = A1, nB[K3P_NT];
-#pragma unroll
-        for (int n = 0; n < K3P_NT; ++n) nB[n] = Bf[n];
-        if (sl + 1 < K3_KPC) {
-            int tap = 2 * (sl + 1) + (g >> 1);
-            tap = tap > 26 ? 26 : tap;
-            const unsigned char* bp = brow + (((tap / 9) * K3_HY + (tap / 3) % 3) * K3_HZ + tap % 3) * 32;
-            nA0 = lds_read16(arow + (sl + 1) * 1024);
-            nA1 = lds_read16(arow + (K3_KPC + sl + 1) * 1024);
-#pragma unroll
-            for (int n = 0; n < K3P_NT; ++n) nB[n] = lds_read16(bp + n * (K3_HZ * 32));
-        }
-#pragma unroll
-        for (int n = 0; n < K3P_NT; ++n) {
-            acc[0][n] = mfma_bf16(A0, Bf[n], acc[0][n]);
-            acc[1][n] = mfma_bf16(A1, Bf[n], acc[1][n]);
-        }
-        A0 = nA0; A1 = nA1;
-#pragma unroll
-        for (int n = 0; n < K3P_NT; ++n) Bf[n] = nB[n];
-        if (sl + 1 < K3_KPC) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-            for (int n = 0; n < K3P_NT; ++n) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * K3P_NT, 0);
-        }
-    }
-}
-
-__global__ __launch_bounds__(512, 1) void conv_bf16_k3p_kernel(ConvBArgs a, int tiles_x, int tiles_y, int tiles_z, int nitems) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
-    const int v = lane & 15, g = lane >> 4;
-    const int D = a.dim;
-    const int nmb = a.cout / 32;
-    const int nchunk = a.nchunk;
-    const int stride = gridDim.x;
-
-    // this thread's halo pieces i = tid + 512 j: (hx, hy, hz) packed; the octet is i & 1 = tid & 1
-    int hpk[K3P_HP];
-#pragma unroll
-    for (int j = 0; j < K3P_HP; ++j) {
-        const int i = tid + 512 * j;
-        const int hv = i >> 1;
-        const int hz = hv % K3_HZ, hy = (hv / K3_HZ) % K3_HY, hx = hv / (K3_HZ * K3_HY);
-        hpk[j] = i < K3_HALO_PIECES ? (hx | (hy << 8) | (hz << 16)) : -1;
-    }
-    auto load_stage = [&](K3PStage& st, int item, int c) {
-        const K3PItem it = k3p_decode(item, nmb, tiles_x, tiles_y, tiles_z);
-        const int coff = c * 16 + (tid & 1) * 8;
-#pragma unroll
-        for (int j = 0; j < K3P_HP; ++j) {
-            const int pk = hpk[j];
-            const int gx = it.x0 + (pk & 0xff) - 1, gy = it.y0 + ((pk >> 8) & 0xff) - 1, gz = it.z0 + ((pk >> 16) & 0xff) - 1;
-            const bool ok = pk >= 0 && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D;
-            const int vox = ok ? ((it.b * D + gx) * D + gy) * D + gz : 0;
-            const u16x8 val = *reinterpret_cast<const u16x8*>(a.in + (long long)vox * a.cin_pad + coff);
-            st.h[j] = ok ? val : zero8();
-        }
-        const unsigned short* wsrc = a.wpack + ((size_t)it.mb * 2 * a.ksteps + (size_t)c * K3_KPC) * 512;
-#pragma unroll
-        for (int j = 0; j < K3P_WP; ++j) {
-            const int i = tid + 512 * j;
-            const int ii = i < K3_W_PIECES ? i : 0;
-            const int m = ii / (K3_KPC * 64), r = ii - m * (K3_KPC * 64);
-            st.w[j] = *reinterpret_cast<const u16x8*>(wsrc + (size_t)m * a.ksteps * 512 + r * 8);
-        }
-    };
-    auto commit_stage = [&](const K3PStage& st, unsigned char* base) {
-#pragma unroll
-        for (int j = 0; j < K3P_HP; ++j) {
-            const int i = tid + 512 * j;
-            if (i < K3_HALO_PIECES) *reinterpret_cast<u16x8*>(base + i * 16) = st.h[j];
-        }
-#pragma unroll
-        for (int j = 0; j < K3P_WP; ++j) {
-            const int i = tid + 512 * j;
-            if (i < K3_W_PIECES) *reinterpret_cast<u16x8*>(base + K3_HALO_BYTES + i * 16) = st.w[j];
-        }
-    };
-    auto advance = [&](int& item, int& c) {
-        if (c + 1 < nchunk) { ++c; } else { c = 0; item += stride; }
-    };
-
-    int item_c = blockIdx.x, c_c = 0;
-    if (item_c >= nitems) return;
-    K3PStage st;
-    load_stage(st, item_c, 0);
-    commit_stage(st, lds);
-    int item_l = item_c, c_l = 0;
-    advance(item_l, c_l);
-    bool have_l = item_l < nitems;
-    if (have_l) load_stage(st, item_l, c_l);
-    __syncthreads();
-
-    f32x4 acc[2][K3P_NT];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < K3P_NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool has_res = epi_has_res(a);
-    const int brow_off = (((w >> 1) * K3_HY + 4 * (w & 1)) * K3_HZ + v) * 32 + (g & 1) * 16;
-    int buf = 0;
-    while (true) {
-        const bool last_chunk = c_c == nchunk - 1;
-        const K3PItem it = k3p_decode(item_c, nmb, tiles_x, tiles_y, tiles_z);
-        const long long obase = (((long long)it.b * D + (it.x0 + (w >> 1))) * D + (it.y0 + 4 * (w & 1))) * D + (it.z0 + v);
-        EpiBias8 eb;
-        u16x8 rv[K3P_NT];
-#pragma unroll
-        for (int n = 0; n < K3P_NT; ++n) rv[n] = zero8();
-        if (last_chunk) {                     // bias and skip tensor of this item: in flight under its last chunk
-            eb = epi_load_bias8(a, it.mb, g);
-            if (has_res) {
-#pragma unroll
-                for (int n = 0; n < K3P_NT; ++n)
-                    rv[n] = *reinterpret_cast<const u16x8*>(a.res + (obase + (long long)n * D) * a.cout + it.mb * 32 + 8 * g);
-            }
-        }
-        const unsigned char* base = lds + buf * K3P_STAGE_BYTES;
-        k3p_compute(acc, base + brow_off, base + K3_HALO_BYTES + lane * 16, g);
-        int item_n = item_l, c_n = c_l;
-        bool have_n = false;
-        if (have_l) {
-            commit_stage(st, lds + (buf ^ 1) * K3P_STAGE_BYTES);
-            advance(item_n, c_n);
-            have_n = item_n < nitems;
-            if (have_n) load_stage(st, item_n, c_n);
-        }
-        __syncthreads();
-        if (last_chunk) {
-#pragma unroll
-            for (int n = 0; n < K3P_NT; ++n) {
-                epi_store_pair(a, acc[0][n], acc[1][n], eb, has_res, rv[n], (obase + (long long)n * D) * a.cout + it.mb * 32 + 8 * g);
-                acc[0][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc[1][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        if (!have_l) break;
-        item_c = item_l; c_c = c_l;
-        item_l = item_n; c_l = c_n; have_l = have_n;
-        buf ^= 1;
-    }
-}
+#include "devtools/bf16_persistent_k3_kernel.inc"
 #endif  // SE_DEVTOOLS (persistent bf16 3x3x3 kernel)
 
 // ------------------------------------------------------------------------------------------------

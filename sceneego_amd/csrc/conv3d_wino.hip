@@ -62,698 +62,7 @@ struct WinoIter {   // uniform walk over this workgroup's items: runs of units w
 };
 
 #ifdef SE_DEVTOOLS   // retired A/B variants: F(2,3) 3^3 kernel, F(2,7) 7^3 kernels (single-phase and ping-pong)
-template <bool STAMP>
-__global__ __launch_bounds__(512) void conv3d_k3_wino_kernel(ConvArgs a, int tiles_per_dim, int ztiles, int total_tiles,
-                                                             int n_cb, int units_per_wg, int diag,
-                                                             unsigned long long* __restrict__ dbg) {
-    // STAMP build only (diagnostics, never the production launch): per-wave cycle totals of the four phases of an item
-    unsigned long long t_setup = 0, t_mfma = 0, t_tail = 0, t_bar = 0, t_prev = 0;
-    auto stamp = [&](unsigned long long& acc_t) {
-        if constexpr (STAMP) {
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned long long now;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
-            __builtin_amdgcn_sched_barrier(0);
-            acc_t += now - t_prev;
-            t_prev = now;
-        }
-    };
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wl = lds;                              // SE_WINO_CHUNK_FLOATS
-    float* tiles = lds + SE_WINO_CHUNK_FLOATS;    // 2 x TILE_FLOATS
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int vl = lane & 15;
-    const int h = lane >> 4;
-    const int dim = a.dim;
-    const int chunks = a.cin >> 4;
-    const int n_units = n_cb * total_tiles;
-    const int u_begin = (int)blockIdx.x * units_per_wg;
-    const int u_end = min(u_begin + units_per_wg, n_units);
-    if (u_begin >= u_end) return;
-
-    // lane's position inside the tile: z pair zp, row ry, column rx (halo coordinates are +1)
-    const int zp = wave >> 2;
-    const int ry = (wave & 3) * 2 + (vl >> 3);
-    const int rx = vl & 7;
-    const int vbase = ((2 * zp) * HY + ry) * HX + rx;          // halo voxel of d0 for (dy,dx) = (0,0)
-
-    int p_hz[PF], p_hy[PF], p_hx[PF], p_q[PF];
-    bool p_ok[PF];
-#pragma unroll
-    for (int k = 0; k < PF; ++k) {
-        const int it = tid + k * 512;
-        const int hv = it >> 2;
-        p_ok[k] = it < HV * 4;
-        p_q[k] = it & 3;
-        p_hx[k] = hv % HX;
-        const int t2 = hv / HX;
-        p_hy[k] = t2 % HY;
-        p_hz[k] = t2 / HY;
-    }
-
-    // (b, tz, ty, tx) of this workgroup's units, decoded ONCE into LDS: the 7 runtime integer divisions per lookup
-    // otherwise sit at the head of every item, where both waves of a SIMD execute them at the same time and the
-    // matrix pipe idles (measured: 20 % of the pure-compute loop).
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4* utab = reinterpret_cast<i32x4*>(lds + SE_WINO_CHUNK_FLOATS + 2 * TILE_FLOATS);
-    for (int i = tid; i < u_end - u_begin; i += 512) {
-        int t = (u_begin + i) % total_tiles;
-        i32x4 e;
-        e.w = t % tiles_per_dim; t /= tiles_per_dim;
-        e.z = t % tiles_per_dim; t /= tiles_per_dim;
-        e.y = t % ztiles; t /= ztiles;
-        e.x = t;
-        utab[i] = e;
-    }
-    __syncthreads();
-    auto unit_coords = [&](int u, int& b, int& tz, int& ty, int& tx) {
-        const i32x4 e = utab[u - u_begin];
-        b = e.x; tz = e.y; ty = e.z; tx = e.w;
-    };
-    // output offset of this lane's voxel (z = 2*zp of the pair) for cout tile 0 of block cb
-    auto out_offset = [&](int u, int cb) -> long long {
-        int b, tz, ty, tx;
-        unit_coords(u, b, tz, ty, tx);
-        const int oz = tz * 4 + 2 * zp, oy = ty * 8 + ry, ox = tx * 8 + rx;
-        return ((((long long)b * dim + oz) * dim + oy) * dim + ox) * a.cout + cb * 32 + 4 * h;
-    };
-    const long long zstride = (long long)dim * dim * a.cout;   // +1 in z
-
-    f32x4 pf[PF];
-    // Branch-free halo fetch (so it can be scheduled INSIDE the MFMA block of the current item): out-of-volume pieces
-    // load from offset 0 and are zeroed by a select afterwards.
-    int p_rel[PF];
-#pragma unroll
-    for (int k = 0; k < PF; ++k) p_rel[k] = ((p_hz[k] * dim + p_hy[k]) * dim + p_hx[k]) * a.cin_pad + p_q[k] * 4;
-    auto fetch = [&](int u, int c) {
-        int b, tz, ty, tx;
-        unit_coords(u, b, tz, ty, tx);
-        const int z0 = tz * 4 - 1, y0 = ty * 8 - 1, x0 = tx * 8 - 1;
-        const long long base = ((((long long)b * dim + z0) * dim + y0) * dim + x0) * a.cin_pad + c * 16;
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const bool ok = p_ok[k] && (unsigned)(z0 + p_hz[k]) < (unsigned)dim && (unsigned)(y0 + p_hy[k]) < (unsigned)dim &&
-                            (unsigned)(x0 + p_hx[k]) < (unsigned)dim;
-            const f32x4 t = *reinterpret_cast<const f32x4*>(a.in + (ok ? base + p_rel[k] : 0));
-            pf[k] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto commit = [&](int buf) {
-        float* tb = tiles + buf * TILE_FLOATS;
-#pragma unroll
-        for (int k = 0; k < PF; ++k)
-            if (p_ok[k]) *reinterpret_cast<f32x4*>(tb + (size_t)(tid + k * 512) * 4) = pf[k];
-    };
-    auto load_weights = [&](int cb, int c) {
-        fill_lds<512>(wl, reinterpret_cast<const f32x4*>(a.wpack_b) + ((size_t)c * n_cb + cb) * (SE_WINO_CHUNK_FLOATS / 4),
-                      SE_WINO_CHUNK_FLOATS / 4, tid);
-    };
-    auto first_item = [&]() {
-        WinoIter it;
-        it.u_lo = u_begin;
-        it.cb = u_begin / total_tiles;
-        it.n = min(u_end, (it.cb + 1) * total_tiles) - u_begin;
-        it.c = 0; it.k = 0; it.valid = true;
-        return it;
-    };
-    auto next_item = [&](WinoIter it) {
-        if (++it.k == it.n) {
-            it.k = 0;
-            if (++it.c == chunks) {
-                it.c = 0;
-                it.u_lo += it.n;
-                if (it.u_lo >= u_end) { it.valid = false; return it; }
-                it.cb = it.u_lo / total_tiles;
-                it.n = min(u_end, (it.cb + 1) * total_tiles) - it.u_lo;
-            }
-        }
-        return it;
-    };
-
-    const bool relu = a.flags & SE_EPI_RELU;
-    const bool use_res = (a.flags & SE_EPI_RES_PRE_RELU) && a.res;
-
-    WinoIter cur = first_item();
-    fetch(cur.u_lo, 0);
-    commit(0);
-    load_weights(cur.cb, 0);
-    __syncthreads();
-
-    f32x4 part[2][2];   // [z of the pair][cout tile]: y-domain partial sums of the previous chunks (prefetched)
-    f32x4 resv[2][2];
-#pragma unroll
-    for (int z = 0; z < 2; ++z)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) part[z][n] = resv[z][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    int buf = 0;
-    if constexpr (STAMP) { unsigned long long dummy = 0; stamp(dummy); }
-    while (true) {
-        const WinoIter nxt = next_item(cur);
-        const int u = cur.u_lo + cur.k;
-        const bool last_chunk = cur.c == chunks - 1;
-        // a run of one unit revisits the same tile in the very next item: its partial cannot be prefetched
-        const bool lone = cur.n == 1;
-        const int fetch_u = nxt.valid ? nxt.u_lo + nxt.k : u;      // (re-fetching the current item at the very end is harmless)
-        const int fetch_c = nxt.valid ? nxt.c : cur.c;
-        const long long o0 = out_offset(u, cur.cb);
-        if (cur.c > 0 && !(diag & 2)) {
-            if (lone) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // same tile as the previous item: stores first
-#pragma unroll
-            for (int z = 0; z < 2; ++z)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) part[z][n] = *reinterpret_cast<const f32x4*>(a.out + o0 + z * zstride + n * 16);
-        }
-        if (last_chunk && use_res) {
-#pragma unroll
-            for (int z = 0; z < 2; ++z)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) resv[z][n] = *reinterpret_cast<const f32x4*>(a.res + o0 + z * zstride + n * 16);
-        }
-
-        // ---- MFMA over the 9 (dy,dx) taps of this 16-channel chunk ----
-        f32x4 acc[4][2];
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) acc[x][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* tb = tiles + buf * TILE_FLOATS + vbase * 16 + 4 * h;
-        const f32x4* wrow = reinterpret_cast<const f32x4*>(wl) + lane;
-        // Software pipeline over the 36 sub-steps (tap, xi): the two weight fragments of sub-step s+1, and in the first
-        // sub-step of a tap the four activation fragments of the NEXT tap, are read before the 8 MFMAs of sub-step s;
-        // left to itself hipcc issues every ds_read directly in front of its first use (one exposed LDS round trip
-        // per 4 MFMAs: measured 78 % MFMA rate in this loop).
-#define SE_WINO_DLOAD(D, T2)                                                                      \
-    {                                                                                             \
-        const int off_ = (((T2) / 3) * HX + ((T2) % 3)) * 16;                                     \
-        D[0] = *reinterpret_cast<const f32x4*>(tb + off_);                                        \
-        D[1] = *reinterpret_cast<const f32x4*>(tb + off_ + 1 * HY * HX * 16);                     \
-        D[2] = *reinterpret_cast<const f32x4*>(tb + off_ + 2 * HY * HX * 16);                     \
-        D[3] = *reinterpret_cast<const f32x4*>(tb + off_ + 3 * HY * HX * 16);                     \
-    }
-        f32x4 dn[4], vc[4], wc[2], wn[2];
-        stamp(t_setup);
-        SE_WINO_DLOAD(dn, 0)
-        wc[0] = wrow[0];
-        wc[1] = wrow[64];
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        vc[0] = dn[0] - dn[2]; vc[1] = dn[1] + dn[2]; vc[2] = dn[2] - dn[1]; vc[3] = dn[1] - dn[3];
-        auto substep = [&](auto s_tag) {
-            constexpr int S = decltype(s_tag)::value;
-            constexpr int t2 = S / 4, x = S % 4;
-            constexpr bool more_w = S + 1 < 36;
-            constexpr bool more_d = x == 0 && t2 + 1 < 9;
-            if constexpr (S == 2) fetch(fetch_u, fetch_c);   // next item's halo: global loads issued under this item's MFMAs
-            if constexpr (more_d) SE_WINO_DLOAD(dn, t2 + 1)
-            if constexpr (more_w) {
-                wn[0] = wrow[((S + 1) * 2 + 0) * 64];
-                wn[1] = wrow[((S + 1) * 2 + 1) * 64];
-            }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                acc[x][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[n].x, vc[x].x, acc[x][n], 0, 0, 0);
-                acc[x][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[n].y, vc[x].y, acc[x][n], 0, 0, 0);
-                acc[x][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[n].z, vc[x].z, acc[x][n], 0, 0, 0);
-                acc[x][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[n].w, vc[x].w, acc[x][n], 0, 0, 0);
-            }
-            if constexpr (more_d) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-            else if constexpr (more_w) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            wc[0] = wn[0];
-            wc[1] = wn[1];
-            if constexpr (x == 3 && t2 + 1 < 9) {
-                if (diag & 8) { vc[0] = dn[0]; vc[1] = dn[1]; vc[2] = dn[2]; vc[3] = dn[3]; }
-                else { vc[0] = dn[0] - dn[2]; vc[1] = dn[1] + dn[2]; vc[2] = dn[2] - dn[1]; vc[3] = dn[1] - dn[3]; }
-            }
-        };
-        for_each_index(substep, std::make_integer_sequence<int, 36>{});
-        stamp(t_mfma);
-#undef SE_WINO_DLOAD
-
-        // ---- item boundary: commit the prefetched halo BEFORE issuing this item's stores (vmcnt is in issue order) ----
-        if (nxt.valid && !(diag & 1)) commit(buf ^ 1);
-        if (!(diag & 2))
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            f32x4 y0 = acc[0][n] + acc[1][n] + acc[2][n];
-            f32x4 y1 = acc[1][n] - acc[2][n] - acc[3][n];
-            if (cur.c > 0) {   // partial sums of the previous chunks (from memory, or kept in registers for a lone unit)
-                y0 += part[0][n];
-                y1 += part[1][n];
-            }
-            if (last_chunk) {
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + cur.cb * 32 + n * 16 + 4 * h);
-                y0 += bias; y1 += bias;
-                if (use_res) { y0 += resv[0][n]; y1 += resv[1][n]; }
-                if (relu) {
-                    y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
-                    y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
-                }
-            }
-            *reinterpret_cast<f32x4*>(a.out + o0 + n * 16) = y0;
-            *reinterpret_cast<f32x4*>(a.out + o0 + zstride + n * 16) = y1;
-        }
-        stamp(t_tail);
-        if (!nxt.valid) break;
-        if (!(diag & 4)) __syncthreads();   // everyone is done with this halo buffer and these weights; the other buffer is complete
-        stamp(t_bar);
-        if (nxt.cb != cur.cb || nxt.c != cur.c) {
-            load_weights(nxt.cb, nxt.c);
-            __syncthreads();
-        }
-        cur = nxt;
-        buf ^= 1;
-    }
-    if constexpr (STAMP) {
-        if (lane == 0 && dbg) {
-            unsigned long long* o = dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
-            o[0] = t_setup; o[1] = t_mfma; o[2] = t_tail; o[3] = t_bar;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 7x7x7 convolution (front layer, cout = 16) with a 1-D Winograd F(2,7) transform along z: 8 multiplies instead of 14
-// per pair of z-neighbouring outputs and (dy, dx, cin, cout) -> 1.65x fewer MFMAs than the direct form (49 taps
-// padded to 13 groups of 4 on the k lanes).  y = A^T [(G g) .* (B^T d)], points {0, +-1, +-2, +-1/2, inf}:
-//   B^T d is applied ONCE per element while the halo is committed to LDS (the inner loop has no VALU work at all):
-//   for each (y, x) column of the 4-channel chunk and each z pair, 8 raw slabs -> 8 transformed slabs V_xi;
-//   G g is folded into the packed weights (section D);  A^T runs in the epilogue.
-// fp32 error of the transform: ~1e-6 relative (tools/wino27_matrices.py), far inside the 1e-3 joint tolerance.
-// Persistent 512-thread workgroup per CU, chunk-outer with y-domain partial sums through the output tensor, like the
-// 3x3x3 kernel above.  LDS: 104 KB weights of one chunk + ONE transformed tile (2 z pairs x 8 xi x 14 x 14 x 16 B =
-// 49 KB); wave w: z pair w>>2, rows 2*(w&3), +1 -> one 16-position tile, 8 accumulators (one per xi).
-// ------------------------------------------------------------------------------------------------
-constexpr int K7_HY = 14, K7_HX = 14, K7_COLS = K7_HY * K7_HX;          // 196 halo columns
-constexpr int K7_VT_FLOATS = 2 * 8 * K7_COLS * 4;                        // transformed tile
-constexpr int K7_W_FLOATS = SE_K7W_CHUNK_FLOATS;
-
-__global__ __launch_bounds__(512) void conv3d_k7_wino_kernel(ConvArgs a, int tiles_per_dim, int ztiles, int total_tiles,
-                                                             int units_per_wg) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wl = lds;
-    float* vt = lds + K7_W_FLOATS;
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4* utab = reinterpret_cast<i32x4*>(lds + K7_W_FLOATS + K7_VT_FLOATS);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int vl = lane & 15;
-    const int h = lane >> 4;
-    const int dim = a.dim;
-    const int chunks = (a.cin + 3) >> 2;
-    const int rem = a.cin & 3;
-    const int u_begin = (int)blockIdx.x * units_per_wg;
-    const int u_end = min(u_begin + units_per_wg, total_tiles);
-    if (u_begin >= u_end) return;
-    const int n = u_end - u_begin;
-
-    for (int i = tid; i < n; i += 512) {
-        int t = u_begin + i;
-        i32x4 e;
-        e.w = t % tiles_per_dim; t /= tiles_per_dim;
-        e.z = t % tiles_per_dim; t /= tiles_per_dim;
-        e.y = t % ztiles; t /= ztiles;
-        e.x = t;
-        utab[i] = e;
-    }
-
-    // compute role: z pair zp, 16 positions (rows 2m, 2m+1 of the 8x8 tile)
-    const int zp = wave >> 2;
-    const int ry = (wave & 3) * 2 + (vl >> 3);
-    const int rx = vl & 7;
-    // per-lane LDS offsets (floats) of the 13 tap groups: tap 4g+h -> (dy,dx); constant for the whole kernel
-    int toff[SE_K7W_GROUPS];
-#pragma unroll
-    for (int g = 0; g < SE_K7W_GROUPS; ++g) {
-        int tap = 4 * g + h;
-        tap = tap < 49 ? tap : 0;   // zero-weight padding
-        toff[g] = (zp * 8 * K7_COLS + (ry + tap / 7) * K7_HX + rx + tap % 7) * 4;
-    }
-
-    // staging role: thread t < 392 owns halo column (t % 196) of z pair (t / 196): 8 raw slabs -> 8 transformed slabs
-    const bool s_on = tid < 2 * K7_COLS;
-    const int s_col = tid % K7_COLS, s_zp = tid / K7_COLS;
-    const int s_cy = s_col / K7_HX, s_cx = s_col % K7_HX;
-    f32x4 raw[8];
-    auto fetch = [&](int k, int c) {
-        const i32x4 e = utab[k];
-        const int gy = e.z * 8 - 3 + s_cy, gx = e.w * 8 - 3 + s_cx;
-        const int gz0 = e.y * 4 + 2 * s_zp - 3;
-        const bool okc = s_on && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim;
-        const long long base = ((((long long)e.x * dim) * dim + gy) * dim + gx) * a.cin_pad + c * 4;
-        const long long zs = (long long)dim * dim * a.cin_pad;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const bool ok = okc && (unsigned)(gz0 + q) < (unsigned)dim;
-            const f32x4 t = *reinterpret_cast<const f32x4*>(a.in + (ok ? base + (gz0 + q) * zs : 0));
-            raw[q] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto commit = [&]() {   // V = B^T d, rows as printed by tools/wino27_matrices.py
-        if (!s_on) return;
-        const f32x4 d0 = raw[0], d1 = raw[1], d2 = raw[2], d3 = raw[3], d4 = raw[4], d5 = raw[5], d6 = raw[6], d7 = raw[7];
-        f32x4 v[8];
-        v[0] = (d6 - d0) + 5.25f * (d2 - d4);
-        v[7] = (d7 - d1) + 5.25f * (d3 - d5);
-        const f32x4 e1 = d2 + d6 - 4.25f * d4, o1 = d1 + d5 - 4.25f * d3;
-        v[1] = e1 + o1;
-        v[2] = e1 - o1;
-        const f32x4 e2 = 0.25f * d2 - 1.25f * d4 + d6, o2 = 0.5f * d1 - 2.5f * d3 + 2.f * d5;
-        v[3] = e2 + o2;
-        v[4] = e2 - o2;
-        const f32x4 e3 = 4.f * d2 - 5.f * d4 + d6, o3 = 2.f * d1 - 2.5f * d3 + 0.5f * d5;
-        v[5] = e3 + o3;
-        v[6] = e3 - o3;
-#pragma unroll
-        for (int x = 0; x < 8; ++x) *reinterpret_cast<f32x4*>(vt + ((s_zp * 8 + x) * K7_COLS + s_col) * 4) = v[x];
-    };
-    auto load_weights = [&](int c) {
-        fill_lds<512>(wl, reinterpret_cast<const f32x4*>(a.wpack_d) + (size_t)c * (K7_W_FLOATS / 4), K7_W_FLOATS / 4, tid);
-    };
-    auto out_offset = [&](int k) -> long long {
-        const i32x4 e = utab[k];
-        const int oz = e.y * 4 + 2 * zp, oy = e.z * 8 + ry, ox = e.w * 8 + rx;
-        return ((((long long)e.x * dim + oz) * dim + oy) * dim + ox) * 16 + 4 * h;
-    };
-    const long long zstride = (long long)dim * dim * 16;
-
-    const bool relu = a.flags & SE_EPI_RELU;
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + 4 * h);
-    const bool lone = n == 1;
-
-    __syncthreads();   // utab
-    fetch(0, 0);
-    commit();
-    load_weights(0);
-    __syncthreads();
-
-    // the running partial sums of the NEXT item are fetched inside the current MFMA block (see the 3x3x3 kernel below)
-    f32x4 part[2], part_n[2];
-    part[0] = part[1] = part_n[0] = part_n[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    long long o0 = out_offset(0), o0_n = 0;
-    const int n_items = chunks * n;
-    for (int item = 0; item < n_items; ++item) {
-        const int c = item / n, k = item - c * n;
-        const bool has_next = item + 1 < n_items;
-        const int c_next = has_next ? (item + 1) / n : c;
-        const int k_next = has_next ? (item + 1) - c_next * n : k;
-        const bool last_chunk = c == chunks - 1;
-        if (c > 0 && lone) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // same tile as the previous item: stores first
-            part[0] = *reinterpret_cast<const f32x4*>(a.out + o0);
-            part[1] = *reinterpret_cast<const f32x4*>(a.out + o0 + zstride);
-        }
-        const bool n_part = has_next && c_next > 0 && !lone;
-
-        f32x4 acc[8];
-#pragma unroll
-        for (int x = 0; x < 8; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const f32x4* wrow = reinterpret_cast<const f32x4*>(wl) + lane;
-        const int nj = (last_chunk && rem != 0) ? rem : 4;   // uniform: real channels in this chunk
-        // software pipeline over the 104 sub-steps (tap group, xi): operands of sub-step s+1 are read before the MFMAs of s
-        f32x4 wc = wrow[0], vc = *reinterpret_cast<const f32x4*>(vt + toff[0]);
-        f32x4 wn = wc, vn = vc;
-        auto body = [&](auto nj_tag) {
-            constexpr int NJ = decltype(nj_tag)::value;
-            auto substep = [&](auto s_tag) {
-                constexpr int S = decltype(s_tag)::value;
-                constexpr int g = S / 8, x = S % 8;
-                if constexpr (S == 3) fetch(k_next, c_next);   // next item's raw columns: global loads under the MFMAs
-                if constexpr (S == 11) {
-                    o0_n = out_offset(k_next);
-                    if (n_part) {
-                        part_n[0] = *reinterpret_cast<const f32x4*>(a.out + o0_n);
-                        part_n[1] = *reinterpret_cast<const f32x4*>(a.out + o0_n + zstride);
-                    }
-                }
-                if constexpr (S + 1 < 104) {
-                    constexpr int g1 = (S + 1) / 8, x1 = (S + 1) % 8;
-                    wn = wrow[(S + 1) * 64];
-                    vn = *reinterpret_cast<const f32x4*>(vt + toff[g1] + x1 * K7_COLS * 4);
-                }
-                acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.x, vc.x, acc[x], 0, 0, 0);
-                if constexpr (NJ > 1) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.y, vc.y, acc[x], 0, 0, 0);
-                if constexpr (NJ > 2) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.z, vc.z, acc[x], 0, 0, 0);
-                if constexpr (NJ > 3) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.w, vc.w, acc[x], 0, 0, 0);
-                if constexpr (S + 1 < 104) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                if constexpr (NJ == 4) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                else if constexpr (NJ == 1) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                wc = wn;
-                vc = vn;
-                (void)g;
-            };
-            for_each_index(substep, std::make_integer_sequence<int, 104>{});
-        };
-        if (nj == 4) body(std::integral_constant<int, 4>{});
-        else if (nj == 1) body(std::integral_constant<int, 1>{});
-        else if (nj == 2) body(std::integral_constant<int, 2>{});
-        else body(std::integral_constant<int, 3>{});
-
-        // A^T: y0 = M0 + ... + M6 ; y1 = M1 - M2 + 2 M3 - 2 M4 + M5/2 - M6/2 + M7
-        f32x4 y0 = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + acc[6]);
-        f32x4 y1 = (acc[1] - acc[2]) + 2.f * (acc[3] - acc[4]) + 0.5f * (acc[5] - acc[6]) + acc[7];
-        if (c > 0) { y0 += part[0]; y1 += part[1]; }
-
-        // single transformed tile: every wave must be done reading it before the next item's columns are committed
-        __syncthreads();
-        if (has_next) {
-            commit();
-            if (c_next != c) load_weights(c_next);
-        }
-        if (last_chunk) {
-            y0 += bias; y1 += bias;
-            if (relu) {
-                y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
-                y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
-            }
-        }
-        *reinterpret_cast<f32x4*>(a.out + o0) = y0;        // (source registers are not touched again until the next A^T)
-        *reinterpret_cast<f32x4*>(a.out + o0 + zstride) = y1;
-        if (!has_next) break;
-        __syncthreads();
-        o0 = o0_n;
-        part[0] = part_n[0];
-        part[1] = part_n[1];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// F(2,7) kernel in ping-pong form (A/B only — measured 5 % SLOWER than the single-phase form, whose 416-MFMA blocks already
-// keep the matrix pipe 79 % busy; kept as a documented negative result): same arithmetic, weights, LDS layout and work units as conv3d_k7_wino_kernel,
-// but the two z pairs of a 4x8x8 tile belong to two groups of 4 waves (one wave per SIMD each) that run HALF A PHASE
-// APART: while one group issues the 416 MFMAs of its z pair, the other does A^T, the partial-sum add, the epilogue, the
-// output stores and the B^T transform + LDS commit of its next z pair (see conv3d_k3_wino43pp_kernel below).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void conv3d_k7_winopp_kernel(ConvArgs a, int tiles_per_dim, int ztiles, int total_tiles,
-                                                               int units_per_wg) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wl = lds;
-    float* vt = lds + K7_W_FLOATS;
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4* utab = reinterpret_cast<i32x4*>(lds + K7_W_FLOATS + K7_VT_FLOATS);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int G = wave >> 2;                       // group = z pair
-    const int wg = wave & 3;
-    const int vl = lane & 15;
-    const int h = lane >> 4;
-    const int dim = a.dim;
-    const int chunks = (a.cin + 3) >> 2;
-    const int rem = a.cin & 3;
-    const int u_begin = (int)blockIdx.x * units_per_wg;
-    const int u_end = min(u_begin + units_per_wg, total_tiles);
-    if (u_begin >= u_end) return;
-    const int n = u_end - u_begin;
-
-    for (int i = tid; i < n; i += 512) {
-        int t = u_begin + i;
-        i32x4 e;
-        e.w = t % tiles_per_dim; t /= tiles_per_dim;
-        e.z = t % tiles_per_dim; t /= tiles_per_dim;
-        e.y = t % ztiles; t /= ztiles;
-        e.x = t;
-        utab[i] = e;
-    }
-
-    const int ry = wg * 2 + (vl >> 3);
-    const int rx = vl & 7;
-    int toff[SE_K7W_GROUPS];
-#pragma unroll
-    for (int g = 0; g < SE_K7W_GROUPS; ++g) {
-        int tap = 4 * g + h;
-        tap = tap < 49 ? tap : 0;   // zero-weight padding
-        toff[g] = (G * 8 * K7_COLS + (ry + tap / 7) * K7_HX + rx + tap % 7) * 4;
-    }
-
-    // staging role inside the group: thread tg < 196 owns halo column tg of this group's z pair
-    const int tg = tid & 255;
-    const bool s_on = tg < K7_COLS;
-    const int s_col = s_on ? tg : 0;
-    const int s_cy = s_col / K7_HX, s_cx = s_col % K7_HX;
-    f32x4 raw[8];
-    auto fetch = [&](int k, int c) {
-        const i32x4 e = utab[k];
-        const int gy = e.z * 8 - 3 + s_cy, gx = e.w * 8 - 3 + s_cx;
-        const int gz0 = e.y * 4 + 2 * G - 3;
-        const bool okc = s_on && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim;
-        const long long base = ((((long long)e.x * dim) * dim + gy) * dim + gx) * a.cin_pad + c * 4;
-        const long long zs = (long long)dim * dim * a.cin_pad;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const bool ok = okc && (unsigned)(gz0 + q) < (unsigned)dim;
-            const f32x4 t = *reinterpret_cast<const f32x4*>(a.in + (ok ? base + (gz0 + q) * zs : 0));
-            raw[q] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto commit = [&]() {   // V = B^T d, rows as printed by tools/wino27_matrices.py
-        if (!s_on) return;
-        const f32x4 d0 = raw[0], d1 = raw[1], d2 = raw[2], d3 = raw[3], d4 = raw[4], d5 = raw[5], d6 = raw[6], d7 = raw[7];
-        f32x4 v[8];
-        v[0] = (d6 - d0) + 5.25f * (d2 - d4);
-        v[7] = (d7 - d1) + 5.25f * (d3 - d5);
-        const f32x4 e1 = d2 + d6 - 4.25f * d4, o1 = d1 + d5 - 4.25f * d3;
-        v[1] = e1 + o1;
-        v[2] = e1 - o1;
-        const f32x4 e2 = 0.25f * d2 - 1.25f * d4 + d6, o2 = 0.5f * d1 - 2.5f * d3 + 2.f * d5;
-        v[3] = e2 + o2;
-        v[4] = e2 - o2;
-        const f32x4 e3 = 4.f * d2 - 5.f * d4 + d6, o3 = 2.f * d1 - 2.5f * d3 + 0.5f * d5;
-        v[5] = e3 + o3;
-        v[6] = e3 - o3;
-#pragma unroll
-        for (int x = 0; x < 8; ++x) *reinterpret_cast<f32x4*>(vt + ((G * 8 + x) * K7_COLS + s_col) * 4) = v[x];
-    };
-    auto load_weights = [&](int c) {
-        fill_lds<512>(wl, reinterpret_cast<const f32x4*>(a.wpack_d) + (size_t)c * (K7_W_FLOATS / 4), K7_W_FLOATS / 4, tid);
-    };
-    auto out_offset = [&](int k) -> long long {
-        const i32x4 e = utab[k];
-        const int oz = e.y * 4 + 2 * G, oy = e.z * 8 + ry, ox = e.w * 8 + rx;
-        return ((((long long)e.x * dim + oz) * dim + oy) * dim + ox) * 16 + 4 * h;
-    };
-    const long long zstride = (long long)dim * dim * 16;
-    const bool relu = a.flags & SE_EPI_RELU;
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + 4 * h);
-
-    __syncthreads();   // utab
-    fetch(0, 0);
-    commit();
-    load_weights(0);
-    __syncthreads();
-
-    f32x4 acc[8], part[2];
-    part[0] = part[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int x = 0; x < 8; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    long long o0 = 0;
-    const f32x4* wrow = reinterpret_cast<const f32x4*>(wl) + lane;
-
-    for (int c = 0; c < chunks; ++c) {
-        const bool last_chunk = c == chunks - 1;
-        const bool seg_next = c + 1 < chunks;
-        const int nj = (last_chunk && rem != 0) ? rem : 4;   // uniform: real channels in this chunk
-        for (int t = 0; t <= 2 * n; ++t) {
-            const int r = t - G;
-            if (r >= 0 && !(r & 1) && (r >> 1) < n) {
-                // ------------------------------ MFMA phase of item (c, k) ------------------------------
-                __builtin_amdgcn_s_setprio(3);
-                const int k = r >> 1;
-                const bool has_next = k + 1 < n || seg_next;
-                const int k_next = k + 1 < n ? k + 1 : 0;
-                const int c_next = k + 1 < n ? c : c + 1;
-#pragma unroll
-                for (int x = 0; x < 8; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                auto body = [&](auto nj_tag) {
-                    constexpr int NJ = decltype(nj_tag)::value;
-                    f32x4 w0 = wrow[0], v0 = *reinterpret_cast<const f32x4*>(vt + toff[0]);
-                    f32x4 w1 = wrow[64], v1 = *reinterpret_cast<const f32x4*>(vt + toff[0] + K7_COLS * 4);
-                    f32x4 w2 = w0, v2 = v0, w3 = w1, v3 = v1;
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                    auto pairstep = [&](auto p_tag) {
-                        constexpr int P = decltype(p_tag)::value;
-                        constexpr int S0 = 2 * P, S1 = 2 * P + 1;
-                        constexpr int x0 = S0 % 8, x1 = S1 % 8;
-                        if constexpr (P == 1) { if (has_next) fetch(k_next, c_next); }   // next z pair's raw columns
-                        if constexpr (P == 3) {                                           // this item's partial sums
-                            o0 = out_offset(k);
-                            if (c > 0) {
-                                part[0] = *reinterpret_cast<const f32x4*>(a.out + o0);
-                                part[1] = *reinterpret_cast<const f32x4*>(a.out + o0 + zstride);
-                            }
-                        }
-                        if constexpr (P + 1 < 52) {
-                            constexpr int g2 = (S0 + 2) / 8, X2 = (S0 + 2) % 8, g3 = (S1 + 2) / 8, X3 = (S1 + 2) % 8;
-                            w2 = wrow[(S0 + 2) * 64];
-                            v2 = *reinterpret_cast<const f32x4*>(vt + toff[g2] + X2 * K7_COLS * 4);
-                            w3 = wrow[(S1 + 2) * 64];
-                            v3 = *reinterpret_cast<const f32x4*>(vt + toff[g3] + X3 * K7_COLS * 4);
-                        }
-                        acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, v0.x, acc[x0], 0, 0, 0);
-                        acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, v1.x, acc[x1], 0, 0, 0);
-                        if constexpr (NJ > 1) {
-                            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, v0.y, acc[x0], 0, 0, 0);
-                            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, v1.y, acc[x1], 0, 0, 0);
-                        }
-                        if constexpr (NJ > 2) {
-                            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, v0.z, acc[x0], 0, 0, 0);
-                            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, v1.z, acc[x1], 0, 0, 0);
-                        }
-                        if constexpr (NJ > 3) {
-                            acc[x0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, v0.w, acc[x0], 0, 0, 0);
-                            acc[x1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, v1.w, acc[x1], 0, 0, 0);
-                        }
-                        if constexpr (P + 1 < 52) {
-                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
-                        } else {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
-                        }
-                        w0 = w2; v0 = v2; w1 = w3; v1 = v3;
-                    };
-                    for_each_index(pairstep, std::make_integer_sequence<int, 52>{});
-                };
-                if (nj == 4) body(std::integral_constant<int, 4>{});
-                else if (nj == 1) body(std::integral_constant<int, 1>{});
-                else if (nj == 2) body(std::integral_constant<int, 2>{});
-                else body(std::integral_constant<int, 3>{});
-                __builtin_amdgcn_s_setprio(0);
-            } else if (r >= 1 && (r & 1) && ((r - 1) >> 1) < n) {
-                // ------------------------------ finish item (c, k), stage the next z pair ------------------------------
-                const int k = (r - 1) >> 1;
-                const bool has_next = k + 1 < n || seg_next;
-                // A^T: y0 = M0 + ... + M6 ; y1 = M1 - M2 + 2 M3 - 2 M4 + M5/2 - M6/2 + M7
-                f32x4 y0 = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + acc[6]);
-                f32x4 y1 = (acc[1] - acc[2]) + 2.f * (acc[3] - acc[4]) + 0.5f * (acc[5] - acc[6]) + acc[7];
-                if (c > 0) { y0 += part[0]; y1 += part[1]; }
-                if (has_next) commit();
-                if (last_chunk) {
-                    y0 += bias; y1 += bias;
-                    if (relu) {
-                        y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
-                        y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
-                    }
-                }
-                *reinterpret_cast<f32x4*>(a.out + o0) = y0;
-                *reinterpret_cast<f32x4*>(a.out + o0 + zstride) = y1;
-            }
-            __syncthreads();
-        }
-        if (seg_next) {
-            load_weights(c + 1);
-            __syncthreads();
-        }
-    }
-}
-
+#include "devtools/wino_f23_f27_kernels.inc"
 #endif  // SE_DEVTOOLS (retired F(2,3) / F(2,7) kernels)
 // ------------------------------------------------------------------------------------------------
 // 3x3x3 convolution with 1-D Winograd F(4,3) along z: 6 multiplies per 4 z-neighbouring outputs instead of 12
@@ -770,271 +79,7 @@ constexpr int W43_FLOATS = SE_WINO43_CHUNK_FLOATS;
 [[maybe_unused]] constexpr int V43_FLOATS = 6 * HY * HX * 16;
 
 #ifdef SE_DEVTOOLS   // retired A/B variant: single-phase form of the F(4,3) kernel
-#ifdef SE_STAMP43
-#define SE_ST43(IDX)                                                                           \
-    {                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-        unsigned long long now_;                                                               \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");          \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-        st_acc[IDX] += now_ - st_prev;                                                         \
-        st_prev = now_;                                                                        \
-    }
-#else
-#define SE_ST43(IDX)
-#endif
-
-__global__ __launch_bounds__(512) void conv3d_k3_wino43_kernel(ConvArgs a, int tiles_per_dim, int ztiles, int total_tiles,
-                                                               int n_cb, int units_per_wg, int variant, unsigned long long* dbg) {
-#ifdef SE_STAMP43
-    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0;
-#endif
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wl = lds;
-    float* vt = lds + W43_FLOATS;
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4* utab = reinterpret_cast<i32x4*>(lds + W43_FLOATS + V43_FLOATS);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int vl = lane & 15;
-    const int h = lane >> 4;
-    const int dim = a.dim;
-    const int chunks = a.cin >> 4;
-    const int n_units = n_cb * total_tiles;
-    const int u_begin = (int)blockIdx.x * units_per_wg;
-    const int u_end = min(u_begin + units_per_wg, n_units);
-    if (u_begin >= u_end) return;
-
-    for (int i = tid; i < u_end - u_begin; i += 512) {
-        int t = (u_begin + i) % total_tiles;
-        i32x4 e;
-        e.w = t % tiles_per_dim; t /= tiles_per_dim;
-        e.z = t % tiles_per_dim; t /= tiles_per_dim;
-        e.y = t % ztiles; t /= ztiles;
-        e.x = t;
-        utab[i] = e;
-    }
-
-    // compute role
-    const int nt = wave >> 2;
-    const int ry = (wave & 3) * 2 + (vl >> 3);
-    const int rx = vl & 7;
-    const float* vb = vt + (ry * HX + rx) * 16 + 4 * h;
-
-    // staging role: thread t < 400 owns halo column (t >> 2) and channel quad (t & 3): 6 raw slabs -> 6 V slabs
-    const bool s_on = tid < HY * HX * 4;
-    const int s_col = tid >> 2, s_q = tid & 3;
-    const int s_cy = s_col / HX, s_cx = s_col % HX;
-    f32x4 raw[6];
-    auto fetch = [&](int u, int c) {
-        const i32x4 e = utab[u - u_begin];
-        const int gy = e.z * 8 - 1 + s_cy, gx = e.w * 8 - 1 + s_cx, gz0 = e.y * 4 - 1;
-        const bool okc = s_on && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim;
-        const long long base = ((((long long)e.x * dim) * dim + gy) * dim + gx) * a.cin_pad + c * 16 + s_q * 4;
-        const long long zs = (long long)dim * dim * a.cin_pad;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const bool ok = okc && (unsigned)(gz0 + q) < (unsigned)dim;
-            const f32x4 t = *reinterpret_cast<const f32x4*>(a.in + (ok ? base + (gz0 + q) * zs : 0));
-            raw[q] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto commit = [&]() {
-        if (!s_on) return;
-        const f32x4 d0 = raw[0], d1 = raw[1], d2 = raw[2], d3 = raw[3], d4 = raw[4], d5 = raw[5];
-        f32x4 v[6];
-        v[0] = 4.f * d0 - 5.f * d2 + d4;
-        v[5] = 4.f * d1 - 5.f * d3 + d5;
-        const f32x4 e1 = d4 - 4.f * d2, o1 = d3 - 4.f * d1;
-        v[1] = e1 + o1;
-        v[2] = e1 - o1;
-        const f32x4 e2 = d4 - d2, o2 = 2.f * (d3 - d1);
-        v[3] = e2 + o2;
-        v[4] = e2 - o2;
-#pragma unroll
-        for (int x = 0; x < 6; ++x) *reinterpret_cast<f32x4*>(vt + (x * HY * HX + s_col) * 16 + s_q * 4) = v[x];
-    };
-    auto load_weights = [&](int cb, int c) {
-        fill_lds<512>(wl, reinterpret_cast<const f32x4*>(a.wpack_e) + ((size_t)c * n_cb + cb) * (W43_FLOATS / 4), W43_FLOATS / 4, tid);
-    };
-    auto out_offset = [&](int u, int cb) -> long long {
-        const i32x4 e = utab[u - u_begin];
-        return ((((long long)e.x * dim + e.y * 4) * dim + e.z * 8 + ry) * dim + e.w * 8 + rx) * a.cout + cb * 32 + nt * 16 + 4 * h;
-    };
-    const long long zstride = (long long)dim * dim * a.cout;
-
-    auto first_item = [&]() {
-        WinoIter it;
-        it.u_lo = u_begin;
-        it.cb = u_begin / total_tiles;
-        it.n = min(u_end, (it.cb + 1) * total_tiles) - u_begin;
-        it.c = 0; it.k = 0; it.valid = true;
-        return it;
-    };
-    auto next_item = [&](WinoIter it) {
-        if (++it.k == it.n) {
-            it.k = 0;
-            if (++it.c == chunks) {
-                it.c = 0;
-                it.u_lo += it.n;
-                if (it.u_lo >= u_end) { it.valid = false; return it; }
-                it.cb = it.u_lo / total_tiles;
-                it.n = min(u_end, (it.cb + 1) * total_tiles) - it.u_lo;
-            }
-        }
-        return it;
-    };
-
-    const bool relu = a.flags & SE_EPI_RELU;
-    const bool use_res = (a.flags & SE_EPI_RES_PRE_RELU) && a.res;
-
-    __syncthreads();   // utab
-    WinoIter cur = first_item();
-    fetch(cur.u_lo, 0);
-    commit();
-    load_weights(cur.cb, 0);
-    __syncthreads();
-
-    // Per-item epilogue operands (running partial sums of earlier chunks, skip tensor, bias) are fetched one item AHEAD, in
-    // the middle of the previous item's MFMA block: issued at item start they sat behind the just-issued output stores and
-    // the address arithmetic ran with the matrix pipe idle (2.2 k cycles of "setup" per item in the stamp build).
-    f32x4 part[4], resv[4], part_n[4], resv_n[4];
-#pragma unroll
-    for (int z = 0; z < 4; ++z) part[z] = resv[z] = part_n[z] = resv_n[z] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    long long o0 = out_offset(cur.u_lo + cur.k, cur.cb), o0_n = 0;
-    f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + cur.cb * 32 + nt * 16 + 4 * h), bias_n = bias;
-    if (chunks == 1 && use_res) {
-#pragma unroll
-        for (int z = 0; z < 4; ++z) resv[z] = *reinterpret_cast<const f32x4*>(a.res + o0 + z * zstride);
-    }
-    bool part_ready = true;     // false: the partial sums of the current item could not be prefetched (run of one unit)
-    bool res_ready = true;
-    const bool prefetch_epi = variant != 7;    // se_debug_set_variant(17): A/B, epilogue operands loaded at item start
-
-#ifdef SE_STAMP43
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
-#endif
-    while (true) {
-        const WinoIter nxt = next_item(cur);
-        const int u = cur.u_lo + cur.k;
-        const bool last_chunk = cur.c == chunks - 1;
-        const int fetch_u = nxt.valid ? nxt.u_lo + nxt.k : u;
-        const int fetch_c = nxt.valid ? nxt.c : cur.c;
-        if (cur.c > 0 && !part_ready) {
-            // a run of one unit meets the same tile again in the very next item: its stores must have landed first
-            if (cur.n == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int z = 0; z < 4; ++z) part[z] = *reinterpret_cast<const f32x4*>(a.out + o0 + z * zstride);
-        }
-        if (last_chunk && use_res && !res_ready) {
-#pragma unroll
-            for (int z = 0; z < 4; ++z) resv[z] = *reinterpret_cast<const f32x4*>(a.res + o0 + z * zstride);
-        }
-        // what the NEXT item needs: decided here, loaded inside the MFMA block below
-        const bool n_part = prefetch_epi && nxt.valid && nxt.c > 0 && nxt.n > 1;
-        const bool n_res = prefetch_epi && nxt.valid && use_res && nxt.c == chunks - 1;
-
-        f32x4 acc[6];
-#pragma unroll
-        for (int x = 0; x < 6; ++x) acc[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const f32x4* wrow = reinterpret_cast<const f32x4*>(wl) + nt * 64 + lane;
-        SE_ST43(0)   // setup
-        f32x4 wc = wrow[0], vc = *reinterpret_cast<const f32x4*>(vb);
-        f32x4 wn = wc, vn = vc;
-        auto substep = [&](auto s_tag) {
-            constexpr int S = decltype(s_tag)::value;
-            constexpr int x = S % 6;
-            if constexpr (S == 3) fetch(fetch_u, fetch_c);   // next item's raw columns: global loads under the MFMAs
-            if constexpr (S == 9) {                          // ... and its epilogue operands
-                if (nxt.valid) {
-                    o0_n = out_offset(fetch_u, nxt.cb);
-                    bias_n = *reinterpret_cast<const f32x4*>(a.bpack + nxt.cb * 32 + nt * 16 + 4 * h);
-                    if (n_part) {
-#pragma unroll
-                        for (int z = 0; z < 4; ++z) part_n[z] = *reinterpret_cast<const f32x4*>(a.out + o0_n + z * zstride);
-                    }
-                    if (n_res) {
-#pragma unroll
-                        for (int z = 0; z < 4; ++z) resv_n[z] = *reinterpret_cast<const f32x4*>(a.res + o0_n + z * zstride);
-                    }
-                }
-            }
-            if constexpr (S + 1 < 54) {
-                constexpr int t1 = (S + 1) / 6, x1 = (S + 1) % 6;
-                wn = wrow[(S + 1) * 128];
-                vn = *reinterpret_cast<const f32x4*>(vb + (x1 * HY * HX + (t1 / 3) * HX + (t1 % 3)) * 16);
-            }
-            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.x, vc.x, acc[x], 0, 0, 0);
-            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.y, vc.y, acc[x], 0, 0, 0);
-            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.z, vc.z, acc[x], 0, 0, 0);
-            acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc.w, vc.w, acc[x], 0, 0, 0);
-            if constexpr (S + 1 < 54) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            wc = wn;
-            vc = vn;
-        };
-        for_each_index(substep, std::make_integer_sequence<int, 54>{});
-        SE_ST43(1)   // mfma block
-
-        // A^T
-        f32x4 y[4];
-        {
-            const f32x4 s12 = acc[1] + acc[2], d12 = acc[1] - acc[2], s34 = acc[3] + acc[4], d34 = acc[3] - acc[4];
-            y[0] = acc[0] + s12 + s34;
-            y[1] = d12 + 2.f * d34;
-            y[2] = s12 + 4.f * s34;
-            y[3] = d12 + 8.f * d34 + acc[5];
-        }
-        if (cur.c > 0) {
-#pragma unroll
-            for (int z = 0; z < 4; ++z) y[z] += part[z];
-        }
-        // single V tile: every wave must be done reading it before the next item's columns are committed
-        __syncthreads();
-        SE_ST43(2)   // A^T + barrier 1
-        if (nxt.valid) {
-            commit();
-            if (nxt.cb != cur.cb || nxt.c != cur.c) load_weights(nxt.cb, nxt.c);
-        }
-        SE_ST43(3)   // commit
-        // NOTE: the registers holding y must not be written again soon after these stores: hipcc guards a store's
-        // source registers with s_waitcnt vmcnt(0), i.e. the full store latency (measured: 5.7k cycles per item when a
-        // loop-carried copy of y followed the stores).  y is rebuilt from scratch one MFMA block later.
-        if (last_chunk) {
-#pragma unroll
-            for (int z = 0; z < 4; ++z) {
-                y[z] += bias;
-                if (use_res) y[z] += resv[z];
-                if (relu) {
-                    y[z].x = fmaxf(y[z].x, 0.f); y[z].y = fmaxf(y[z].y, 0.f);
-                    y[z].z = fmaxf(y[z].z, 0.f); y[z].w = fmaxf(y[z].w, 0.f);
-                }
-            }
-        }
-#pragma unroll
-        for (int z = 0; z < 4; ++z) *reinterpret_cast<f32x4*>(a.out + o0 + z * zstride) = y[z];
-        if (!nxt.valid) break;
-        SE_ST43(4)   // epilogue
-        __syncthreads();
-        SE_ST43(5)   // barrier 2
-        part_ready = !(nxt.c > 0) || n_part;
-        res_ready = n_res;
-        cur = nxt;
-        o0 = o0_n;
-        bias = bias_n;
-#pragma unroll
-        for (int z = 0; z < 4; ++z) { part[z] = part_n[z]; resv[z] = resv_n[z]; }
-    }
-#ifdef SE_STAMP43
-    if (lane == 0 && dbg) {
-        unsigned long long* o = dbg + ((size_t)blockIdx.x * 8 + wave) * 6;
-        for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
-    }
-#endif
-}
-
+#include "devtools/wino_f43_single_phase_kernel.inc"
 #endif  // SE_DEVTOOLS (single-phase F(4,3) kernel)
 
 // ------------------------------------------------------------------------------------------------

@@ -330,6 +330,8 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     };
 
     f32x4 acc[24];
+    f32x2 raw[6][2];      // input rows of the next step (12 loads per lane)
+    f32x4 wreg[9];        // weight stream pieces in flight
     // ReLU as max(v, 0) / no ReLU as max(v, -inf): one v_max_f32 per element, no per-element select on a run-time flag
     const float relu_lo = (a.flags & SE_EPI_RELU) ? 0.f : -__builtin_inff();
     const bool use_res = (a.flags & SE_EPI_RES_PRE_RELU) && a.res;
@@ -495,8 +497,6 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     int ccur = 0, icur = 0;
     Unit unx = ucur;
     int cnx = 0, inx = 0;
-    f32x2 raw[6][2];
-    f32x4 wreg[9];
     int step_index = 0;
     f32x4 bias_next = *reinterpret_cast<const f32x4*>(a.bpack + ucur.cb * 32 + ct * 16 + 4 * h);   // bias of the tile whose first MFMA phase comes next
 
@@ -581,6 +581,9 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         for_each_idx(group, std::make_integer_sequence<int, 18>{});
     };
 
+#ifdef SE_DEVTOOLS
+#include "devtools/wino2d_lockstep.inc"      // experiment (exp & 0x200000): both waves of a SIMD in the same phase, no ping-pong
+#endif
     // ---- prologue: each group's V tile of step 0; weight half 0 of step 0 (by group 1's threads - half 1 of step 0 is written by
     // group 0 inside its first MFMA phase) ----
     fetch_setup(ucur);
@@ -776,6 +779,7 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
             case 57: W2_VAR(0x20000); break; // attribution: no skip-tensor loads
             case 58: W2_VAR(0x40000); break; // attribution: no output stores
             case 60: W2_VAR(0x100000); break; // experiment: LDS-counter group barriers + cross-group waits instead of workgroup barriers
+            case 61: W2_VAR(0x200000); break; // experiment (round 3): lockstep form, no ping-pong
             default: W2_VAR(0); break;
         }
 #undef W2_VAR

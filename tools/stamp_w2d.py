@@ -28,6 +28,10 @@ for g, name in ((0, "group A (waves 0-3)"), (1, "group B (waves 4-7)")):
     print(f"   MFMA phase   : first half {w[:, :, 0].mean() / nm:7.0f}  mid-barrier wait {w[:, :, 1].mean() / nm:7.0f}  second half {w[:, :, 2].mean() / nm:7.0f}  end-barrier wait {w[:, :, 3].mean() / nm:7.0f}   (ideal 2304 + 2304 cycles of MFMA issue)")
     print(f"   staging phase: first half {w[:, :, 4].mean() / ns:7.0f}  mid-barrier wait {w[:, :, 5].mean() / ns:7.0f}  second half {w[:, :, 6].mean() / ns:7.0f}  end-barrier wait {w[:, :, 7].mean() / ns:7.0f}")
     print(f"   staging: first half = commit, second half = epilogue (1 phase in {cin // 8}) {w[:, :, 13].mean() / ns:7.0f} + unit walk")
+if int(os.environ.get("VARIANT", 0)) == 61:
+    w = d.mean(dim=(0, 1))
+    n = float(w[8])
+    print("lockstep form, cycles per step (mean over waves): MFMA phase %.0f  barrier %.0f  V-tile transform %.0f  weight commit %.0f  epilogue+walk %.0f  barrier %.0f  (ideal MFMA 9216 per SIMD = 2 waves x 144 x 32)" % tuple(float(w[k]) / n for k in range(6)))
 if os.environ.get("PERWAVE"):
     names = ["mfma1", "midwait", "mfma2", "endwait", "stg1", "midwait", "stg2", "endwait"]
     print("per wave (mean over workgroups), cycles per phase:  " + "  ".join(f"{n:>8s}" for n in names))
