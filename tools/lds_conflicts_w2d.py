@@ -6,7 +6,10 @@
 For the layout constants given on the command line (default: the kernel's) it prints the extra LDS cycles per step (one 8-channel
 chunk of one tile, both wave groups) of (1) the MFMA phase's B-operand reads and (2) the 96 stores of the V-tile transform, with the
 lanes that have no output parked as the kernel parks them.  Round 2 (VREC 200, no tile pad, dummy = lane * 4 floats): 792 extra
-cycles per step = the 18 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE the counters showed (804 per step measured).
+cycles per step, next to the 804 the counters showed.  CAUTION: the model explains WHERE the conflicts are (the counter attribution
+of tools/pmc_lds_attr.sh agrees: all of them come from these stores) but not their number after a layout change - for the round-3
+layout it predicts 96, the counter says 590-710 (profiles/r03_lds_conflict_attribution.txt): ds_write_b128 does not bank the way
+the published table says.
 
 usage: python tools/lds_conflicts_w2d.py [VREC TILE_PAD [old-dummy]]
 """
