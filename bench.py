@@ -426,6 +426,7 @@ def main():
     # ---- parity gate on the timed output + CPU baseline, same frames (rank 0's) -----------------------
     want_cpu = world == 1 and not args.no_cpu_baseline
     parity_ok = True
+    j64 = None
     if not args.no_parity or want_cpu:
         nref = args.batch if G <= 64 else 1          # the oracle takes ~1 s per frame at 64^3 and ~10 s at 128^3
         j32, j64, base = oracle_reference(sd, G, img_h[:nref], depth_h[:nref], timed=want_cpu)
@@ -447,7 +448,8 @@ def main():
         line["shard_check"] = shard_check
         parity_ok = parity_ok and shard_check["max_abs_diff_m"] <= shard_check["tol"]
     if world == 1 and not bf16 and args.backbone_dtype == "fp32" and G == 64 and not args.no_extras:
-        line["extra"] = {"config3_bf16_b32": config3_extra(net, rank, device, args.depth_kind),
+        line["extra"] = {"split_bf16_v2v_b8": split_extra(net, img, depth, timed_joints, j64),
+                         "config3_bf16_b32": config3_extra(net, rank, device, args.depth_kind),
                          "no_scene_v2v32_b8": no_scene_extra(device),
                          "config5_g128_b8": config5_extra(device, args.depth_kind)}
     if dt_single is not None:
@@ -507,6 +509,29 @@ def _time_forward(net, img, depth, steps=5, warm=2):
         dt = (time.perf_counter() - t0) / steps
     assert bool(torch.isfinite(out[0]).all())
     return dt
+
+
+def split_extra(net, img, depth, f32_joints, oracle_j64):
+    """EXPERIMENTAL split-bf16 arithmetic for the 3x3x3 layers (float32 tensors; csrc/conv3d_split.hip), beside the headline: the same
+    frames, one stream; joints against the float32 program of this run and against the oracle."""
+    import torch
+    try:
+        net.set_v2v_dtype("split_bf16")
+        dt = _time_forward(net, img, depth)
+        with torch.no_grad():
+            kp = net(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth)[0].cpu()
+        r = {"value": round(img.shape[0] / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "batch": int(img.shape[0]),
+             "dtype": "f32 tensors, 3x3x3 layers as split-bf16 products (hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, f32 accumulate)",
+             "streams": 1, "max_joint_diff_to_f32_program_m": round(float((kp - f32_joints).abs().max()), 9),
+             "note": "experimental; not the float32 headline.  tol 1e-3 m"}
+        if oracle_j64 is not None:
+            n = oracle_j64.shape[0]
+            r["max_joint_err_vs_oracle_m"] = round(float((kp[:n] - oracle_j64).abs().max()), 9)
+        return r
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+    finally:
+        net.set_v2v_dtype("fp32")
 
 
 def config5_extra(device, depth_kind):

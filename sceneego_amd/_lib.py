@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -62,6 +62,7 @@ SIGNATURES = {
     "se_preprocess_image_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "se_bias_act_nchw_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_conv3d_f32_algo": (_i, [_i, _i, _i, _i]),
+    "se_conv3d_k3_split3_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
 # present only in development builds (csrc/build.sh --devtools): A/B kernel selection and cycle-stamp diagnostics (tools/)
 DEVTOOLS_SIGNATURES = {
@@ -368,6 +369,16 @@ def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksi
     if _prof is not None:
         e1.record()
         _prof.append((("conv3d" if inp.dtype == torch.float32 else "conv3d_bf16", ksize, cin_pad, cout, dim), e0, e1))
+
+
+def conv3d_k3_split3(inp, wpack_hi, wpack_lo, bpack, residual, out, batch, dim, cin_pad, cout, flags):
+    """EXPERIMENTAL: 3x3x3 convolution on float32 channels-last tensors with split-bf16 arithmetic (se_conv3d_k3_split3_f32)."""
+    require_hip(inp, out, wpack_hi, wpack_lo, bpack)
+    _chk_f32(inp, out, bpack, residual)
+    assert wpack_hi.dtype == torch.bfloat16 and wpack_lo.dtype == torch.bfloat16
+    with _timed(("conv3d_split3", 3, cin_pad, cout, dim)):
+        _check(load().se_conv3d_k3_split3_f32(_ptr(inp), _ptr(wpack_hi), _ptr(wpack_lo), _ptr(bpack), _ptr(residual), _ptr(out), batch,
+                                              dim, cin_pad, cout, flags, _stream()), "se_conv3d_k3_split3_f32")
 
 
 def conv3d_skip16(inp, wpack, bpack_sum, skip_in, skip_w, out, batch, dim, cin, cout, flags):

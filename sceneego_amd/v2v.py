@@ -111,12 +111,12 @@ class V2VModel(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     # -- execution ---------------------------------------------------------------------------
-    def compile(self, dtype=None, output_scale=1.0) -> "V2VProgram":
+    def compile(self, dtype=None, output_scale=1.0, split3=False) -> "V2VProgram":
         """(Re)build the HIP launch program from the current parameters (call after loading weights).
         ``dtype``: torch.float32 (default; parity path) or torch.bfloat16 (bf16 storage, float32 accumulation).
         ``output_scale``: ``run(..., scaled=True)`` returns output_scale * logits (the caller's ``volume_multiplier``,
         reference network/voxel_net_depth.py:271, folded into the output layer); ``forward`` / ``run()`` return the plain logits."""
-        self._program = V2VProgram(self, dtype or getattr(self, "program_dtype", torch.float32), output_scale)
+        self._program = V2VProgram(self, dtype or getattr(self, "program_dtype", torch.float32), output_scale, split3)
         return self._program
 
     @property
@@ -156,10 +156,12 @@ def channels_last_to_octet_planar(x):
 # the launch program
 # ------------------------------------------------------------------------------------------------
 class _PackedConv:
-    __slots__ = ("w", "b", "cin", "cin_pad", "cout", "k", "transposed", "fused")
+    __slots__ = ("w", "b", "cin", "cin_pad", "cout", "k", "transposed", "fused", "w_hi", "w_lo")
 
-    def __init__(self, conv, bn, cin_pad=None, dtype=torch.float32, scale=1.0):
-        """``scale``: the packed layer computes scale * conv(x) (weights and bias multiplied before packing)."""
+    def __init__(self, conv, bn, cin_pad=None, dtype=torch.float32, scale=1.0, split3=False):
+        """``scale``: the packed layer computes scale * conv(x) (weights and bias multiplied before packing).
+        ``split3`` (float32 3x3x3 layers, experimental): also pack the two bfloat16 halves of the BatchNorm-folded weights for
+        se_conv3d_k3_split3_f32."""
         transposed = isinstance(conv, nn.ConvTranspose3d)
         w = conv.weight.detach().float().contiguous()
         if scale != 1.0:
@@ -190,13 +192,26 @@ class _PackedConv:
         if scale != 1.0 and bias is not None:
             bias = bias * float(scale)
         _lib.conv3d_pack(w, bias, g, be, mu, var, eps, self.w, self.b, cout, cin, self.cin_pad, k, transposed)
+        self.w_hi = self.w_lo = None
+        if split3 and not bf16 and not transposed and k == 3 and cout % 32 == 0 and self.cin_pad % 16 == 0:
+            wf = w if g is None else w * (g / torch.sqrt(var + eps)).view(-1, 1, 1, 1, 1)      # the folding se_conv3d_pack_f32 applies
+            hi = wf.to(torch.bfloat16).float()
+            lo = wf - hi
+            n = _lib.conv3d_packed_elems(cout, self.cin_pad, 3, False, bf16=True)
+            dummy_b = torch.empty(_round16(cout), device=dev, dtype=torch.float32)
+            self.w_hi = torch.empty(n, device=dev, dtype=torch.bfloat16)
+            self.w_lo = torch.empty(n, device=dev, dtype=torch.bfloat16)
+            _lib.conv3d_pack(hi.contiguous(), None, None, None, None, None, 0.0, self.w_hi, dummy_b, cout, cin, self.cin_pad, 3, False)
+            _lib.conv3d_pack(lo.contiguous(), None, None, None, None, None, 0.0, self.w_lo, dummy_b, cout, cin, self.cin_pad, 3, False)
 
 
 class V2VProgram:
-    def __init__(self, model: V2VModel, dtype=torch.float32, output_scale=1.0):
+    def __init__(self, model: V2VModel, dtype=torch.float32, output_scale=1.0, split3=False):
         assert dtype in (torch.float32, torch.bfloat16)
         self.dtype = dtype
         self.output_scale = float(output_scale)
+        # EXPERIMENTAL: float32 tensors, 3x3x3 layers of the 64^3 / 32^3 / 16^3 levels on split-bf16 arithmetic (csrc/conv3d_split.hip)
+        self.split3 = bool(split3) and dtype == torch.float32
         p = next(model.parameters())
         if not p.is_cuda:
             raise _lib.HipExtensionError("V2VModel must live on a HIP device to be compiled (got %s)" % p.device)
@@ -223,8 +238,8 @@ class V2VProgram:
         self.workspace = torch.empty(32 << 20, device=self.device, dtype=torch.float32) if dtype == torch.float32 else None
 
     def _pack_res(self, m):
-        c1 = _PackedConv(m.res_branch[0], m.res_branch[1], None, self.dtype)
-        c2 = _PackedConv(m.res_branch[3], m.res_branch[4], None, self.dtype)
+        c1 = _PackedConv(m.res_branch[0], m.res_branch[1], None, self.dtype, split3=self.split3)
+        c2 = _PackedConv(m.res_branch[3], m.res_branch[4], None, self.dtype, split3=self.split3)
         sk = _PackedConv(m.skip_con[0], m.skip_con[1], None, self.dtype) if len(m.skip_con) else None
         if sk is not None and sk.cin == 16 and self.dtype == torch.float32:
             # 16-channel skip convolution (front_layers.1): folded weights [cout][16] + summed bias for se_conv3d_skip16_f32, which
@@ -241,6 +256,9 @@ class V2VProgram:
     def _conv(self, x, pc, B, dim, flags, residual=None, out=None, pool_out=None):
         if out is None:
             out = self._new(B, dim, pc.cout)
+        if self.split3 and pc.w_hi is not None and dim % 16 == 0 and pool_out is None:
+            _lib.conv3d_k3_split3(x, pc.w_hi, pc.w_lo, pc.b, residual, out, B, dim, pc.cin_pad, pc.cout, flags)
+            return out
         _lib.conv3d(x, pc.w, pc.b, residual, out, B, dim, pc.cin, pc.cin_pad, pc.cout, pc.k, flags, self.workspace, pool_out=pool_out)
         return out
 
@@ -251,7 +269,7 @@ class V2VProgram:
         convolutions is always octet-planar [B][C/8][D][D][D][8]; ``x_oct`` says the block input is, ``out_oct`` asks for an
         octet-planar block output (4x fewer cache lines per halo load of the reader; see run() for who reads what)."""
         c1, c2, sk = blk
-        w2d = (self.dtype == torch.float32 and _lib.conv3d_algo(dim, c1.cin_pad, c1.cout, 3) == 2
+        w2d = (self.dtype == torch.float32 and not self.split3 and _lib.conv3d_algo(dim, c1.cin_pad, c1.cout, 3) == 2
                and _lib.conv3d_algo(dim, c2.cin_pad, c2.cout, 3) == 2)
         assert w2d or not (x_oct or out_oct)
         assert sk is None or not x_oct           # the 1x1x1 skip convolution reads channels-last
@@ -272,7 +290,7 @@ class V2VProgram:
 
     def _oct_ok(self, blk, dim):
         c1, c2, _ = blk
-        return (self.dtype == torch.float32 and _lib.conv3d_algo(dim, c1.cin_pad, c1.cout, 3) == 2
+        return (self.dtype == torch.float32 and not self.split3 and _lib.conv3d_algo(dim, c1.cin_pad, c1.cout, 3) == 2
                 and _lib.conv3d_algo(dim, c2.cin_pad, c2.cout, 3) == 2)
 
     def _pool(self, x, B, dim, c, x_oct=False):

@@ -132,7 +132,10 @@ class VoxelNetwork_depth(nn.Module):
         return self
 
     def set_v2v_dtype(self, dtype):
-        """'fp32' / 'bf16' (or the torch dtypes); takes effect at the next forward."""
+        """'fp32' / 'bf16' (or the torch dtypes); takes effect at the next forward.  'split_bf16' (EXPERIMENTAL): float32 tensors
+        everywhere, the 3x3x3 layers of the 64^3 / 32^3 / 16^3 levels computed with split-bf16 operands (three bf16 MFMA products per
+        float32 product, float32 accumulation; csrc/conv3d_split.hip) - measured beside the headline, never part of it."""
+        self.v2v_split3 = isinstance(dtype, str) and dtype.lower() in ("split_bf16", "split-bf16", "bf16x3")
         if isinstance(dtype, str):
             dtype = torch.bfloat16 if dtype.lower() in ("bf16", "bfloat16") else torch.float32
         assert dtype in (torch.float32, torch.bfloat16)
@@ -176,7 +179,7 @@ class VoxelNetwork_depth(nn.Module):
         b = pf.bias.detach().to(dtype)
         self._folded = (fb, w, b)
         # volume_multiplier (reference :271 ``volumes * self.volume_multiplier``) is folded into the output layer's packed weights
-        self.volume_net.compile(self.v2v_dtype, output_scale=float(self.volume_multiplier))
+        self.volume_net.compile(self.v2v_dtype, output_scale=float(self.volume_multiplier), split3=getattr(self, "v2v_split3", False))
         return self
 
     def _device_tables(self, grid_coord_proj_batch, coord_volumes, device):
@@ -275,7 +278,7 @@ class VoxelNetwork_depth(nn.Module):
         # lift to the volume: V2V input buffer [B,G,G,G,cin_pad], zero beyond the real channels
         prog = self.volume_net.program
         if prog.output_scale != float(self.volume_multiplier):      # the attribute was changed after compile()
-            prog = self.volume_net.compile(self.v2v_dtype, output_scale=float(self.volume_multiplier))
+            prog = self.volume_net.compile(self.v2v_dtype, output_scale=float(self.volume_multiplier), split3=getattr(self, "v2v_split3", False))
         C = FEATURE_CHANNELS
         # V2V input buffer: persistent per batch size, zero-filled once (pad channels stay zero; every call rewrites
         # the real channels), so no per-call clearing pass is needed

@@ -158,6 +158,30 @@ def test_forward_relu_volumes_vs_golden(golden, golden_meta):
     assert np.abs(vs - g["volumes_samples"]).max() <= 1e-4 * float(np.abs(g["logits_samples"]).max())
 
 
+def test_forward_split_bf16_mode_vs_goldens(golden, golden_meta):
+    """EXPERIMENTAL `set_v2v_dtype("split_bf16")`: float32 tensors, the 3x3x3 layers of the 64^3 / 32^3 / 16^3 levels on split-bf16
+    operands (three bf16 MFMA products per float32 product).  Unlike the bf16-STORAGE mode this one is inside the north-star
+    tolerance: joints <= 1e-3 m of the reference goldens (CPU emulation of the scheme: 2e-5 m, tests/test_oracle_golden.py)."""
+    net = _build()
+    net.set_v2v_dtype("split_bf16")
+    for case in ("b1_floor", "b2_uniform"):
+        m = next(c for c in golden_meta["cases"] if c["name"] == case)
+        g = golden(case)
+        img, depth = synth.make_inputs(m["input_seed"], m["batch"], m["depth_kind"])
+        kp, _, vols, _ = _forward(net, img, depth)
+        prog = net.volume_net.program
+        assert prog.split3 and prog.dtype == torch.float32 and prog.front_res[1][0].w_hi is not None
+        err = float(np.abs(kp.cpu().numpy() - g["joints"]).max())
+        print(f"split_bf16 mode, {case}: joints vs reference golden {err:.2e} m")
+        assert err <= JOINT_TOL, err
+        pos = torch.from_numpy(g["sample_pos"]).to(DEV)
+        vs = vols.reshape(m["batch"], 15, -1)[:, :, pos].cpu().numpy()
+        assert np.abs(vs - g["volumes_samples"]).max() <= 2e-3 * g["volumes_max"].max() + 1e-7
+    net.set_v2v_dtype("fp32")
+    kp32 = _forward(net, img, depth)[0]
+    assert not net.volume_net.program.split3 and float((kp32 - kp).abs().max()) < 1e-3
+
+
 def test_v2v_stagewise_vs_oracle(net64, oracle_constants):
     """Every stage boundary of the pipeline against the oracle on the same seeded input (B=1)."""
     sd = synthetic_state_dict(False)

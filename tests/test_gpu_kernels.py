@@ -207,6 +207,58 @@ def test_conv3d_vs_torch(B, dim, cin, cout, k, relu, residual, bn):
         assert err < 2e-5 * max(1.0, float(want.abs().max())), (err, workspace is not None)
 
 
+SPLIT3_CASES = [(1, 16, 32, 32, True, True), (2, 32, 16, 32, True, False), (1, 16, 64, 128, False, False), (1, 32, 32, 64, True, True),
+                (2, 16, 128, 128, True, True), (3, 16, 48, 32, True, True)]
+
+
+@pytest.mark.parametrize("B,dim,cin,cout,relu,residual", SPLIT3_CASES)
+def test_conv3d_split_bf16_vs_torch(B, dim, cin, cout, relu, residual):
+    """EXPERIMENTAL split-bf16 3x3x3 convolution (se_conv3d_k3_split3_f32: float32 tensors, every product as hi*hi + hi*lo + lo*hi on
+    the bf16 MFMA, float32 accumulation) against torch-CPU float32 Conv3d + BatchNorm3d (+ skip) (+ ReLU), reference
+    network/v2v.py:21-43.  Bound: 1e-4 of max|y| (16 mantissa bits per operand; the float32 kernels' bound is 2e-5); measured ~1e-5."""
+    seed = hash((B, dim, cin, cout, 3)) % 1000
+    conv = nn.Conv3d(cin, cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(synth.normal(seed, "w", tuple(conv.weight.shape), (2.0 / (cin * 27)) ** 0.5)))
+        conv.bias.copy_(torch.from_numpy(synth.uniform(seed, "cb", (cout,), -0.2, 0.2)))
+    bnm = _rand_bn(cout, seed)
+    x = torch.from_numpy(synth.normal(seed, "x", (B, cin, dim, dim, dim)))
+    res = torch.from_numpy(synth.normal(seed, "r", (B, cout, dim, dim, dim))) if residual else None
+    with torch.no_grad():
+        want = bnm(conv(x))
+        if residual:
+            want = want + res
+        if relu:
+            want = F.relu(want)
+    pc = _PackedConv(conv.to(DEV), bnm.to(DEV), split3=True)
+    assert pc.w_hi is not None and pc.w_hi.dtype == torch.bfloat16
+    out = torch.full((B, dim, dim, dim, cout), -77.0, device=DEV)
+    flags = (_lib.EPI_RELU if relu else 0) | (_lib.EPI_RES_PRE_RELU if residual else 0)
+    _lib.conv3d_k3_split3(_ndhwc(x).to(DEV), pc.w_hi, pc.w_lo, pc.b, _ndhwc(res).to(DEV) if residual else None, out, B, dim, pc.cin_pad,
+                          cout, flags)
+    got = _ncdhw(out.cpu())
+    err = float((got - want).abs().max())
+    scale = max(1.0, float(want.abs().max()))
+    print(f"split-bf16 conv {cin}->{cout} @{dim}^3: max error {err:.2e} = {err / scale:.2e} of max|y|")
+    assert err < 1e-4 * scale, (err, scale)
+    # the float32 kernel on the same data, for scale
+    out32 = torch.empty_like(out)
+    _lib.conv3d(_ndhwc(x).to(DEV), pc.w, pc.b, _ndhwc(res).to(DEV) if residual else None, out32, B, dim, cin, pc.cin_pad, cout, 3, flags, None)
+    assert float((out - out32).abs().max()) < 1e-4 * scale
+
+
+def test_conv3d_split_bf16_refuses_unsupported_shapes():
+    t = torch.zeros(64, device=DEV)
+    import ctypes
+    p = ctypes.c_void_p(t.data_ptr())
+    lib = _lib.load()
+    assert lib.se_conv3d_k3_split3_f32(p, p, p, p, None, p, 1, 8, 32, 32, 0, None) == -1      # dim % 16
+    assert lib.se_conv3d_k3_split3_f32(p, p, p, p, None, p, 1, 16, 24, 32, 0, None) == -1     # cin_pad % 16
+    assert lib.se_conv3d_k3_split3_f32(p, p, p, p, None, p, 1, 16, 32, 16, 0, None) == -1     # cout % 32
+    assert lib.se_conv3d_k3_split3_f32(p, p, p, p, None, p, 1, 16, 32, 32, _lib.IN_OCTET, None) == -1
+    assert lib.se_conv3d_k3_split3_f32(p, None, p, p, None, p, 1, 16, 32, 32, 0, None) == -1
+
+
 def test_conv3d_padded_input_channels_and_planar_output():
     """33 real channels inside a 48-channel buffer (front conv) and the 15-channel planar output layer."""
     for dim in (8, 16):     # direct kernel, then the LDS-tiled 7^3 kernel (occupancy channel in a 9th 4-channel chunk)
