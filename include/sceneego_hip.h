@@ -217,12 +217,16 @@ long long se_conv3d_packed_elems_bf16(int cout, int cin_pad, int ksize, int tran
  * k = 3 + folded BN + epilogue on float32 channels-last tensors with SPLIT-bf16 arithmetic: every operand x = hi + lo
  * (hi = bf16(x), lo = bf16(x - hi)), a product = hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with float32 accumulation.
  * Replaces the same reference calls as se_conv3d_f32 with ksize 3 (network/v2v.py:21-43) for the shapes dim % 16 == 0,
- * cin_pad % 16 == 0, cout % 32 == 0.  wpack_hi / wpack_lo: se_conv3d_pack_bf16(ksize 3, no BatchNorm arguments) of the two halves
- * of the BatchNorm-folded float32 weights; bpack: the folded float32 bias (as se_conv3d_pack_f32 writes it); flags: SE_EPI_RELU,
- * SE_EPI_RES_PRE_RELU / SE_EPI_RES_POST_RELU.  SE_ERR_BAD_ARG for anything else (nothing launched).                          */
-int se_conv3d_k3_split3_f32(const float* in, const se_bf16* wpack_hi, const se_bf16* wpack_lo, const float* bpack,
-                            const float* residual, float* out, int batch, int dim, int cin_pad, int cout, int flags,
-                            void* stream);
+ * cin_pad % 8 == 0, cout % 32 == 0.
+ * se_conv3d_split3_pack: w = float32 [cout][cin][3][3][3] with the BatchNorm scale already folded in -> wsplit
+ * (se_conv3d_split3_packed_elems bf16 elements; -1 for an unsupported shape): both halves in MFMA fragment order.
+ * se_conv3d_k3_split3_f32: bpack = the folded float32 bias (as se_conv3d_pack_f32 writes it); flags: SE_EPI_RELU,
+ * SE_EPI_RES_PRE_RELU / SE_EPI_RES_POST_RELU, SE_IN_OCTET / SE_OUT_OCTET / SE_RES_OCTET (octet-planar tensors, as for
+ * se_conv3d_f32's 2-D Winograd shapes).  SE_ERR_BAD_ARG for anything else (nothing launched).                                 */
+long long se_conv3d_split3_packed_elems(int cout, int cin_pad);
+int se_conv3d_split3_pack(const float* w, se_bf16* wsplit, int cout, int cin, int cin_pad, void* stream);
+int se_conv3d_k3_split3_f32(const float* in, const se_bf16* wsplit, const float* bpack, const float* residual, float* out,
+                            int batch, int dim, int cin_pad, int cout, int flags, void* stream);
 
 /* Conv3d k = 1, 3 or 7 + folded BN + epilogue (flags as se_conv3d_f32; SE_EPI_OUT_PLANAR is not supported: the
  * float32 planar logits come from se_pointwise_chain3_bf16).  in [B][D]^3[cin_pad] -> out [B][D]^3[cout].

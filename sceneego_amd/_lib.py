@@ -62,7 +62,9 @@ SIGNATURES = {
     "se_preprocess_image_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "se_bias_act_nchw_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_conv3d_f32_algo": (_i, [_i, _i, _i, _i]),
-    "se_conv3d_k3_split3_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_conv3d_split3_packed_elems": (_ll, [_i, _i]),
+    "se_conv3d_split3_pack": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "se_conv3d_k3_split3_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
 # present only in development builds (csrc/build.sh --devtools): A/B kernel selection and cycle-stamp diagnostics (tools/)
 DEVTOOLS_SIGNATURES = {
@@ -371,14 +373,27 @@ def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksi
         _prof.append((("conv3d" if inp.dtype == torch.float32 else "conv3d_bf16", ksize, cin_pad, cout, dim), e0, e1))
 
 
-def conv3d_k3_split3(inp, wpack_hi, wpack_lo, bpack, residual, out, batch, dim, cin_pad, cout, flags):
-    """EXPERIMENTAL: 3x3x3 convolution on float32 channels-last tensors with split-bf16 arithmetic (se_conv3d_k3_split3_f32)."""
-    require_hip(inp, out, wpack_hi, wpack_lo, bpack)
+def conv3d_split3_pack(w_folded, cout, cin, cin_pad):
+    """EXPERIMENTAL: float32 [cout][cin][3][3][3] weights (BatchNorm scale folded in) -> the split-bf16 kernel's packed (hi, lo) halves."""
+    require_hip(w_folded)
+    _chk_f32(w_folded)
+    n = int(load().se_conv3d_split3_packed_elems(cout, cin_pad))
+    if n <= 0:
+        raise HipExtensionError(f"split-bf16 convolution does not cover cout={cout} cin_pad={cin_pad}")
+    out = torch.empty(n, device=w_folded.device, dtype=torch.bfloat16)
+    _check(load().se_conv3d_split3_pack(_ptr(w_folded), _ptr(out), cout, cin, cin_pad, _stream()), "se_conv3d_split3_pack")
+    return out
+
+
+def conv3d_k3_split3(inp, wsplit, bpack, residual, out, batch, dim, cin_pad, cout, flags):
+    """EXPERIMENTAL: 3x3x3 convolution on float32 tensors (channels-last, or octet-planar per IN_/OUT_/RES_OCTET) with split-bf16
+    arithmetic (se_conv3d_k3_split3_f32)."""
+    require_hip(inp, out, wsplit, bpack)
     _chk_f32(inp, out, bpack, residual)
-    assert wpack_hi.dtype == torch.bfloat16 and wpack_lo.dtype == torch.bfloat16
+    assert wsplit.dtype == torch.bfloat16
     with _timed(("conv3d_split3", 3, cin_pad, cout, dim)):
-        _check(load().se_conv3d_k3_split3_f32(_ptr(inp), _ptr(wpack_hi), _ptr(wpack_lo), _ptr(bpack), _ptr(residual), _ptr(out), batch,
-                                              dim, cin_pad, cout, flags, _stream()), "se_conv3d_k3_split3_f32")
+        _check(load().se_conv3d_k3_split3_f32(_ptr(inp), _ptr(wsplit), _ptr(bpack), _ptr(residual), _ptr(out), batch, dim, cin_pad, cout,
+                                              flags, _stream()), "se_conv3d_k3_split3_f32")
 
 
 def conv3d_skip16(inp, wpack, bpack_sum, skip_in, skip_w, out, batch, dim, cin, cout, flags):

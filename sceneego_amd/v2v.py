@@ -156,7 +156,7 @@ def channels_last_to_octet_planar(x):
 # the launch program
 # ------------------------------------------------------------------------------------------------
 class _PackedConv:
-    __slots__ = ("w", "b", "cin", "cin_pad", "cout", "k", "transposed", "fused", "w_hi", "w_lo")
+    __slots__ = ("w", "b", "cin", "cin_pad", "cout", "k", "transposed", "fused", "w_split")
 
     def __init__(self, conv, bn, cin_pad=None, dtype=torch.float32, scale=1.0, split3=False):
         """``scale``: the packed layer computes scale * conv(x) (weights and bias multiplied before packing).
@@ -192,18 +192,10 @@ class _PackedConv:
         if scale != 1.0 and bias is not None:
             bias = bias * float(scale)
         _lib.conv3d_pack(w, bias, g, be, mu, var, eps, self.w, self.b, cout, cin, self.cin_pad, k, transposed)
-        self.w_hi = self.w_lo = None
-        if split3 and not bf16 and not transposed and k == 3 and cout % 32 == 0 and self.cin_pad % 16 == 0:
+        self.w_split = None
+        if split3 and not bf16 and not transposed and k == 3 and cout % 32 == 0 and self.cin_pad % 8 == 0:
             wf = w if g is None else w * (g / torch.sqrt(var + eps)).view(-1, 1, 1, 1, 1)      # the folding se_conv3d_pack_f32 applies
-            hi = wf.to(torch.bfloat16).float()
-            lo = wf - hi
-            n = _lib.conv3d_packed_elems(cout, self.cin_pad, 3, False, bf16=True)
-            dummy_b = torch.empty(_round16(cout), device=dev, dtype=torch.float32)
-            self.w_hi = torch.empty(n, device=dev, dtype=torch.bfloat16)
-            self.w_lo = torch.empty(n, device=dev, dtype=torch.bfloat16)
-            _lib.conv3d_pack(hi.contiguous(), None, None, None, None, None, 0.0, self.w_hi, dummy_b, cout, cin, self.cin_pad, 3, False)
-            _lib.conv3d_pack(lo.contiguous(), None, None, None, None, None, 0.0, self.w_lo, dummy_b, cout, cin, self.cin_pad, 3, False)
-
+            self.w_split = _lib.conv3d_split3_pack(wf.contiguous(), cout, cin, self.cin_pad)
 
 class V2VProgram:
     def __init__(self, model: V2VModel, dtype=torch.float32, output_scale=1.0, split3=False):
@@ -256,8 +248,8 @@ class V2VProgram:
     def _conv(self, x, pc, B, dim, flags, residual=None, out=None, pool_out=None):
         if out is None:
             out = self._new(B, dim, pc.cout)
-        if self.split3 and pc.w_hi is not None and dim % 16 == 0 and pool_out is None:
-            _lib.conv3d_k3_split3(x, pc.w_hi, pc.w_lo, pc.b, residual, out, B, dim, pc.cin_pad, pc.cout, flags)
+        if self.split3 and pc.w_split is not None and dim % 16 == 0 and pool_out is None:
+            _lib.conv3d_k3_split3(x, pc.w_split, pc.b, residual, out, B, dim, pc.cin_pad, pc.cout, flags)
             return out
         _lib.conv3d(x, pc.w, pc.b, residual, out, B, dim, pc.cin, pc.cin_pad, pc.cout, pc.k, flags, self.workspace, pool_out=pool_out)
         return out
@@ -269,14 +261,13 @@ class V2VProgram:
         convolutions is always octet-planar [B][C/8][D][D][D][8]; ``x_oct`` says the block input is, ``out_oct`` asks for an
         octet-planar block output (4x fewer cache lines per halo load of the reader; see run() for who reads what)."""
         c1, c2, sk = blk
-        w2d = (self.dtype == torch.float32 and not self.split3 and _lib.conv3d_algo(dim, c1.cin_pad, c1.cout, 3) == 2
-               and _lib.conv3d_algo(dim, c2.cin_pad, c2.cout, 3) == 2)
+        w2d = self._oct_ok(blk, dim)       # both convolutions take the octet-planar flags (2-D Winograd, or the split-bf16 kernel)
         assert w2d or not (x_oct or out_oct)
         assert sk is None or not x_oct           # the 1x1x1 skip convolution reads channels-last
         mid = _lib.OUT_OCTET if w2d else 0
         a = self._conv(x, c1, B, dim, _lib.EPI_RELU | mid | (_lib.IN_OCTET if x_oct else 0))
         fused = sk.fused if sk is not None else None
-        if fused is not None and w2d and out_oct and pool_out is None and not x_oct:
+        if fused is not None and w2d and not self.split3 and out_oct and pool_out is None and not x_oct:
             out = torch.empty((B, dim, dim, dim, c2.cout), device=self.device, dtype=self.dtype)
             _lib.conv3d_skip16(a, c2.w, fused[1], x, fused[0], out, B, dim, c2.cin, c2.cout, _lib.EPI_RELU | _lib.IN_OCTET | _lib.OUT_OCTET)
             return out
@@ -290,8 +281,11 @@ class V2VProgram:
 
     def _oct_ok(self, blk, dim):
         c1, c2, _ = blk
-        return (self.dtype == torch.float32 and not self.split3 and _lib.conv3d_algo(dim, c1.cin_pad, c1.cout, 3) == 2
-                and _lib.conv3d_algo(dim, c2.cin_pad, c2.cout, 3) == 2)
+        if self.dtype != torch.float32:
+            return False
+        if self.split3:
+            return c1.w_split is not None and c2.w_split is not None and dim % 16 == 0
+        return _lib.conv3d_algo(dim, c1.cin_pad, c1.cout, 3) == 2 and _lib.conv3d_algo(dim, c2.cin_pad, c2.cout, 3) == 2
 
     def _pool(self, x, B, dim, c, x_oct=False):
         out = self._new(B, dim // 2, c)
@@ -328,7 +322,7 @@ class V2VProgram:
         pooled = None
         for i, blk in enumerate(self.front_res):
             ok = self._oct_ok(blk, G)
-            if ok and i == len(self.front_res) - 1:
+            if ok and not self.split3 and i == len(self.front_res) - 1:      # (the split-bf16 kernel has no pooled form)
                 pooled = self._new(B, G // 2, blk[1].cout)
             x = self._res(x, blk, B, G, x_oct=x_oct, out_oct=ok, pool_out=pooled)
             x_oct = ok
@@ -341,7 +335,7 @@ class V2VProgram:
             pooled = None
             dim //= 2
             ok = self._oct_ok(self.enc[k], dim)
-            if ok and k < 4:
+            if ok and not self.split3 and k < 4:
                 pooled = self._new(B, dim // 2, self.enc[k][1].cout)
             x = self._res(x, self.enc[k], B, dim, x_oct=False, out_oct=ok, pool_out=pooled)
             x_oct = ok

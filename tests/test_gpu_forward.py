@@ -170,7 +170,7 @@ def test_forward_split_bf16_mode_vs_goldens(golden, golden_meta):
         img, depth = synth.make_inputs(m["input_seed"], m["batch"], m["depth_kind"])
         kp, _, vols, _ = _forward(net, img, depth)
         prog = net.volume_net.program
-        assert prog.split3 and prog.dtype == torch.float32 and prog.front_res[1][0].w_hi is not None
+        assert prog.split3 and prog.dtype == torch.float32 and prog.front_res[1][0].w_split is not None
         err = float(np.abs(kp.cpu().numpy() - g["joints"]).max())
         print(f"split_bf16 mode, {case}: joints vs reference golden {err:.2e} m")
         assert err <= JOINT_TOL, err

@@ -231,10 +231,10 @@ def test_conv3d_split_bf16_vs_torch(B, dim, cin, cout, relu, residual):
         if relu:
             want = F.relu(want)
     pc = _PackedConv(conv.to(DEV), bnm.to(DEV), split3=True)
-    assert pc.w_hi is not None and pc.w_hi.dtype == torch.bfloat16
+    assert pc.w_split is not None and pc.w_split.dtype == torch.bfloat16
     out = torch.full((B, dim, dim, dim, cout), -77.0, device=DEV)
     flags = (_lib.EPI_RELU if relu else 0) | (_lib.EPI_RES_PRE_RELU if residual else 0)
-    _lib.conv3d_k3_split3(_ndhwc(x).to(DEV), pc.w_hi, pc.w_lo, pc.b, _ndhwc(res).to(DEV) if residual else None, out, B, dim, pc.cin_pad,
+    _lib.conv3d_k3_split3(_ndhwc(x).to(DEV), pc.w_split, pc.b, _ndhwc(res).to(DEV) if residual else None, out, B, dim, pc.cin_pad,
                           cout, flags)
     got = _ncdhw(out.cpu())
     err = float((got - want).abs().max())
@@ -245,6 +245,18 @@ def test_conv3d_split_bf16_vs_torch(B, dim, cin, cout, relu, residual):
     out32 = torch.empty_like(out)
     _lib.conv3d(_ndhwc(x).to(DEV), pc.w, pc.b, _ndhwc(res).to(DEV) if residual else None, out32, B, dim, cin, pc.cin_pad, cout, 3, flags, None)
     assert float((out - out32).abs().max()) < 1e-4 * scale
+    # octet-planar forms (SE_IN_OCTET / SE_OUT_OCTET / SE_RES_OCTET): same arithmetic in the same order -> bit-identical
+    to_oct = lambda t, c: t.view(B, dim, dim, dim, c // 8, 8).permute(0, 4, 1, 2, 3, 5).contiguous()
+    from_oct = lambda t, c: t.permute(0, 2, 3, 4, 1, 5).reshape(B, dim, dim, dim, c)
+    xin = torch.zeros(B, dim, dim, dim, pc.cin_pad, device=DEV)
+    xin[..., :cin] = _ndhwc(x).to(DEV)
+    res_cl = _ndhwc(res).to(DEV) if residual else None
+    for fl in (_lib.IN_OCTET, _lib.OUT_OCTET, _lib.IN_OCTET | _lib.OUT_OCTET | (_lib.RES_OCTET if residual else 0)):
+        o = torch.full((B, cout // 8, dim, dim, dim, 8) if fl & _lib.OUT_OCTET else (B, dim, dim, dim, cout), -77.0, device=DEV)
+        _lib.conv3d_k3_split3(to_oct(xin, pc.cin_pad) if fl & _lib.IN_OCTET else xin, pc.w_split, pc.b,
+                              (to_oct(res_cl, cout) if fl & _lib.RES_OCTET else res_cl) if residual else None, o, B, dim, pc.cin_pad, cout,
+                              flags | fl)
+        assert torch.equal(from_oct(o, cout) if fl & _lib.OUT_OCTET else o, out), fl
 
 
 def test_conv3d_split_bf16_refuses_unsupported_shapes():
@@ -252,11 +264,12 @@ def test_conv3d_split_bf16_refuses_unsupported_shapes():
     import ctypes
     p = ctypes.c_void_p(t.data_ptr())
     lib = _lib.load()
-    assert lib.se_conv3d_k3_split3_f32(p, p, p, p, None, p, 1, 8, 32, 32, 0, None) == -1      # dim % 16
-    assert lib.se_conv3d_k3_split3_f32(p, p, p, p, None, p, 1, 16, 24, 32, 0, None) == -1     # cin_pad % 16
-    assert lib.se_conv3d_k3_split3_f32(p, p, p, p, None, p, 1, 16, 32, 16, 0, None) == -1     # cout % 32
-    assert lib.se_conv3d_k3_split3_f32(p, p, p, p, None, p, 1, 16, 32, 32, _lib.IN_OCTET, None) == -1
-    assert lib.se_conv3d_k3_split3_f32(p, None, p, p, None, p, 1, 16, 32, 32, 0, None) == -1
+    assert lib.se_conv3d_k3_split3_f32(p, p, p, None, p, 1, 8, 32, 32, 0, None) == -1      # dim % 16
+    assert lib.se_conv3d_k3_split3_f32(p, p, p, None, p, 1, 16, 20, 32, 0, None) == -1     # cin_pad % 8
+    assert lib.se_conv3d_k3_split3_f32(p, p, p, None, p, 1, 16, 32, 16, 0, None) == -1     # cout % 32
+    assert lib.se_conv3d_k3_split3_f32(p, p, p, None, p, 1, 16, 32, 32, 256, None) == -1        # unknown flag bit
+    assert lib.se_conv3d_k3_split3_f32(p, None, p, None, p, 1, 16, 32, 32, 0, None) == -1
+    assert lib.se_conv3d_split3_packed_elems(48, 32) == -1 and lib.se_conv3d_split3_packed_elems(32, 32) == 2 * 1 * 4 * 896 * 8
 
 
 def test_conv3d_padded_input_channels_and_planar_output():

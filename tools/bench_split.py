@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--rounds", type=int, default=12)
+    ap.add_argument("--octet", type=int, default=3, help="1 IN_OCTET, 2 OUT_OCTET (both kernels interpret the same buffers alike)")
     args = ap.parse_args()
     dev = "cuda:0"
     _lib.load()
@@ -31,7 +32,7 @@ def main():
         res = torch.randn(B, dim, dim, dim, cout, device=dev)
         o32 = torch.empty_like(res)
         osp = torch.empty_like(res)
-        flags = _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU
+        flags = _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | (_lib.IN_OCTET if args.octet & 1 else 0) | (_lib.OUT_OCTET if args.octet & 2 else 0)
         t32, tsp = [], []
         for r in range(args.rounds + 2):
             for which in (0, 1):
@@ -40,7 +41,7 @@ def main():
                 if which == 0:
                     _lib.conv3d(x, pc.w, pc.b, res, o32, B, dim, cin, pc.cin_pad, cout, 3, flags, None)
                 else:
-                    _lib.conv3d_k3_split3(x, pc.w_hi, pc.w_lo, pc.b, res, osp, B, dim, pc.cin_pad, cout, flags)
+                    _lib.conv3d_k3_split3(x, pc.w_split, pc.b, res, osp, B, dim, pc.cin_pad, cout, flags)
                 e1.record()
                 torch.cuda.synchronize()
                 if r >= 2:
@@ -49,7 +50,7 @@ def main():
         flop = 2.0 * B * dim ** 3 * 27 * cin * cout
         nbytes = 4.0 * B * dim ** 3 * (cin + 2 * cout)
         d = float((o32 - osp).abs().max() / o32.abs().max())
-        print(f"3x3x3 {cin:3d}->{cout:3d} @{dim}^3 B={B}: f32 Winograd (channels-last) med {t32[len(t32) // 2]:.4f} ms | split-bf16 med {tsp[len(tsp) // 2]:.4f} ms "
+        print(f"3x3x3 {cin:3d}->{cout:3d} @{dim}^3 B={B}: f32 Winograd med {t32[len(t32) // 2]:.4f} ms | split-bf16 med {tsp[len(tsp) // 2]:.4f} ms "
               f"min {tsp[0]:.4f} = {flop / tsp[len(tsp) // 2] / 1e9:.0f} TF/s direct-equivalent ({3 * flop / tsp[len(tsp) // 2] / 1e9:.0f} executed bf16 TF/s), "
               f"{nbytes / tsp[len(tsp) // 2] / 1e6:.0f} GB/s algorithmic; max|diff| / max|y| {d:.1e}", flush=True)
 
