@@ -21,6 +21,7 @@
 
 #include "conv_common.h"
 #include "wino47_matrices.h"
+#include "wino67_matrices.h"
 
 namespace {
 
@@ -179,6 +180,35 @@ __global__ void pack_k7f_kernel(const float* __restrict__ w, const float* __rest
         float u = 0.f;
 #pragma unroll
         for (int kz = 0; kz < 7; ++kz) u += SE_W47_G[xi][kz] * wp[kz * 49];
+        v = u * sc;
+    }
+    out[t] = v;
+}
+
+// Section H (k = 7, cout <= 16): 1-D Winograd F(6,7) along z for conv3d_wino67.hip.  U_xi = sum_kz G[xi][kz] * W[..][kz][dy][dx]
+// (G: wino67_matrices.h).  Per 3-channel chunk the 147 (channel, dy, dx) taps are taken 4 at a time on the MFMA k lanes: k lane h of
+// group g carries slot 4g+h = (channel * 49 + dy * 7 + dx), slot 147 is zero padding; a lane's 12 xi are 48 contiguous bytes:
+//   [chunk3][g(37)][lane][xi 0..11]
+__global__ void pack_k7h_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
+                                float eps, float* __restrict__ out, int cout, int cin, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int chunk = (int)(t / SE_K7H_CHUNK_FLOATS);
+    int r = (int)(t - (long long)chunk * SE_K7H_CHUNK_FLOATS);
+    const int g = r / 768;
+    r -= g * 768;
+    const int lane = r / 12, xi = r - lane * 12;
+    const int slot = 4 * g + (lane >> 4);
+    const int cl = slot / 49, tap2d = slot - cl * 49;
+    const int cc = chunk * 3 + cl;
+    const int co = lane & 15;
+    float v = 0.f;
+    if (co < cout && cc < cin && slot < 147) {
+        const float sc = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
+        const float* wp = w + ((size_t)co * cin + cc) * 343 + tap2d;
+        float u = 0.f;
+#pragma unroll
+        for (int kz = 0; kz < 7; ++kz) u += SE_W67_G[xi][kz] * wp[kz * 49];
         v = u * sc;
     }
     out[t] = v;
@@ -838,7 +868,7 @@ int launch_direct(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int se_abi_version(void) { return 9; }
+extern "C" int se_abi_version(void) { return 10; }
 
 // Mirrors the dispatch of se_conv3d_f32 -> se_conv3d_tiled_try -> se_conv3d_wino_try / se_conv3d_k7_wino_try for the
 // default channels-last call (no SE_EPI_OUT_PLANAR / SE_EPI_RES_POST_RELU flags).
@@ -858,7 +888,7 @@ extern "C" long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, in
     long long n = packed_elems_a(cout, cin_pad, ksize, transposed);
     if (!transposed && ksize == 7) n += (long long)(cin_pad / 4) * SE_K7_GROUPS * (round_up16(cout) / 16) * 256;
     if (!transposed && ksize == 7 && cout <= 16) n += (long long)(cin_pad / 4) * SE_K7W_CHUNK_FLOATS;
-    if (!transposed && ksize == 7 && cout <= 16) n += (long long)((cin_pad + 2) / 3) * SE_K7F_CHUNK_FLOATS;     // section F (last)
+    if (!transposed && ksize == 7 && cout <= 16) n += (long long)((cin_pad + 2) / 3) * (SE_K7F_CHUNK_FLOATS + SE_K7H_CHUNK_FLOATS);     // sections F, H (last)
     if (!transposed && ksize == 3 && cout % 32 == 0)
         n += (long long)(cin_pad / 16) * (cout / 32) * (SE_WINO_CHUNK_FLOATS + SE_WINO43_CHUNK_FLOATS);
     if (!transposed && ksize == 3 && cout % 32 == 0) n += (long long)(cin_pad / 8) * (cout / 32) * SE_WINO2D_CHUNK_FLOATS;   // section G (last)
@@ -882,7 +912,7 @@ extern "C" int se_conv3d_pack_f32(const float* w, const float* b, const float* g
     const long long total_a = packed_elems_a(cout, cin_pad, ksize, transposed);
     const long long threads = total > round_up16(cout) ? total : round_up16(cout);
     long long total_main = total;
-    if (!transposed && ksize == 7 && cout <= 16) total_main -= (long long)((cin_pad + 2) / 3) * SE_K7F_CHUNK_FLOATS;
+    if (!transposed && ksize == 7 && cout <= 16) total_main -= (long long)((cin_pad + 2) / 3) * (SE_K7F_CHUNK_FLOATS + SE_K7H_CHUNK_FLOATS);
     const long long n_g = (!transposed && ksize == 3 && cout % 32 == 0) ? (long long)(cin_pad / 8) * (cout / 32) * SE_WINO2D_CHUNK_FLOATS : 0;
     total_main -= n_g;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, se_stream(stream), w, b,
@@ -890,9 +920,12 @@ extern "C" int se_conv3d_pack_f32(const float* w, const float* b, const float* g
     SE_CHECK_LAUNCH();
     if (n_g) return se_conv3d_pack_wino2d(w, gamma, var, eps, wpack + total_main, cout, cin, cin_pad, se_stream(stream));
     if (total_main != total) {
-        const long long nf = total - total_main;
+        const long long nf = (long long)((cin_pad + 2) / 3) * SE_K7F_CHUNK_FLOATS, nh = total - total_main - nf;
         hipLaunchKernelGGL(pack_k7f_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, se_stream(stream), w, gamma, var, eps,
                            wpack + total_main, cout, cin, nf);
+        SE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(pack_k7h_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, se_stream(stream), w, gamma, var, eps,
+                           wpack + total_main + nf, cout, cin, nh);
         SE_CHECK_LAUNCH();
     }
     return 0;
@@ -923,6 +956,8 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
         a.wpack_d = a.wpack_b + (long long)(cin_pad / 4) * SE_K7_GROUPS * (round_up16(cout) / 16) * 256;
     a.wpack_f = nullptr;
     if (ksize == 7 && cout <= 16) a.wpack_f = a.wpack_d + (long long)(cin_pad / 4) * SE_K7W_CHUNK_FLOATS;
+    a.wpack_h = nullptr;
+    if (ksize == 7 && cout <= 16) a.wpack_h = a.wpack_f + (long long)((cin_pad + 2) / 3) * SE_K7F_CHUNK_FLOATS;
     a.wpack_e = nullptr;
     if (ksize == 3 && cout % 32 == 0) a.wpack_e = a.wpack_b + (long long)(cin_pad / 16) * (cout / 32) * SE_WINO_CHUNK_FLOATS;
     a.wpack_g = nullptr;

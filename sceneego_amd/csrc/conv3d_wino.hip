@@ -25,6 +25,7 @@
 // F(4,7) 7^3 kernel, one translation unit per input layout (conv3d_wino47.hip compiled with -DSE_K7F_PLANAR=0 / 1)
 int se_conv3d_k7_wino47_launch_cl(const ConvArgs& a, int batch, int num_cus, hipStream_t s, unsigned long long* dbg);
 int se_conv3d_k7_wino47_launch_p3(const ConvArgs& a, int batch, int num_cus, hipStream_t s, unsigned long long* dbg);
+int se_conv3d_k7_wino67_launch(const ConvArgs& a, int batch, int num_cus, hipStream_t s);   // conv3d_wino67.hip
 
 namespace {
 
@@ -459,6 +460,15 @@ int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
         return 0;
     }
 #endif
+    // dim % 16 == 0: the tile-outer F(6,7) kernel (conv3d_wino67.hip); development builds keep the F(4,7) kernel selectable (variant 47)
+    if (a.wpack_h && (dim & 15) == 0
+#ifdef SE_DEVTOOLS
+        && g_variant != 47
+#endif
+    ) {
+        const int rc67 = se_conv3d_k7_wino67_launch(a, batch, num_cus, s);
+        if (rc67 != SE_TILED_NOT_TAKEN) return rc67;
+    }
     const int rc = (a.flags & SE_IN_PLANAR3) ? se_conv3d_k7_wino47_launch_p3(a, batch, num_cus, s, g_wino_dbg43)
                                              : se_conv3d_k7_wino47_launch_cl(a, batch, num_cus, s, g_wino_dbg43);
     if (rc == SE_TILED_NOT_TAKEN && (a.flags & SE_IN_PLANAR3)) return SE_ERR_BAD_ARG;   // cannot happen behind the unit-budget batch slices

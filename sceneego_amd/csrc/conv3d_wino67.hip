@@ -1,0 +1,317 @@
+// 7x7x7 convolution (V2V front layer, cout = 16) with the 1-D Winograd transform F(6,7) along z on the f32 MFMA, tile-outer:
+// 12 multiplies per 6 z-neighbouring outputs (F(4,7): 10 per 4, direct: 42), ALL input channels of a tile accumulated in registers,
+// the output written once.  Replaces Basic3DBlock(33, 16, 7) of network/v2v.py:75-77 (conv + folded BN + ReLU) for volumes with
+// dim % 16 == 0; conv3d_wino47.hip (F(4,7), chunk-outer, partial sums through the output tensor: 10x the algorithmic HBM bytes)
+// keeps the other shapes.  Points {0, +-1, +-3/4, +-3/2, +-1/3, +-5/2, inf} (tools/wino67_matrices.py -> wino67_matrices.h); float32
+// error of the transform on N(0,1) data: 7.3e-6 mean per 7-tap dot product (F(4,7): 3.6e-6).
+//
+// Work unit = 6(z) x 8(y) x 16(x) output tile, one persistent 512-thread workgroup per CU, wave w = row y of the tile, the 16 MFMA
+// columns = the 16 x of that row.  An item = (tile, 3-channel chunk): the 147 (channel, dy, dx) taps of the chunk sit 4 at a time on
+// the MFMA k lanes (37 groups, one pad slot), each group is 12 MFMAs (one per xi) from 3 + 3 ds_read_b128:
+//   weights  [g(37)][lane][12 xi]            (section H of the packed weights; lane stride 48 B)                        113,664 B
+//   inputs   [channel(3)][column(14 x 22)][12 xi]   (B^T applied when the halo is committed; column stride 48 B)         44,352 B
+// 48-byte strides: a 16-lane ds_read_b128 group hits 16 distinct 4-bank groups.  A^T is applied after every item and the six
+// output-domain sums of a wave live in registers over all chunks of a tile; bias, ReLU and the only store happen once per tile.
+//
+// Weight stream: the LDS holds ONE chunk of weights, refilled in two regions while the other one is being read - region B (groups
+// 19..36) of the CURRENT chunk during the first 19 groups of an item, region A (groups 0..18) of the NEXT chunk during the last 18;
+// a workgroup barrier between the two halves and one at the end of the item order this.  The refill (8 + 8 16-byte loads and LDS
+// writes per thread) and the 12 halo loads of the next item ride inside the MFMA stream; L2 serves the 113 KB per item.
+#include "conv_common.h"
+#include "wino67_matrices.h"
+
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+template <typename F, int... S>
+__device__ __forceinline__ void for_each_index(F&& f, std::integer_sequence<int, S...>) {
+    (f(std::integral_constant<int, S>{}), ...);
+}
+
+constexpr int S_TZ = 6, S_TY = 8, S_TX = 16;
+constexpr int S_HY = S_TY + 6, S_HX = S_TX + 6, S_COLS = S_HY * S_HX;          // 308 halo columns, 12 raw slabs each
+constexpr int S_XI = 12;
+constexpr int S_G = SE_K7H_GROUPS;                                             // 37 k groups per chunk
+constexpr int S_GA = 19;                                                       // weight region A = groups 0..18, region B = 19..36
+constexpr int S_W_FLOATS = SE_K7H_CHUNK_FLOATS;                                // 28416
+constexpr int S_WA_F4 = S_GA * 64 * 3;                                         // 3648 16-byte pieces
+constexpr int S_WB_F4 = (S_G - S_GA) * 64 * 3;                                 // 3456
+constexpr int S_CS = S_COLS * S_XI;                                            // channel stride of the transformed tile (floats)
+constexpr int S_VT_FLOATS = 3 * S_CS;                                          // 11088
+constexpr int S_DUMMY_FLOATS = 256;                                            // one 16-byte slot per lane for masked rider writes
+constexpr int S_LDS_FIXED = (S_W_FLOATS + S_VT_FLOATS + S_DUMMY_FLOATS) * 4;   // 159,040 B
+
+struct f32x3 { float x, y, z; };
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct K7SOps { f32x4 a0, a1, a2, b0, b1, b2; };    // 12 xi of weights (A) and of transformed inputs (B) for one k group
+
+template <bool PLANAR>
+__global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int tiles_x, int tiles_y, int tiles_z, int total_tiles,
+                                                               int units_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;
+    float* vt = lds + S_W_FLOATS;
+    float* dummy = vt + S_VT_FLOATS;
+    i32x4* utab = reinterpret_cast<i32x4*>(dummy + S_DUMMY_FLOATS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int vl = lane & 15;
+    const int h = lane >> 4;
+    const int dim = a.dim;
+    const int chunks = (a.cin + 2) / 3;
+    const int u_begin = (int)blockIdx.x * units_per_wg;
+    const int u_end = min(u_begin + units_per_wg, total_tiles);
+    if (u_begin >= u_end) return;
+    const int n = u_end - u_begin;
+
+    for (int i = tid; i < n; i += 512) {
+        int t = u_begin + i;
+        i32x4 e;
+        e.w = t % tiles_x; t /= tiles_x;
+        e.z = t % tiles_y; t /= tiles_y;
+        e.y = t % tiles_z; t /= tiles_z;
+        e.x = t;
+        utab[i] = e;
+    }
+
+    // compute role: per-lane LDS offsets (floats) of the 37 k groups: slot 4g+h -> (channel, dy, dx)
+    int toff[S_G];
+#pragma unroll
+    for (int g = 0; g < S_G; ++g) {
+        int slot = 4 * g + h;
+        slot = slot < 147 ? slot : 0;   // zero-weight padding
+        const int cl = slot / 49, tap = slot - cl * 49;
+        toff[g] = cl * S_CS + ((wave + tap / 7) * S_HX + vl + tap % 7) * S_XI;
+    }
+
+    // staging role: thread t < 308 owns halo column t: 12 raw slabs x 3 channels -> 12 transformed slabs x 3 channels
+    const bool s_on = tid < S_COLS;
+    const int s_col = s_on ? tid : 0;
+    const int s_cy = s_col / S_HX, s_cx = s_col - s_cy * S_HX;
+    f32x3 raw[S_XI];
+    const long long f_zs = (long long)dim * dim * (PLANAR ? 3 : a.cin_pad);
+    auto fetch = [&](int k, int c) {   // out-of-volume taps load the buffer's first record (one cache line for all of them) and are zeroed
+        const i32x4 e = utab[k];
+        const int gy = e.z * S_TY - 3 + s_cy, gx = e.w * S_TX - 3 + s_cx;
+        const int gz0 = e.y * S_TZ - 3;
+        const bool okc = s_on && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim;
+        // channels-last: a chunk whose third channel lies past the record (cin_pad == 3 c + 2) is read one float earlier
+        const bool shift = !PLANAR && (c * 3 + 2 >= a.cin_pad);
+        const long long base = PLANAR ? ((((long long)e.x * chunks + c) * dim * dim + gy) * dim + gx) * 3
+                                      : ((((long long)e.x * dim) * dim + gy) * dim + gx) * a.cin_pad + c * 3 - (shift ? 1 : 0);
+#pragma unroll
+        for (int q = 0; q < S_XI; ++q) {
+            const bool ok = okc && (unsigned)(gz0 + q) < (unsigned)dim;
+            const f32x3 t = *reinterpret_cast<const f32x3*>(a.in + (ok ? base + (gz0 + q) * f_zs : (shift ? 1 : 0)));
+            if (PLANAR) {
+                raw[q].x = ok ? t.x : 0.f; raw[q].y = ok ? t.y : 0.f; raw[q].z = ok ? t.z : 0.f;
+            } else {
+                raw[q].x = ok ? (shift ? t.y : t.x) : 0.f; raw[q].y = ok ? (shift ? t.z : t.y) : 0.f; raw[q].z = (ok && !shift) ? t.z : 0.f;
+            }
+        }
+    };
+    auto commit = [&]() {   // V = B^T d per channel: row 0 even q, row 11 odd q, rows 2k+1 / 2k+2 = even part +- odd part; 16-byte stores
+        if (!s_on) return;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float d[S_XI];
+#pragma unroll
+            for (int q = 0; q < S_XI; ++q) d[q] = j == 0 ? raw[q].x : j == 1 ? raw[q].y : raw[q].z;
+            float o[S_XI];
+            float r0 = 0.f, r11 = 0.f;
+#pragma unroll
+            for (int q = 0; q < S_XI; ++q) {
+                if (SE_W67_BT[0][q] != 0.f) r0 += SE_W67_BT[0][q] * d[q];
+                if (SE_W67_BT[11][q] != 0.f) r11 += SE_W67_BT[11][q] * d[q];
+            }
+            o[0] = r0; o[11] = r11;
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                const int xi = 2 * p + 1;
+                float ev = 0.f, od = 0.f;
+#pragma unroll
+                for (int q = 1; q < 11; ++q) {
+                    const float cf = SE_W67_BT[xi][q];
+                    if (q & 1) od += cf * d[q]; else ev += cf * d[q];
+                }
+                o[xi] = ev + od; o[xi + 1] = ev - od;
+            }
+            f32x4* dst = reinterpret_cast<f32x4*>(vt + j * S_CS + s_col * S_XI);
+            dst[0] = (f32x4){o[0], o[1], o[2], o[3]};
+            dst[1] = (f32x4){o[4], o[5], o[6], o[7]};
+            dst[2] = (f32x4){o[8], o[9], o[10], o[11]};
+        }
+    };
+
+    // weight refill riders: batch of up to four 16-byte pieces per thread in flight
+    f32x4 wb[4];
+    auto wload = [&](const float* src, auto count_tag, auto j0_tag, auto n_tag) {
+        constexpr int COUNT = decltype(count_tag)::value, J0 = decltype(j0_tag)::value, N = decltype(n_tag)::value;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = (J0 + i) * 512 + tid;
+            wb[i] = reinterpret_cast<const f32x4*>(src)[((J0 + i + 1) * 512 <= COUNT || idx < COUNT) ? idx : 0];
+        }
+    };
+    auto wwrite = [&](float* region, auto count_tag, auto j0_tag, auto n_tag) {
+        constexpr int COUNT = decltype(count_tag)::value, J0 = decltype(j0_tag)::value, N = decltype(n_tag)::value;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = (J0 + i) * 512 + tid;
+            f32x4* d = ((J0 + i + 1) * 512 <= COUNT || idx < COUNT) ? reinterpret_cast<f32x4*>(region) + idx : reinterpret_cast<f32x4*>(dummy) + lane;
+            *d = wb[i];
+        }
+    };
+    using CA = std::integral_constant<int, S_WA_F4>;
+    using CB = std::integral_constant<int, S_WB_F4>;
+
+    auto lds_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const bool relu = a.flags & SE_EPI_RELU;
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + 4 * h);
+
+    __syncthreads();   // utab
+    fetch(0, 0);
+    commit();
+    for (int i = tid; i < S_WA_F4; i += 512) reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(a.wpack_h)[i];   // region A of chunk 0
+    __syncthreads();
+
+    auto read_ops = [&](K7SOps& r, auto g_tag) {
+        constexpr int g = decltype(g_tag)::value;
+        const f32x4* ap = reinterpret_cast<const f32x4*>(wl + g * 768 + lane * 12);
+        const f32x4* bp = reinterpret_cast<const f32x4*>(vt + toff[g]);
+        r.a0 = ap[0]; r.a1 = ap[1]; r.a2 = ap[2];
+        r.b0 = bp[0]; r.b1 = bp[1]; r.b2 = bp[2];
+    };
+
+    f32x4 acc[S_XI];
+    f32x4 y[S_TZ];
+#pragma unroll
+    for (int i = 0; i < S_TZ; ++i) y[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int n_items = chunks * n;
+    int k = 0, c = 0;
+    for (int item = 0; item < n_items; ++item) {
+        const bool has_next = item + 1 < n_items;
+        const bool last_chunk = c == chunks - 1;
+        const int c_next = has_next ? (last_chunk ? 0 : c + 1) : c;
+        const int k_next = has_next ? (last_chunk ? k + 1 : k) : k;
+        const float* w_cur_b = a.wpack_h + (size_t)c * S_W_FLOATS + S_GA * 768;     // region B of this chunk
+        const float* w_next_a = a.wpack_h + (size_t)c_next * S_W_FLOATS;            // region A of the next item's chunk
+
+        K7SOps cur, nxt;
+        read_ops(cur, std::integral_constant<int, 0>{});
+        nxt = cur;
+        auto step = [&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            using I0 = std::integral_constant<int, 0>;
+            using I3 = std::integral_constant<int, 3>;
+            using I4 = std::integral_constant<int, 4>;
+            // first half: region B of this chunk (7 pieces per thread) and the next item's raw halo columns
+            if constexpr (g == 1) wload(w_cur_b, CB{}, I0{}, I4{});
+            if constexpr (g == 2) fetch(k_next, c_next);
+            if constexpr (g == 7) { wwrite(wl + S_GA * 768, CB{}, I0{}, I4{}); wload(w_cur_b, CB{}, I4{}, I3{}); }
+            if constexpr (g == 12) wwrite(wl + S_GA * 768, CB{}, I4{}, I3{});
+            // second half: region A of the next item's chunk (8 pieces per thread)
+            if constexpr (g == S_GA + 1) wload(w_next_a, CA{}, I0{}, I4{});
+            if constexpr (g == S_GA + 6) { wwrite(wl, CA{}, I0{}, I4{}); wload(w_next_a, CA{}, I4{}, I4{}); }
+            if constexpr (g == S_GA + 11) wwrite(wl, CA{}, I4{}, I4{});
+
+            constexpr bool pipelined = g + 1 < S_G && g + 1 != S_GA;     // the first read of region B waits for the mid barrier
+            if constexpr (pipelined) read_ops(nxt, std::integral_constant<int, g + 1>{});
+            const float av[12] = {cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w, cur.a2.x, cur.a2.y, cur.a2.z, cur.a2.w};
+            const float bv[12] = {cur.b0.x, cur.b0.y, cur.b0.z, cur.b0.w, cur.b1.x, cur.b1.y, cur.b1.z, cur.b1.w, cur.b2.x, cur.b2.y, cur.b2.z, cur.b2.w};
+            // group 0 starts the item's accumulators from the MFMA's zero C operand (no v_mov per item)
+#pragma unroll
+            for (int x = 0; x < S_XI; ++x)
+                acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x], bv[x], g == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[x], 0, 0, 0);
+            if constexpr (pipelined) {   // spread the next group's reads between this group's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            }
+            if constexpr (g + 1 == S_GA) {   // everybody is past region A; region B of this chunk is complete
+                lds_barrier();
+                read_ops(nxt, std::integral_constant<int, S_GA>{});
+            }
+            cur = nxt;
+        };
+        for_each_index(step, std::make_integer_sequence<int, S_G>{});
+
+        // A^T (6 x 12; xi 1..10 in +- pairs) after EVERY item, summed in the output domain: the rounding error of a Winograd-domain
+        // accumulator is amplified by A^T (|A^T| <= 98), so the sums that live across chunks are the six outputs, not the twelve xi
+        // (float32 model, error / std of the output: 1.2e-5 mean with one A^T per tile, 4.3e-6 per chunk; F(4,7) per chunk: 2.5e-6)
+        {
+            f32x4 s[5], d[5];
+#pragma unroll
+            for (int p = 0; p < 5; ++p) { s[p] = acc[2 * p + 1] + acc[2 * p + 2]; d[p] = acc[2 * p + 1] - acc[2 * p + 2]; }
+#pragma unroll
+            for (int i = 0; i < S_TZ; ++i) {
+                f32x4 v = y[i];
+                if (i == 0) v += acc[0];
+                if (i == S_TZ - 1) v += acc[11];
+#pragma unroll
+                for (int p = 0; p < 5; ++p) v += SE_W67_AT[i][2 * p + 1] * ((i & 1) ? d[p] : s[p]);
+                y[i] = v;
+            }
+        }
+        // single transformed tile: every wave must be done reading it before the next item's columns are committed.  Barriers inside
+        // the loop wait for this wave's LDS traffic only (a __syncthreads() would also wait for vmcnt(0))
+        lds_barrier();
+        if (has_next) commit();
+        if (last_chunk) {   // bias, ReLU, the only store of this tile
+            const i32x4 e = utab[k];
+            const int oz0 = e.y * S_TZ, oy = e.z * S_TY + wave, ox = e.w * S_TX + vl;
+            float* op = a.out + ((((long long)e.x * dim + oz0) * dim + oy) * dim + ox) * 16 + 4 * h;
+            const long long zstride = (long long)dim * dim * 16;
+#pragma unroll
+            for (int i = 0; i < S_TZ; ++i) {
+                f32x4 v = y[i] + bias;
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (oz0 + i < dim) *reinterpret_cast<f32x4*>(op + i * zstride) = v;
+                y[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (!has_next) break;
+        lds_barrier();
+        k = k_next; c = c_next;
+    }
+}
+
+}  // namespace
+
+// Returns 0 on launch, SE_TILED_NOT_TAKEN if the shape / unit table is not covered, else a hipError_t.  Preconditions (checked by the
+// caller, se_conv3d_k7_wino_try): ksize 7, cout 16, no residual, channels-last output, a.wpack_h set.
+int se_conv3d_k7_wino67_launch(const ConvArgs& a, int batch, int num_cus, hipStream_t s) {
+    constexpr int LDS_BYTES = 160 * 1024;
+    constexpr int MAX_UNITS = (LDS_BYTES - S_LDS_FIXED) / 16;
+    const int dim = a.dim;
+    if (dim < 16 || (dim & 15)) return SE_TILED_NOT_TAKEN;
+    const int tx = dim / S_TX, ty = dim / S_TY, tz = (dim + S_TZ - 1) / S_TZ;
+    const long long total_ll = (long long)batch * tx * ty * tz;
+    if (total_ll > (1 << 30)) return SE_TILED_NOT_TAKEN;
+    const int total = (int)total_ll;
+    const int grid = total < num_cus ? total : num_cus;
+    const int per = (total + grid - 1) / grid;
+    if (per > MAX_UNITS) return SE_TILED_NOT_TAKEN;
+    if (a.flags & SE_IN_PLANAR3) {
+        SE_ENSURE_LDS(conv3d_k7_wino67_kernel<true>, LDS_BYTES);
+        hipLaunchKernelGGL(conv3d_k7_wino67_kernel<true>, dim3((total + per - 1) / per), dim3(512), LDS_BYTES, s, a, tx, ty, tz, total, per);
+    } else {
+        SE_ENSURE_LDS(conv3d_k7_wino67_kernel<false>, LDS_BYTES);
+        hipLaunchKernelGGL(conv3d_k7_wino67_kernel<false>, dim3((total + per - 1) / per), dim3(512), LDS_BYTES, s, a, tx, ty, tz, total, per);
+    }
+    SE_CHECK_LAUNCH();
+    return 0;
+}

@@ -19,6 +19,10 @@
 // 1-D Winograd F(4,7) section (F) of the packed 7x7x7 weights: per 3-channel chunk 13 (dy,dx) tap groups x 10 xi x 64 lanes x 3
 #define SE_K7F_XI 10
 #define SE_K7F_CHUNK_FLOATS (SE_K7W_GROUPS * SE_K7F_XI * 64 * 3)
+// 1-D Winograd F(6,7) section (H) of the packed 7x7x7 weights (conv3d_wino67.hip): per 3-channel chunk the 147 (channel, dy, dx)
+// taps 4 at a time on the k lanes = 37 groups x 64 lanes x 12 xi
+#define SE_K7H_GROUPS 37
+#define SE_K7H_CHUNK_FLOATS (SE_K7H_GROUPS * 64 * 12)
 
 // G matrix of F(2,7) with interpolation points {0, 1, -1, 2, -2, 1/2, -1/2, inf} (Cook-Toom; tools/wino27_matrices.py):
 // row xi, column kz.  y = A^T [(G g) .* (B^T d)].
@@ -52,6 +56,7 @@ struct ConvArgs {
     const float* wpack_e;  // k = 3, cout % 32 == 0: Winograd F(4,3) section E (else NULL)
     const float* wpack_d;  // k = 7, cout <= 16: Winograd F(2,7) section D [chunk4][g13][xi8][lane][4] (else NULL)
     const float* wpack_f;  // k = 7, cout <= 16: Winograd F(4,7) section F [chunk3][g13][xi10][lane][3] (else NULL)
+    const float* wpack_h;  // k = 7, cout <= 16: Winograd F(6,7) section H [chunk3][g37][lane][xi12] (else NULL)
     const float* wpack_g;  // k = 3, cout % 32 == 0: 2-D Winograd F(4,3) x F(2,3) section G (else NULL)
     const float* skip_w;   // SE_EPI_SKIPCONV16: folded 1x1x1 skip weights [cout][16]; `res` then is the skip convolution's 16-channel input
     float* pool_out;       // 2-D Winograd kernel only: also write max_pool3d(out, 2, 2), channels-last [B][D/2][D/2][D/2][cout] (else NULL)
