@@ -50,7 +50,7 @@ def test_pure_host_entry_points():
     # packed weight sizes: taps * cin_pad/16 * ceil(cout/16) * 256 floats
     assert lib.se_conv3d_packed_elems(32, 32, 3, 0) == 27 * 2 * 2 * 256 + 2 * 9 * 4 * 2 * 256 + 2 * 9 * 6 * 2 * 256 + 4 * 24 * 3 * 2 * 128   # + F(2,3), F(4,3), F(4,3)xF(2,3)
     assert lib.se_conv3d_packed_elems(15, 32, 1, 0) == 1 * 2 * 1 * 256
-    assert lib.se_conv3d_packed_elems(16, 48, 7, 0) == 343 * 3 * 256 + 12 * 86 * 256 + 12 * 13 * 8 * 256 + 16 * 13 * 10 * 64 * 3   # sections A, B, D, F (F(4,7): 3-channel chunks)
+    assert lib.se_conv3d_packed_elems(16, 48, 7, 0) == 343 * 3 * 256 + 12 * 86 * 256 + 12 * 13 * 8 * 256 + 16 * 13 * 10 * 64 * 3 + 16 * 37 * 64 * 12   # sections A, B, D, F (F(4,7): 3-channel chunks), H (F(6,7))
     assert lib.se_conv3d_packed_elems(64, 128, 2, 1) == 8 * 8 * 4 * 256
     assert lib.se_softargmax3d_scratch_elems(30) > 0
 
