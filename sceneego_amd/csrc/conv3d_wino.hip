@@ -25,7 +25,7 @@
 // F(4,7) 7^3 kernel, one translation unit per input layout (conv3d_wino47.hip compiled with -DSE_K7F_PLANAR=0 / 1)
 int se_conv3d_k7_wino47_launch_cl(const ConvArgs& a, int batch, int num_cus, hipStream_t s, unsigned long long* dbg);
 int se_conv3d_k7_wino47_launch_p3(const ConvArgs& a, int batch, int num_cus, hipStream_t s, unsigned long long* dbg);
-int se_conv3d_k7_wino67_launch(const ConvArgs& a, int batch, int num_cus, hipStream_t s);   // conv3d_wino67.hip
+int se_conv3d_k7_wino67_launch(const ConvArgs& a, int batch, int num_cus, hipStream_t s, unsigned long long* dbg);   // conv3d_wino67.hip
 
 namespace {
 
@@ -423,7 +423,7 @@ int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
 #ifdef SE_DEVTOOLS
 // Debug only: device buffer (grid * 8 waves * 4 u64) that makes the Winograd kernel run its STAMP build.
 extern "C" void se_debug_set_stamp_buffer(void* p) {
-#if defined(SE_STAMP43) || defined(SE_STAMPPP) || defined(SE_STAMP47)
+#if defined(SE_STAMP43) || defined(SE_STAMPPP) || defined(SE_STAMP47) || defined(SE_STAMP67)
     g_wino_dbg43 = reinterpret_cast<unsigned long long*>(p);
 #else
     g_wino_dbg = reinterpret_cast<unsigned long long*>(p);
@@ -466,7 +466,7 @@ int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
         && g_variant != 47
 #endif
     ) {
-        const int rc67 = se_conv3d_k7_wino67_launch(a, batch, num_cus, s);
+        const int rc67 = se_conv3d_k7_wino67_launch(a, batch, num_cus, s, g_wino_dbg43);
         if (rc67 != SE_TILED_NOT_TAKEN) return rc67;
     }
     const int rc = (a.flags & SE_IN_PLANAR3) ? se_conv3d_k7_wino47_launch_p3(a, batch, num_cus, s, g_wino_dbg43)

@@ -14,9 +14,13 @@
 // output-domain sums of a wave live in registers over all chunks of a tile; bias, ReLU and the only store happen once per tile.
 //
 // Weight stream: the LDS holds ONE chunk of weights, refilled in two regions while the other one is being read - region B (groups
-// 19..36) of the CURRENT chunk during the first 19 groups of an item, region A (groups 0..18) of the NEXT chunk during the last 18;
-// a workgroup barrier between the two halves and one at the end of the item order this.  The refill (8 + 8 16-byte loads and LDS
-// writes per thread) and the 12 halo loads of the next item ride inside the MFMA stream; L2 serves the 113 KB per item.
+// 16..36) of the CURRENT chunk during the first 16 groups of an item, region A (groups 0..15) of the NEXT chunk during the last 21;
+// a workgroup barrier between the two halves and one at the end of the item order this.  The refill is LDS-DMA
+// (global_load_lds_dwordx4: 8 + 6 instructions per wave and item, no registers, no ds_write) and, like the 12 halo loads of the next
+// item (raw buffer loads: scalar slab offset, one 32-bit column offset per lane, out-of-volume -> zeros by the bounds check), rides
+// inside the MFMA stream; L2 serves the 113 KB per item.  Measured steps (33->16 @64^3, B = 8; F(4,7) kernel 2.34 ms): first form
+// with register-staged refill and global loads 1.97, + A^T per item 2.06 (accuracy), operand reads 3 + 3 ahead of 10 MFMAs 2.02,
+// buffer loads 1.92, LDS-DMA 1.80 ms; without any rider 1.63 ms = the MFMA issue time (profiles/r03_k67_*).
 #include "conv_common.h"
 #include "wino67_matrices.h"
 
@@ -34,27 +38,38 @@ constexpr int S_TZ = 6, S_TY = 8, S_TX = 16;
 constexpr int S_HY = S_TY + 6, S_HX = S_TX + 6, S_COLS = S_HY * S_HX;          // 308 halo columns, 12 raw slabs each
 constexpr int S_XI = 12;
 constexpr int S_G = SE_K7H_GROUPS;                                             // 37 k groups per chunk
-constexpr int S_GA = 19;                                                       // weight region A = groups 0..18, region B = 19..36
+constexpr int S_GA = 16;                                                       // weight region A = groups 0..15, region B = 16..36
 constexpr int S_W_FLOATS = SE_K7H_CHUNK_FLOATS;                                // 28416
-constexpr int S_WA_F4 = S_GA * 64 * 3;                                         // 3648 16-byte pieces
-constexpr int S_WB_F4 = (S_G - S_GA) * 64 * 3;                                 // 3456
+constexpr int S_WA_F4 = S_GA * 64 * 3;                                         // 16-byte pieces of region A
 constexpr int S_CS = S_COLS * S_XI;                                            // channel stride of the transformed tile (floats)
 constexpr int S_VT_FLOATS = 3 * S_CS;                                          // 11088
-constexpr int S_DUMMY_FLOATS = 256;                                            // one 16-byte slot per lane for masked rider writes
-constexpr int S_LDS_FIXED = (S_W_FLOATS + S_VT_FLOATS + S_DUMMY_FLOATS) * 4;   // 159,040 B
+constexpr int S_LDS_FIXED = (S_W_FLOATS + S_VT_FLOATS) * 4;                    // 158,016 B
 
 struct f32x3 { float x, y, z; };
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 struct K7SOps { f32x4 a0, a1, a2, b0, b1, b2; };    // 12 xi of weights (A) and of transformed inputs (B) for one k group
 
+#ifndef SE_K67_EXP      // attribution builds only (results wrong): 1 no weight riders, 2 no halo fetch riders, 4 no mid barrier, 8 no A^T, 16 no commit
+#define SE_K67_EXP 0
+#endif
+#ifdef SE_STAMP67   // cycle stamps (tools/stamp_k67.py; development builds with -DSE_STAMP67)
+#define T67(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+                 st_sum[i] += t_ - st_last; st_last = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define T67(i)
+#endif
+
 template <bool PLANAR>
 __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int tiles_x, int tiles_y, int tiles_z, int total_tiles,
-                                                               int units_per_wg) {
+                                                               int units_per_wg, unsigned long long* dbg) {
+    (void)dbg;
+#ifdef SE_STAMP67
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;
     float* vt = lds + S_W_FLOATS;
-    float* dummy = vt + S_VT_FLOATS;
-    i32x4* utab = reinterpret_cast<i32x4*>(dummy + S_DUMMY_FLOATS);
+    i32x4* utab = reinterpret_cast<i32x4*>(vt + S_VT_FLOATS);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -94,25 +109,41 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
     const int s_cy = s_col / S_HX, s_cx = s_col - s_cy * S_HX;
     f32x3 raw[S_XI];
     const long long f_zs = (long long)dim * dim * (PLANAR ? 3 : a.cin_pad);
-    auto fetch = [&](int k, int c) {   // out-of-volume taps load the buffer's first record (one cache line for all of them) and are zeroed
+    // buffer loads: the item's uniform part (sample, chunk) is the descriptor base, the z slab a scalar offset, the column a 32-bit
+    // per-lane offset whose bit 31 marks a column outside the volume (-> zeros); a slab outside the volume reads a zero-size descriptor
+    const float* f_xb = a.in;
+    unsigned f_voff = 0x80000000u;
+    int f_gz0 = 0;
+    bool f_shift = false;
+    const int f_rec_bytes = PLANAR ? dim * dim * dim * 12 : dim * dim * dim * a.cin_pad * 4;
+    auto fetch_setup = [&](int k, int c) {
         const i32x4 e = utab[k];
         const int gy = e.z * S_TY - 3 + s_cy, gx = e.w * S_TX - 3 + s_cx;
-        const int gz0 = e.y * S_TZ - 3;
+        f_gz0 = e.y * S_TZ - 3;
         const bool okc = s_on && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim;
-        // channels-last: a chunk whose third channel lies past the record (cin_pad == 3 c + 2) is read one float earlier
-        const bool shift = !PLANAR && (c * 3 + 2 >= a.cin_pad);
-        const long long base = PLANAR ? ((((long long)e.x * chunks + c) * dim * dim + gy) * dim + gx) * 3
-                                      : ((((long long)e.x * dim) * dim + gy) * dim + gx) * a.cin_pad + c * 3 - (shift ? 1 : 0);
-#pragma unroll
-        for (int q = 0; q < S_XI; ++q) {
-            const bool ok = okc && (unsigned)(gz0 + q) < (unsigned)dim;
-            const f32x3 t = *reinterpret_cast<const f32x3*>(a.in + (ok ? base + (gz0 + q) * f_zs : (shift ? 1 : 0)));
-            if (PLANAR) {
-                raw[q].x = ok ? t.x : 0.f; raw[q].y = ok ? t.y : 0.f; raw[q].z = ok ? t.z : 0.f;
-            } else {
-                raw[q].x = ok ? (shift ? t.y : t.x) : 0.f; raw[q].y = ok ? (shift ? t.z : t.y) : 0.f; raw[q].z = (ok && !shift) ? t.z : 0.f;
-            }
+        f_shift = !PLANAR && (c * 3 + 2 >= a.cin_pad);
+        const int b = __builtin_amdgcn_readfirstlane(e.x);
+        f_xb = PLANAR ? a.in + ((long long)b * chunks + c) * dim * dim * dim * 3
+                      : a.in + (long long)b * dim * dim * dim * a.cin_pad + c * 3 - (f_shift ? 1 : 0);
+        f_voff = okc ? (unsigned)((gy * dim + gx) * (PLANAR ? 12 : a.cin_pad * 4)) : 0x80000000u;
+    };
+    auto fetch_one = [&](auto q_tag) {
+        constexpr int q = decltype(q_tag)::value;
+        const int z = __builtin_amdgcn_readfirstlane(f_gz0) + q;
+        const bool zok = (unsigned)z < (unsigned)dim;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f_xb), 0, zok ? f_rec_bytes : 0, 0x00020000);
+        typedef float f32x3v __attribute__((ext_vector_type(3)));
+        const f32x3v t = __builtin_bit_cast(f32x3v, __builtin_amdgcn_raw_buffer_load_b96(rs, (int)f_voff, z * (int)(f_zs * 4), 0));
+        const bool shift = f_shift;
+        if (PLANAR) {
+            raw[q].x = t.x; raw[q].y = t.y; raw[q].z = t.z;
+        } else {
+            raw[q].x = shift ? t.y : t.x; raw[q].y = shift ? t.z : t.y; raw[q].z = shift ? 0.f : t.z;
         }
+    };
+    auto fetch = [&](int k, int c) {
+        fetch_setup(k, c);
+        for_each_index(fetch_one, std::make_integer_sequence<int, S_XI>{});
     };
     auto commit = [&]() {   // V = B^T d per channel: row 0 even q, row 11 odd q, rows 2k+1 / 2k+2 = even part +- odd part; 16-byte stores
         if (!s_on) return;
@@ -121,12 +152,13 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
             float d[S_XI];
 #pragma unroll
             for (int q = 0; q < S_XI; ++q) d[q] = j == 0 ? raw[q].x : j == 1 ? raw[q].y : raw[q].z;
+            // explicit fmaf chains in a fixed order: both input-layout instantiations round identically (bit-equal outputs)
             float o[S_XI];
             float r0 = 0.f, r11 = 0.f;
 #pragma unroll
             for (int q = 0; q < S_XI; ++q) {
-                if (SE_W67_BT[0][q] != 0.f) r0 += SE_W67_BT[0][q] * d[q];
-                if (SE_W67_BT[11][q] != 0.f) r11 += SE_W67_BT[11][q] * d[q];
+                if (SE_W67_BT[0][q] != 0.f) r0 = fmaf(SE_W67_BT[0][q], d[q], r0);
+                if (SE_W67_BT[11][q] != 0.f) r11 = fmaf(SE_W67_BT[11][q], d[q], r11);
             }
             o[0] = r0; o[11] = r11;
 #pragma unroll
@@ -136,7 +168,7 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
 #pragma unroll
                 for (int q = 1; q < 11; ++q) {
                     const float cf = SE_W67_BT[xi][q];
-                    if (q & 1) od += cf * d[q]; else ev += cf * d[q];
+                    if (q & 1) od = fmaf(cf, d[q], od); else ev = fmaf(cf, d[q], ev);
                 }
                 o[xi] = ev + od; o[xi + 1] = ev - od;
             }
@@ -147,27 +179,17 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
         }
     };
 
-    // weight refill riders: batch of up to four 16-byte pieces per thread in flight
-    f32x4 wb[4];
-    auto wload = [&](const float* src, auto count_tag, auto j0_tag, auto n_tag) {
-        constexpr int COUNT = decltype(count_tag)::value, J0 = decltype(j0_tag)::value, N = decltype(n_tag)::value;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int idx = (J0 + i) * 512 + tid;
-            wb[i] = reinterpret_cast<const f32x4*>(src)[((J0 + i + 1) * 512 <= COUNT || idx < COUNT) ? idx : 0];
-        }
+    // LDS-DMA piece J of a weight region for this wave: wave-instruction 8 J + wave (clamped: the surplus ones repeat the last piece)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto wglds = [&](const float* src, float* region, auto n_tag, auto j_tag) {
+        constexpr int NWI = decltype(n_tag)::value, J = decltype(j_tag)::value;
+        int piece = J * 8 + wave_u;
+        piece = piece < NWI ? piece : NWI - 1;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (piece * 64 + lane) * 4),
+                                         (void __attribute__((address_space(3)))*)(region + piece * 256), 16, 0, 0);
     };
-    auto wwrite = [&](float* region, auto count_tag, auto j0_tag, auto n_tag) {
-        constexpr int COUNT = decltype(count_tag)::value, J0 = decltype(j0_tag)::value, N = decltype(n_tag)::value;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int idx = (J0 + i) * 512 + tid;
-            f32x4* d = ((J0 + i + 1) * 512 <= COUNT || idx < COUNT) ? reinterpret_cast<f32x4*>(region) + idx : reinterpret_cast<f32x4*>(dummy) + lane;
-            *d = wb[i];
-        }
-    };
-    using CA = std::integral_constant<int, S_WA_F4>;
-    using CB = std::integral_constant<int, S_WB_F4>;
+    using NA = std::integral_constant<int, S_GA * 3>;
+    using NB = std::integral_constant<int, (S_G - S_GA) * 3>;
 
     auto lds_barrier = [&]() {
         __builtin_amdgcn_sched_barrier(0);
@@ -206,23 +228,28 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
         const float* w_next_a = a.wpack_h + (size_t)c_next * S_W_FLOATS;            // region A of the next item's chunk
 
         K7SOps cur, nxt;
+#ifdef SE_STAMP67
+        { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#endif
         read_ops(cur, std::integral_constant<int, 0>{});
         nxt = cur;
         auto step = [&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
-            using I0 = std::integral_constant<int, 0>;
-            using I3 = std::integral_constant<int, 3>;
-            using I4 = std::integral_constant<int, 4>;
             // first half: region B of this chunk (7 pieces per thread) and the next item's raw halo columns
-            if constexpr (g == 1) wload(w_cur_b, CB{}, I0{}, I4{});
-            if constexpr (g == 2) fetch(k_next, c_next);
-            if constexpr (g == 7) { wwrite(wl + S_GA * 768, CB{}, I0{}, I4{}); wload(w_cur_b, CB{}, I4{}, I3{}); }
-            if constexpr (g == 12) wwrite(wl + S_GA * 768, CB{}, I4{}, I3{});
-            // second half: region A of the next item's chunk (8 pieces per thread)
-            if constexpr (g == S_GA + 1) wload(w_next_a, CA{}, I0{}, I4{});
-            if constexpr (g == S_GA + 6) { wwrite(wl, CA{}, I0{}, I4{}); wload(w_next_a, CA{}, I4{}, I4{}); }
-            if constexpr (g == S_GA + 11) wwrite(wl, CA{}, I4{}, I4{});
-
+            constexpr bool WR = !(SE_K67_EXP & 1), FR = !(SE_K67_EXP & 2);
+            // first half: region B of this chunk by LDS-DMA (63 wave-instructions = 8 per wave, the 64th repeats the 63rd), then the
+            // next item's raw halo columns; second half: region A of the next item's chunk (48 = 6 per wave).  All of them early in
+            // their half: a wave stalled on a vector-memory issue is covered by its SIMD partner only while that one still has MFMAs
+            // (measured: two LDS-DMAs per group = one per group; skipping the fetch in the waves without columns by a branch: +6 %)
+            if constexpr (WR && g >= 1 && g <= 4) {
+                wglds(w_cur_b, wl + S_GA * 768, NB{}, std::integral_constant<int, 2 * (g - 1)>{});
+                wglds(w_cur_b, wl + S_GA * 768, NB{}, std::integral_constant<int, 2 * (g - 1) + 1>{});
+            }
+            if constexpr (FR && g == 5) fetch(k_next, c_next);
+            if constexpr (WR && g >= S_GA + 1 && g <= S_GA + 3) {
+                wglds(w_next_a, wl, NA{}, std::integral_constant<int, 2 * (g - S_GA - 1)>{});
+                wglds(w_next_a, wl, NA{}, std::integral_constant<int, 2 * (g - S_GA - 1) + 1>{});
+            }
             constexpr bool pipelined = g + 1 < S_G && g + 1 != S_GA;     // the first read of region B waits for the mid barrier
             if constexpr (pipelined) read_ops(nxt, std::integral_constant<int, g + 1>{});
             const float av[12] = {cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w, cur.a2.x, cur.a2.y, cur.a2.z, cur.a2.w};
@@ -231,28 +258,30 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
 #pragma unroll
             for (int x = 0; x < S_XI; ++x)
                 acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x], bv[x], g == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[x], 0, 0, 0);
-            if constexpr (pipelined) {   // spread the next group's reads between this group's MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if constexpr (pipelined) {   // the next group's reads between this group's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
             } else {
                 __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
             }
             if constexpr (g + 1 == S_GA) {   // everybody is past region A; region B of this chunk is complete
-                lds_barrier();
+                T67(0);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // region B has landed; the 12 halo loads behind it may still fly
+                if (!(SE_K67_EXP & 4)) lds_barrier();
+                T67(1);
                 read_ops(nxt, std::integral_constant<int, S_GA>{});
             }
             cur = nxt;
         };
         for_each_index(step, std::make_integer_sequence<int, S_G>{});
+        T67(2);
 
         // A^T (6 x 12; xi 1..10 in +- pairs) after EVERY item, summed in the output domain: the rounding error of a Winograd-domain
         // accumulator is amplified by A^T (|A^T| <= 98), so the sums that live across chunks are the six outputs, not the twelve xi
         // (float32 model, error / std of the output: 1.2e-5 mean with one A^T per tile, 4.3e-6 per chunk; F(4,7) per chunk: 2.5e-6)
-        {
+        if (!(SE_K67_EXP & 8) || last_chunk) {
             f32x4 s[5], d[5];
 #pragma unroll
             for (int p = 0; p < 5; ++p) { s[p] = acc[2 * p + 1] + acc[2 * p + 2]; d[p] = acc[2 * p + 1] - acc[2 * p + 2]; }
@@ -262,14 +291,20 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
                 if (i == 0) v += acc[0];
                 if (i == S_TZ - 1) v += acc[11];
 #pragma unroll
-                for (int p = 0; p < 5; ++p) v += SE_W67_AT[i][2 * p + 1] * ((i & 1) ? d[p] : s[p]);
+                for (int p = 0; p < 5; ++p) {
+                    const float cf = SE_W67_AT[i][2 * p + 1];
+                    const f32x4 t = (i & 1) ? d[p] : s[p];
+                    v.x = fmaf(cf, t.x, v.x); v.y = fmaf(cf, t.y, v.y); v.z = fmaf(cf, t.z, v.z); v.w = fmaf(cf, t.w, v.w);
+                }
                 y[i] = v;
             }
         }
+        T67(3);
         // single transformed tile: every wave must be done reading it before the next item's columns are committed.  Barriers inside
         // the loop wait for this wave's LDS traffic only (a __syncthreads() would also wait for vmcnt(0))
         lds_barrier();
-        if (has_next) commit();
+        T67(4);
+        if (has_next && !(SE_K67_EXP & 16)) commit();
         if (last_chunk) {   // bias, ReLU, the only store of this tile
             const i32x4 e = utab[k];
             const int oz0 = e.y * S_TZ, oy = e.z * S_TY + wave, ox = e.w * S_TX + vl;
@@ -283,21 +318,33 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
                 y[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
+        T67(5);
         if (!has_next) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // region A of the next chunk has landed
         lds_barrier();
+        T67(6);
         k = k_next; c = c_next;
     }
+#ifdef SE_STAMP67
+    if (lane == 0 && dbg) {
+        unsigned long long* o = dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = st_sum[i];
+        o[7] = n_items;
+    }
+#endif
 }
 
 }  // namespace
 
 // Returns 0 on launch, SE_TILED_NOT_TAKEN if the shape / unit table is not covered, else a hipError_t.  Preconditions (checked by the
 // caller, se_conv3d_k7_wino_try): ksize 7, cout 16, no residual, channels-last output, a.wpack_h set.
-int se_conv3d_k7_wino67_launch(const ConvArgs& a, int batch, int num_cus, hipStream_t s) {
+int se_conv3d_k7_wino67_launch(const ConvArgs& a, int batch, int num_cus, hipStream_t s, unsigned long long* dbg) {
     constexpr int LDS_BYTES = 160 * 1024;
     constexpr int MAX_UNITS = (LDS_BYTES - S_LDS_FIXED) / 16;
     const int dim = a.dim;
     if (dim < 16 || (dim & 15)) return SE_TILED_NOT_TAKEN;
+    // 32-bit buffer offsets inside one sample (channels-last) / one chunk volume (triplet-planar); bit 31 marks out-of-volume lanes
+    if ((long long)dim * dim * dim * ((a.flags & SE_IN_PLANAR3) ? 12 : a.cin_pad * 4) >= (1LL << 31)) return SE_TILED_NOT_TAKEN;
     const int tx = dim / S_TX, ty = dim / S_TY, tz = (dim + S_TZ - 1) / S_TZ;
     const long long total_ll = (long long)batch * tx * ty * tz;
     if (total_ll > (1 << 30)) return SE_TILED_NOT_TAKEN;
@@ -307,10 +354,10 @@ int se_conv3d_k7_wino67_launch(const ConvArgs& a, int batch, int num_cus, hipStr
     if (per > MAX_UNITS) return SE_TILED_NOT_TAKEN;
     if (a.flags & SE_IN_PLANAR3) {
         SE_ENSURE_LDS(conv3d_k7_wino67_kernel<true>, LDS_BYTES);
-        hipLaunchKernelGGL(conv3d_k7_wino67_kernel<true>, dim3((total + per - 1) / per), dim3(512), LDS_BYTES, s, a, tx, ty, tz, total, per);
+        hipLaunchKernelGGL(conv3d_k7_wino67_kernel<true>, dim3((total + per - 1) / per), dim3(512), LDS_BYTES, s, a, tx, ty, tz, total, per, dbg);
     } else {
         SE_ENSURE_LDS(conv3d_k7_wino67_kernel<false>, LDS_BYTES);
-        hipLaunchKernelGGL(conv3d_k7_wino67_kernel<false>, dim3((total + per - 1) / per), dim3(512), LDS_BYTES, s, a, tx, ty, tz, total, per);
+        hipLaunchKernelGGL(conv3d_k7_wino67_kernel<false>, dim3((total + per - 1) / per), dim3(512), LDS_BYTES, s, a, tx, ty, tz, total, per, dbg);
     }
     SE_CHECK_LAUNCH();
     return 0;

@@ -8,10 +8,10 @@
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int F, int D, int BAR, int GROUPS>
-__global__ __launch_bounds__(512) void kself(float* out, const float* in, int steps) {
+template <int F, int D, int BAR, int GROUPS, int THREADS = 512>
+__global__ __launch_bounds__(THREADS) void kself(float* out, const float* in, int steps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    for (int i = threadIdx.x; i < 24576; i += 512) lds[i] = (float)(i & 15) * 0.001f;
+    for (int i = threadIdx.x; i < 24576; i += THREADS) lds[i] = (float)(i & 15) * 0.001f;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(512) void kself(float* out, const float* in, int st
     float ts = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) ts += t[i];
-    out[blockIdx.x * 512 + threadIdx.x] = sres.x + sres.y + sres.z + sres.w + ts;
+    out[blockIdx.x * THREADS + threadIdx.x] = sres.x + sres.y + sres.z + sres.w + ts;
 }
 
 template <typename Fn>
@@ -101,6 +101,16 @@ double time_ms(Fn f) {
                GROUPS * 8, ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3);                                                          \
     }
 
+#define RUN1(F, D, BAR, GROUPS)   /* ONE wave per SIMD (256-thread workgroups, one per CU) */                                           \
+    {                                                                                                                              \
+        auto k = kself<F, D, BAR, GROUPS, 256>;                                                                                    \
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);                              \
+        double ms = time_ms([&] { hipLaunchKernelGGL(k, dim3(256), dim3(256), 98304, 0, out, in, steps); });                       \
+        double flop = 256.0 * 4 * steps * (GROUPS * 8) * (16.0 * 16 * 4 * 2);                                                      \
+        printf("ONE wave per SIMD: VALU/MFMA=%d ds_write_b128/step=%2d barrier=%d MFMAs/step=%3d : %.3f ms  %.1f TF/s  (%.2f of 157.3)\n", F, D, \
+               BAR, GROUPS * 8, ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3);                                                     \
+    }
+
 int main() {
     float *out, *in;
     (void)hipMalloc(&out, 256 * 512 * sizeof(float));
@@ -110,5 +120,6 @@ int main() {
     RUN(0, 0, 0, 18) RUN(1, 0, 0, 18) RUN(2, 0, 0, 18) RUN(3, 0, 0, 18) RUN(4, 0, 0, 18)
     RUN(1, 12, 1, 18) RUN(2, 12, 1, 18) RUN(2, 18, 1, 18) RUN(3, 18, 1, 18)
     RUN(2, 9, 1, 9) RUN(3, 9, 1, 9)
+    RUN1(0, 0, 0, 18) RUN1(1, 0, 0, 18) RUN1(0, 0, 1, 18)
     return 0;
 }
