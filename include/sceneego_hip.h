@@ -269,7 +269,7 @@ int se_bias_act_nchw_bf16(const se_bf16* x, const se_bf16* bias, const se_bf16* 
 /* Which kernel family se_conv3d_f32 selects for a float32 convolution of this shape (bench.py prices the roofline with it):
  *   0 direct implicit GEMM (every product on the matrix cores),
  *   1 1-D Winograd F(4,3) along z (1/2 of the direct products), 2 2-D Winograd F(4,3) x F(2,3) along z, y (1/3),
- *   7 1-D Winograd F(4,7) along z for the 7x7x7 front layer (10/28).
+ *   7 1-D Winograd along z for the 7x7x7 front layer: F(6,7) (12/42 of the direct products) when dim % 16 == 0, else F(4,7) (10/28).
  * Pure function of the arguments; no device access. */
 int se_conv3d_f32_algo(int dim, int cin, int cout, int ksize);
 
