@@ -11,6 +11,8 @@ net = VoxelNetwork_depth(cfg, device="cpu", verbose=False)
 sd = synthetic_state_dict(False, 0)
 net.load_state_dict(sd, strict=True)
 net = net.to("cuda:0").eval()
+if len(sys.argv) > 1 and sys.argv[1] == "split_bf16":
+    net.set_v2v_dtype("split_bf16")
 const = O.Constants(os.path.join(ROOT, "sceneego_amd", "calibration", "fisheye.calibration_05_08.json"))
 worst = 0.0
 for seed in (3, 19, 101, 2027, 5150, 90210):
