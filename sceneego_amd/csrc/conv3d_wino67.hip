@@ -240,12 +240,17 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
             // first half: region B of this chunk by LDS-DMA (63 wave-instructions = 8 per wave, the 64th repeats the 63rd), then the
             // next item's raw halo columns; second half: region A of the next item's chunk (48 = 6 per wave).  All of them early in
             // their half: a wave stalled on a vector-memory issue is covered by its SIMD partner only while that one still has MFMAs
-            // (measured: two LDS-DMAs per group = one per group; skipping the fetch in the waves without columns by a branch: +6 %)
+            // (measured: two LDS-DMAs per group = one per group; skipping the fetch in the waves without columns by a branch: +6 %;
+            // hipcc sinks the halo loads towards the mid barrier - pinning them to groups 5-10 by sched_group_barrier: +0.5 %, all
+            // twelve in group 5: +2.6 %)
             if constexpr (WR && g >= 1 && g <= 4) {
                 wglds(w_cur_b, wl + S_GA * 768, NB{}, std::integral_constant<int, 2 * (g - 1)>{});
                 wglds(w_cur_b, wl + S_GA * 768, NB{}, std::integral_constant<int, 2 * (g - 1) + 1>{});
             }
-            if constexpr (FR && g == 5) fetch(k_next, c_next);
+            if constexpr (FR && g == 5) {
+                asm volatile("" ::: "memory");   // the halo loads stay behind the LDS-DMAs: the counted wait in front of the mid barrier relies on it
+                fetch(k_next, c_next);
+            }
             if constexpr (WR && g >= S_GA + 1 && g <= S_GA + 3) {
                 wglds(w_next_a, wl, NA{}, std::integral_constant<int, 2 * (g - S_GA - 1)>{});
                 wglds(w_next_a, wl, NA{}, std::integral_constant<int, 2 * (g - S_GA - 1) + 1>{});
