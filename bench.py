@@ -11,7 +11,7 @@ prints ONE JSON line.  A step = one forward over one batch of synthetic input al
 of the joints when N > 1).  Weak scaling: every rank runs --batch frames (BASELINE.json configs[1]: batch 8, fp32, 64^3).
 Nothing is recorded inside the timed region; per-launch and per-stage durations come from a SEPARATE short pass with HIP
 events on the launch stream (SURVEY.md §8d "Timing").
-Consecutive steps are issued round-robin on `--streams` HIP streams (default 2, sceneego_amd/pipeline.py): each step is still one
+Consecutive steps are issued round-robin on `--streams` HIP streams (default 3, sceneego_amd/pipeline.py): each step is still one
 complete forward of --batch frames, the K steps are all inside the timed bracket, and `extra.single_stream` reports the same K
 steps issued on one stream beside the headline; `config.streams` says which form `value` is.
 
@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--dump-kernel-events", action="store_true", help="per-shape launch times to stderr")
     ap.add_argument("--dump-launch-order", default="", help="write the launch keys of one profiled step, in issue order, to this JSON file")
     ap.add_argument("--graphs", action="store_true", help="replay the forward as a captured hipGraph")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="consecutive steps are issued round-robin on this many HIP streams (sceneego_amd/pipeline.py: the 2-D backbone of "
                          "step i+1 runs in the gaps of step i); 1 = every step behind the previous one")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-started launcher (0: a free one)")

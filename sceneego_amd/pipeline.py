@@ -4,8 +4,9 @@ One forward is a chain of ~170 launches whose big members (the persistent 3-D co
 its registers and most of its LDS) own the chip while they run, but 2.1 ms of it is the MIOpen 2-D backbone and another ~1 ms are
 the small pyramid levels and the tail - launches that leave most CUs idle.  Batches are independent (the reference evaluates them
 one after the other, ``network/voxel_net_depth.py:244-275`` has no state across calls), so the backbone of batch i+1 can run in
-those gaps of batch i: two streams give 717 -> 770 frames/s at B = 8 on one MI355X (``tools/diag/two_stream.py``; a third stream
-is not a consistent gain; putting each forward's backbone on a low-priority stream and its 3-D part on a high-priority one measured
+those gaps of batch i: two streams give 717 -> 770 frames/s at B = 8 on one MI355X (``tools/diag/two_stream.py``; round 3, with the
+shorter 7^3 front layer: 767 on one stream, 819 on two, 831 on three - six alternating runs on one box, 815 on four - so ``bench.py``
+issues on three; putting each forward's backbone on a low-priority stream and its 3-D part on a high-priority one measured
 slower, 753 vs 780; replaying each replica as a hipGraph adds ~1 %, ``tools/diag/two_stream_graphs.py``; capping the persistent kernels to half the
 CUs so that the two forwards' big kernels run side by side changes nothing, 772.7 vs 772.4).
 
