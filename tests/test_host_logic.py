@@ -313,3 +313,34 @@ def test_bf16_kernel_lds_reads_are_conflict_free():
     assert m.k3() == 1
     assert m.k7(24, False) == 1 and m.k7(24, True) == 1
     assert m.k7(16, False) > 1          # the naive pitch is not conflict-free: the padding is what buys it
+
+
+@pytest.mark.parametrize("tool,header,prefix,m", [("wino47_matrices", "wino47_matrices.h", "SE_W47", 4), ("wino67_matrices", "wino67_matrices.h", "SE_W67", 6)])
+def test_winograd_7tap_matrices_are_exact_and_headers_in_sync(tool, header, prefix, m):
+    """The Cook-Toom matrices of the 7^3 front-layer kernels (F(4,7): csrc/conv3d_wino47.hip, F(6,7): csrc/conv3d_wino67.hip; both
+    restate Conv3d(33, 16, 7) of network/v2v.py:75-77 along z): y = A^T [(G g) .* (B^T d)] equals the 7-tap correlation exactly (to
+    float64 rounding), the +- row pairs the kernels' transforms rely on are there, and the committed C header holds exactly the
+    float32 values the generator tool produces."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(tool, os.path.join(root, "tools", tool + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    AT, G, BT = mod.matrices()
+    n = m + 6
+    assert AT.shape == (m, n) and G.shape == (n, 7) and BT.shape == (n, n)
+    rng = np.random.default_rng(7)
+    for _ in range(20):
+        g, d = rng.standard_normal(7), rng.standard_normal(n)
+        want = np.array([np.dot(g, d[i:i + 7]) for i in range(m)])
+        got = AT @ ((G @ g) * (BT @ d))
+        assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(BT).max() * np.abs(AT).max())
+    for k in range(1, n - 1, 2):       # rows k, k+1 = points +p, -p: even columns equal, odd columns negated
+        assert np.allclose(BT[k, 0::2], BT[k + 1, 0::2]) and np.allclose(BT[k, 1::2], -BT[k + 1, 1::2])
+        assert np.allclose(AT[0::2, k], AT[0::2, k + 1]) and np.allclose(AT[1::2, k], -AT[1::2, k + 1])
+    text = open(os.path.join(root, "sceneego_amd", "csrc", header)).read()
+    for name, mat in (("AT", AT), ("G", G), ("BT", BT)):
+        body = re.search(r"%s_%s\[\d+\]\[\d+\] = \{(.*?)\};" % (prefix, name), text, re.S).group(1)
+        vals = np.array([float(v.rstrip("f")) for v in re.findall(r"-?\d+\.?\d*(?:e-?\d+)?f", body)], dtype=np.float32)
+        assert vals.size == mat.size and np.array_equal(vals, mat.astype(np.float32).ravel()), name
