@@ -33,6 +33,14 @@ for f in voxelize gather softargmax conv3d conv3d_tiled conv3d_wino conv3d_wino2
     pids+=($!)
   fi
 done
+# development builds: the F(4,3) x F(4,3) experiment of round 3 (se_debug_set_variant(63))
+if [ -n "$DEV" ]; then
+  OBJS+=($OBJ/conv3d_wino44.o)
+  if newer conv3d_wino44.hip $OBJ/conv3d_wino44.o; then
+    hipcc $FLAGS -c conv3d_wino44.hip -o $OBJ/conv3d_wino44.o &
+    pids+=($!)
+  fi
+fi
 # the F(4,7) 7^3 kernel: one object per input layout (each takes minutes to compile: 390 unrolled MFMAs under sched_group_barrier)
 for v in 0 1; do
   OBJS+=($OBJ/conv3d_wino47_$v.o)

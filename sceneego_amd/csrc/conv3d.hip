@@ -891,12 +891,18 @@ extern "C" long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, in
     if (!transposed && ksize == 7 && cout <= 16) n += (long long)((cin_pad + 2) / 3) * (SE_K7F_CHUNK_FLOATS + SE_K7H_CHUNK_FLOATS);     // sections F, H (last)
     if (!transposed && ksize == 3 && cout % 32 == 0)
         n += (long long)(cin_pad / 16) * (cout / 32) * (SE_WINO_CHUNK_FLOATS + SE_WINO43_CHUNK_FLOATS);
-    if (!transposed && ksize == 3 && cout % 32 == 0) n += (long long)(cin_pad / 8) * (cout / 32) * SE_WINO2D_CHUNK_FLOATS;   // section G (last)
+    if (!transposed && ksize == 3 && cout % 32 == 0) n += (long long)(cin_pad / 8) * (cout / 32) * SE_WINO2D_CHUNK_FLOATS;   // section G
+#ifdef SE_DEVTOOLS
+    if (!transposed && ksize == 3 && cout % 32 == 0) n += (long long)(cin_pad / 4) * (cout / 32) * SE_WINO44_CHUNK_FLOATS;   // section I (last; development builds)
+#endif
     return n;
 }
 
 // conv3d_wino2d.hip
 int se_conv3d_pack_wino2d(const float* w, const float* gamma, const float* var, float eps, float* out, int cout, int cin,
+                          int cin_pad, hipStream_t s);
+// conv3d_wino44.hip
+int se_conv3d_pack_wino44(const float* w, const float* gamma, const float* var, float eps, float* out, int cout, int cin,
                           int cin_pad, hipStream_t s);
 
 extern "C" int se_conv3d_pack_f32(const float* w, const float* b, const float* gamma, const float* beta,
@@ -914,11 +920,24 @@ extern "C" int se_conv3d_pack_f32(const float* w, const float* b, const float* g
     long long total_main = total;
     if (!transposed && ksize == 7 && cout <= 16) total_main -= (long long)((cin_pad + 2) / 3) * (SE_K7F_CHUNK_FLOATS + SE_K7H_CHUNK_FLOATS);
     const long long n_g = (!transposed && ksize == 3 && cout % 32 == 0) ? (long long)(cin_pad / 8) * (cout / 32) * SE_WINO2D_CHUNK_FLOATS : 0;
-    total_main -= n_g;
+#ifdef SE_DEVTOOLS
+    const long long n_i = n_g ? (long long)(cin_pad / 4) * (cout / 32) * SE_WINO44_CHUNK_FLOATS : 0;
+#else
+    const long long n_i = 0;
+#endif
+    total_main -= n_g + n_i;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, se_stream(stream), w, b,
                        gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_pad, taps, transposed, total_a, total_main);
     SE_CHECK_LAUNCH();
-    if (n_g) return se_conv3d_pack_wino2d(w, gamma, var, eps, wpack + total_main, cout, cin, cin_pad, se_stream(stream));
+    if (n_g) {
+        const int rc = se_conv3d_pack_wino2d(w, gamma, var, eps, wpack + total_main, cout, cin, cin_pad, se_stream(stream));
+#ifdef SE_DEVTOOLS
+        if (rc) return rc;
+        return se_conv3d_pack_wino44(w, gamma, var, eps, wpack + total_main + n_g, cout, cin, cin_pad, se_stream(stream));
+#else
+        return rc;
+#endif
+    }
     if (total_main != total) {
         const long long nf = (long long)((cin_pad + 2) / 3) * SE_K7F_CHUNK_FLOATS, nh = total - total_main - nf;
         hipLaunchKernelGGL(pack_k7f_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, se_stream(stream), w, gamma, var, eps,
@@ -962,6 +981,10 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
     if (ksize == 3 && cout % 32 == 0) a.wpack_e = a.wpack_b + (long long)(cin_pad / 16) * (cout / 32) * SE_WINO_CHUNK_FLOATS;
     a.wpack_g = nullptr;
     if (ksize == 3 && cout % 32 == 0) a.wpack_g = a.wpack_e + (long long)(cin_pad / 16) * (cout / 32) * SE_WINO43_CHUNK_FLOATS;
+    a.wpack_i = nullptr;
+#ifdef SE_DEVTOOLS
+    if (ksize == 3 && cout % 32 == 0) a.wpack_i = a.wpack_g + (long long)(cin_pad / 8) * (cout / 32) * SE_WINO2D_CHUNK_FLOATS;
+#endif
     a.pool_out = pool_out;
     a.skip_w = skip_w;
     if (!skip_w && (flags & SE_EPI_SKIPCONV16)) return SE_ERR_BAD_ARG;
@@ -1056,6 +1079,8 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
     a.wpack_e = nullptr;
     a.wpack_f = nullptr;
     a.wpack_g = nullptr;
+    a.wpack_h = nullptr;
+    a.wpack_i = nullptr;
     a.pool_out = nullptr;
     a.skip_w = nullptr;
     // all eight sub-positions per workgroup where that still fills the chip (measured at B=8: 64->32 from 32^3, 2048 workgroups,

@@ -738,11 +738,20 @@ int se_conv3d_pack_wino2d(const float* w, const float* gamma, const float* var, 
     return 0;
 }
 
+#ifdef SE_DEVTOOLS
+bool se_conv3d_wino44_takes(const ConvArgs& a);                               // conv3d_wino44.hip (development builds)
+int se_conv3d_wino44_launch(const ConvArgs& a, int batch, hipStream_t s);
+#endif
+
 // Returns 0 on launch, SE_TILED_NOT_TAKEN if the shape/flags are not covered, else a hipError_t.
 int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
     const int dim = a.dim;
     if (!a.wpack_g || a.cin_pad != a.cin || !se_wino2d_shape_ok(dim, a.cin, a.cout)) return SE_TILED_NOT_TAKEN;
     if (a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR)) return SE_TILED_NOT_TAKEN;
+#ifdef SE_DEVTOOLS
+    // experiment (round 3, se_debug_set_variant(63)): F(4,3) x F(4,3), lockstep form with an LDS-DMA weight stream (conv3d_wino44.hip)
+    if (g_variant == 63 && se_conv3d_wino44_takes(a)) return se_conv3d_wino44_launch(a, batch, s);
+#endif
     const int tx = dim / 16, ty = dim / 8, tz = dim / 4;
     const long long total_tiles = (long long)batch * tx * ty * tz;
     const long long n_units = total_tiles * (a.cout / 32);

@@ -13,6 +13,9 @@
 // 2-D Winograd F(4,3) x F(2,3) section (G) of the packed 3x3x3 weights (conv3d_wino2d.hip): per (32-cout block, 8-cin chunk)
 // 24 xi x 3 dx x 2 cout tiles x 64 lanes x 2 = 73,728 B
 #define SE_WINO2D_CHUNK_FLOATS (24 * 3 * 2 * 128)
+// 2-D Winograd F(4,3) x F(4,3) section (I) of the packed 3x3x3 weights (conv3d_wino44.hip): per (32-cout block, 4-cin chunk)
+// 9 xi quads x 3 dx x 2 cout tiles x 64 lanes x 4 = 55,296 B
+#define SE_WINO44_CHUNK_FLOATS (9 * 3 * 2 * 256)
 // 1-D Winograd F(2,7) section of the packed 7x7x7 weights: per 4-channel chunk 13 (dy,dx) tap groups x 8 xi x 1 KiB
 #define SE_K7W_GROUPS 13
 #define SE_K7W_CHUNK_FLOATS (SE_K7W_GROUPS * 8 * 256)
@@ -57,6 +60,7 @@ struct ConvArgs {
     const float* wpack_d;  // k = 7, cout <= 16: Winograd F(2,7) section D [chunk4][g13][xi8][lane][4] (else NULL)
     const float* wpack_f;  // k = 7, cout <= 16: Winograd F(4,7) section F [chunk3][g13][xi10][lane][3] (else NULL)
     const float* wpack_h;  // k = 7, cout <= 16: Winograd F(6,7) section H [chunk3][g37][lane][xi12] (else NULL)
+    const float* wpack_i;  // k = 3, cout % 32 == 0: 2-D Winograd F(4,3) x F(4,3) section I (else NULL)
     const float* wpack_g;  // k = 3, cout % 32 == 0: 2-D Winograd F(4,3) x F(2,3) section G (else NULL)
     const float* skip_w;   // SE_EPI_SKIPCONV16: folded 1x1x1 skip weights [cout][16]; `res` then is the skip convolution's 16-channel input
     float* pool_out;       // 2-D Winograd kernel only: also write max_pool3d(out, 2, 2), channels-last [B][D/2][D/2][D/2][cout] (else NULL)

@@ -671,3 +671,59 @@ def test_conv3d_octet_planar_forms_match_channels_last(B, dim, cin, cout):
     small = torch.randn(1, 8, 8, 8, cin, device=DEV)
     with pytest.raises(_lib.HipExtensionError):
         _lib.conv3d(small, pc.w, pc.b, None, torch.empty(1, 8, 8, 8, cout, device=DEV), 1, 8, cin, cin, cout, 3, _lib.IN_OCTET)
+
+
+@pytest.mark.parametrize("B,dim,cin,cout,residual", [(1, 32, 32, 32, True), (2, 32, 16, 32, False), (1, 32, 64, 64, True)])
+def test_conv3d_wino44_experiment_vs_torch(B, dim, cin, cout, residual):
+    """Round-3 experiment, development builds only (csrc/build.sh --devtools; se_debug_set_variant(63)): 2-D Winograd F(4,3) x F(4,3)
+    for the 3x3x3 layers (csrc/conv3d_wino44.hip; reference network/v2v.py:21-43) against torch-CPU float32, channels-last and
+    octet-planar forms.  Skipped when the development library has not been built; the production library does not contain it."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libsceneego_hip_dev.so")
+    if not os.path.exists(path):
+        pytest.skip("development library not built")
+    lib = ctypes.CDLL(path)
+    if lib.se_abi_version() != _lib.ABI_VERSION:
+        pytest.skip("development library is stale")
+    for name, (res_t, args) in _lib.SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype, fn.argtypes = res_t, args
+    seed = hash((B, dim, cin, cout, 44)) % 1000
+    conv = nn.Conv3d(cin, cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(synth.normal(seed, "w", tuple(conv.weight.shape), (2.0 / (cin * 27)) ** 0.5)))
+        conv.bias.copy_(torch.from_numpy(synth.uniform(seed, "cb", (cout,), -0.2, 0.2)))
+    x = torch.from_numpy(synth.normal(seed, "x", (B, cin, dim, dim, dim)))
+    res = torch.from_numpy(synth.normal(seed, "r", (B, cout, dim, dim, dim))) if residual else None
+    with torch.no_grad():
+        want = conv(x) + (res if residual else 0)
+        want = F.relu(want)
+    vp = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    w = conv.weight.detach().float().contiguous().to(DEV)
+    bias = conv.bias.detach().float().contiguous().to(DEV)
+    wp = torch.empty(int(lib.se_conv3d_packed_elems(cout, cin, 3, 0)), device=DEV)
+    bp = torch.empty((cout + 15) // 16 * 16, device=DEV)
+    assert lib.se_conv3d_pack_f32(vp(w), vp(bias), None, None, None, None, 0.0, vp(wp), vp(bp), cout, cin, cin, 3, 0, None) == 0
+    xin = _ndhwc(x).to(DEV)
+    rin = _ndhwc(res).to(DEV) if residual else None
+    flags = _lib.EPI_RELU | (_lib.EPI_RES_PRE_RELU if residual else 0)
+    to_oct = lambda t, c: t.view(B, dim, dim, dim, c // 8, 8).permute(0, 4, 1, 2, 3, 5).contiguous()
+    lib.se_debug_set_variant(63)
+    try:
+        out = torch.full((B, dim, dim, dim, cout), -7.0, device=DEV)
+        assert lib.se_conv3d_f32(vp(xin), vp(wp), vp(bp), vp(rin), vp(out), B, dim, cin, cin, cout, 3, flags, None, 0, None) == 0
+        out_o = torch.full((B, cout // 8, dim, dim, dim, 8), -7.0, device=DEV)
+        fl = flags | _lib.IN_OCTET | _lib.OUT_OCTET | (_lib.RES_OCTET if residual else 0)
+        assert lib.se_conv3d_f32(vp(to_oct(xin, cin)), vp(wp), vp(bp), vp(to_oct(rin, cout)) if residual else None, vp(out_o), B, dim, cin, cin,
+                                 cout, 3, fl, None, 0, None) == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.se_debug_set_variant(0)
+    got = _ncdhw(out.cpu())
+    err = float((got - want).abs().max())
+    scale = max(1.0, float(want.abs().max()))
+    print(f"F(4,3)xF(4,3) experiment {cin}->{cout} @{dim}^3: max error {err:.2e} = {err / scale:.2e} of max|y|")
+    assert err < 2e-5 * scale
+    assert torch.equal(out_o.permute(0, 2, 3, 4, 1, 5).reshape(B, dim, dim, dim, cout), out)      # same arithmetic in every layout
