@@ -285,7 +285,7 @@ class VoxelNetwork_depth(nn.Module):
         bf16 = prog.dtype == torch.bfloat16
         fast_occ = (self.with_scene is True and scene_volumes is None and not self.with_intersection
                     and prog.cin_pad >= C + (8 if bf16 else 4))
-        # float32 production case (features + depth occupancy): triplet-planar input [B,11,G,G,G,3] for the F(4,7) front layer
+        # float32 production case (features + depth occupancy): triplet-planar input [B,11,G,G,G,3] for the 7^3 front layer
         planar3 = (fast_occ and not bf16 and prog.cin == C + 1 and G % 8 == 0 and G >= 16 and self.planar3_input)
         xkey = (B, G, prog.cin_pad, str(dev), prog.dtype, planar3)
         x = self._xbuf.get(xkey)
