@@ -346,7 +346,13 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     // The epilogue adds W_skip x to the outputs with 4 MFMAs per output vector: A = weights (row = cout, k lane h carries input
     // channels 4h..4h+3, one per k step), B = x (column = voxel, same channel split): both operands are one 16-byte load per lane.
     f32x4 wsk = {0.f, 0.f, 0.f, 0.f};
-    auto epi_prefetch = [&](const Unit& u, f32x4 (&resv)[2][4]) {
+    // The bias of a finished tile is requested here, with its skip tensor, and added in the epilogue (32 adds per tile).  Rounds 2-3
+    // carried it through the accumulators (the point (xi_z, xi_y) = (1, 1) has the coefficient 1 in every row of both output
+    // transforms) in four registers held across the loop; hipcc spilled exactly those in five of the eleven layouts, and a scratch
+    // reload is a vmcnt(0) behind everything in flight: -5 % at 16->32 @64^3, -2.7 % at 32->32 @64^3 for the <0,2> layout
+    // (profiles/r03_wino2d_and_small_level_experiments.txt section 9); no instantiation uses scratch now.
+    auto epi_prefetch = [&](const Unit& u, f32x4 (&resv)[2][4], f32x4& bias_e) {
+        bias_e = *reinterpret_cast<const f32x4*>(a.bpack + u.cb * 32 + ct * 16 + 4 * h);
         if constexpr (skc) {
             wsk = *reinterpret_cast<const f32x4*>(a.skip_w + (u.cb * 32 + ct * 16 + px) * 16 + 4 * h);
             const float* xb = a.res + (((((long long)u.b * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * 16);
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
 #pragma unroll
             for (int z = 0; z < 4; ++z) resv[r][z] = *reinterpret_cast<const f32x4*>(rb + z * rzstride + r * rystride + rvoff);
     };
-    auto epilogue = [&](const Unit& u, const f32x4 (&resv_all)[2][4]) {
+    auto epilogue = [&](const Unit& u, const f32x4 (&resv_all)[2][4], const f32x4& bias_e) {
         // uniform 64-bit base of the wave's first output row + a 32-bit per-lane offset (global_* saddr form); raw buffer
         // STORES with a scalar offset dropped data here, so stores and skip loads use plain global accesses
         const long long s00 = (((((long long)u.b * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * a.cout + u.cb * 32 + ct * 16);
@@ -415,6 +421,12 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
                 }
             }
         }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int z = 0; z < 4; ++z)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) out[r][z][c] += bias_e[c];
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (skc) {
 #pragma unroll
@@ -502,7 +514,6 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
     Unit unx = ucur;
     int cnx = 0, inx = 0;
     int step_index = 0;
-    f32x4 bias_next = *reinterpret_cast<const f32x4*>(a.bpack + ucur.cb * 32 + ct * 16 + 4 * h);   // bias of the tile whose first MFMA phase comes next
 
     // ---- MFMA phase of group GG: 18 groups (xi_z, dx) of 4 xi_y x 2 k steps; the workgroup's mid-phase barrier sits in front of
     // the first access to the second weight half.
@@ -626,12 +637,9 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         // ------------------------------ MFMA phase of step i = (ucur, ccur) ------------------------------
         W2_T(t0)
         if (ccur == 0) {
-            // The bias enters through the accumulators: the point (xi_z, xi_y) = (1, 1) has the coefficient 1 in every row of both
-            // output transforms (A^T of F(4,3): column 1 = (1,1,1,1); of F(2,3): column 1 = (1,1)), so starting that accumulator
-            // at b adds exactly b to all eight outputs and the epilogue carries no bias arithmetic (and no load to wait for).
+            // (the bias is added in the epilogue, see epi_prefetch)
 #pragma unroll
             for (int e = 0; e < 24; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc[1 * 4 + 1] = bias_next;        // loaded during the previous staging phase (prologue for the first tile)
         }
         if constexpr ((exp & 0x300) == 0) __builtin_amdgcn_s_setprio(3);          // production
         if constexpr ((exp & 0x300) == 0x200) __builtin_amdgcn_s_setprio(0);      // experiment: staging wave above the MFMA wave
@@ -646,21 +654,21 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         // tile, second half = the epilogue of a finished tile and the unit walk.
         const bool epi = ccur == chunks - 1;
         f32x4 resv[2][4];
+        f32x4 bias_e = {0.f, 0.f, 0.f, 0.f};
         commit(raw);
         // skip tensor of a finished tile: in flight across the barrier and the output transform (issued in front of the V-tile
         // transform it measured slower, 0.428 vs 0.415 ms: that transform then waits behind these loads for its input rows)
-        if (epi) epi_prefetch(ucur, resv);
+        if (epi) epi_prefetch(ucur, resv, bias_e);
         W2_T(t5)
         phase_barrier();                                          // mid-phase barrier
         W2_T(t6)
-        if (epi) epilogue(ucur, resv);
+        if (epi) epilogue(ucur, resv, bias_e);
 #ifdef SE_STAMP2D
         unsigned tb = 0;
         W2_T(tb)
         st[13] += tb - t6;
 #endif
         ucur = unx; ccur = cnx; icur = inx;
-        if (ccur == 0) bias_next = *reinterpret_cast<const f32x4*>(a.bpack + ucur.cb * 32 + ct * 16 + 4 * h);
         step_after(unx, cnx, inx);
         if (cnx == 0) fetch_setup(unx);                           // new unit (or, behind the last step, the same one again)
         if constexpr (GG == 1) fetch(raw, unx, cnx);              // group 1: input rows of step i+2 (group 0: inside its MFMA phase)
