@@ -17,6 +17,11 @@
  *   - activations are float32, channels-last: volumes are [B][Z][Y][X][C] ("NDHWC"; the reference's
  *     meshgrid order i,j,k of voxel_net_depth.py:117-121 is our Z,Y,X, flat voxel n = (i*G + j)*G + k),
  *     images are [B][H][W][C].
+ *
+ * Parity surface: every *_f32 / *_f64 entry point computes in the reference's arithmetic type and is covered by the
+ * parity tests.  NOT part of the parity surface (opt-in, reduced precision, never selected by se_conv3d_f32 and never
+ * part of bench.py's `value`): the *_bf16 entry points (bfloat16 storage, BASELINE configs[2]) and the three
+ * se_conv3d_split3_* / se_conv3d_k3_split3_f32 entry points (EXPERIMENTAL: float32 tensors, 16-bit-mantissa products).
  */
 #ifndef SCENEEGO_HIP_H
 #define SCENEEGO_HIP_H

@@ -114,17 +114,17 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
     const float* f_xb = a.in;
     unsigned f_voff = 0x80000000u;
     int f_gz0 = 0;
-    bool f_shift = false;
+    int f_shift = 0;       // channels-last: channels of the last chunk beyond cin_pad (0, 1 or 2): the load starts that many channels early
     const int f_rec_bytes = PLANAR ? dim * dim * dim * 12 : dim * dim * dim * a.cin_pad * 4;
     auto fetch_setup = [&](int k, int c) {
         const i32x4 e = utab[k];
         const int gy = e.z * S_TY - 3 + s_cy, gx = e.w * S_TX - 3 + s_cx;
         f_gz0 = e.y * S_TZ - 3;
         const bool okc = s_on && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim;
-        f_shift = !PLANAR && (c * 3 + 2 >= a.cin_pad);
+        f_shift = PLANAR ? 0 : max(0, c * 3 + 3 - a.cin_pad);
         const int b = __builtin_amdgcn_readfirstlane(e.x);
         f_xb = PLANAR ? a.in + ((long long)b * chunks + c) * dim * dim * dim * 3
-                      : a.in + (long long)b * dim * dim * dim * a.cin_pad + c * 3 - (f_shift ? 1 : 0);
+                      : a.in + (long long)b * dim * dim * dim * a.cin_pad + c * 3 - f_shift;
         f_voff = okc ? (unsigned)((gy * dim + gx) * (PLANAR ? 12 : a.cin_pad * 4)) : 0x80000000u;
     };
     auto fetch_one = [&](auto q_tag) {
@@ -134,11 +134,13 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f_xb), 0, zok ? f_rec_bytes : 0, 0x00020000);
         typedef float f32x3v __attribute__((ext_vector_type(3)));
         const f32x3v t = __builtin_bit_cast(f32x3v, __builtin_amdgcn_raw_buffer_load_b96(rs, (int)f_voff, z * (int)(f_zs * 4), 0));
-        const bool shift = f_shift;
+        const int shift = f_shift;
         if (PLANAR) {
             raw[q].x = t.x; raw[q].y = t.y; raw[q].z = t.z;
-        } else {
-            raw[q].x = shift ? t.y : t.x; raw[q].y = shift ? t.z : t.y; raw[q].z = shift ? 0.f : t.z;
+        } else {    // the record never reads past channel cin_pad - 1 (the next voxel's data, or the end of the tensor): slots beyond it are zero
+            raw[q].x = shift == 0 ? t.x : shift == 1 ? t.y : t.z;
+            raw[q].y = shift == 0 ? t.y : shift == 1 ? t.z : 0.f;
+            raw[q].z = shift == 0 ? t.z : 0.f;
         }
     };
     auto fetch = [&](int k, int c) {

@@ -10,6 +10,8 @@ On CPU (tests) the same code runs over ``gloo``.
 from __future__ import annotations
 
 import os
+import sys
+from datetime import timedelta
 
 import torch
 import torch.distributed as dist
@@ -21,8 +23,32 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_from_env(backend: str | None = None, device_type: str = "cuda"):
-    """Initialise ``torch.distributed`` from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*; returns (rank, world, device)."""
+def _pin_host_threads(local_rank: int, local_world: int):
+    """N dispatch loops on one host (about 170 launches per 10 ms step each) must not fight for cores: every rank takes a
+    contiguous share of the cores this process may use and keeps its intra-op pools inside it.  Returns (n_threads, cores)."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return torch.get_num_threads(), None
+    per = max(1, len(cores) // max(1, local_world))
+    mine = cores[(local_rank % max(1, local_world)) * per:][:per] or cores
+    if os.environ.get("SCENEEGO_PIN_CORES", "1") == "1" and local_world > 1:
+        try:
+            os.sched_setaffinity(0, mine)
+        except OSError:
+            mine = cores
+    n = max(1, min(len(mine), int(os.environ.get("SCENEEGO_RANK_THREADS", "4"))))
+    torch.set_num_threads(n)
+    return n, mine
+
+
+def init_from_env(backend: str | None = None, device_type: str = "cuda", timeout_s: float | None = None):
+    """Initialise ``torch.distributed`` from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*; returns (rank, world, device).
+
+    With more than one rank the launcher's MASTER_ADDR / MASTER_PORT are REQUIRED (no fixed default port: two jobs on one
+    host would meet on it), the process group is created with an explicit timeout (``SCENEEGO_DIST_TIMEOUT_S``, 120 s) and a
+    failure to form it ends the rank with exit code 4 and the backend's message - it is never retried by starting a new
+    process from a rank that has touched the GPU."""
     rank, local_rank, world = env_world()
     if device_type == "cuda":
         index = local_rank
@@ -30,20 +56,45 @@ def init_from_env(backend: str | None = None, device_type: str = "cuda"):
             # readiness runs on a box with fewer GPUs than ranks (tests): ranks share devices.  RCCL refuses two ranks on one
             # device, so such a run also sets SCENEEGO_DIST_BACKEND=gloo; everything else (sharding, stream ordering) is the N-GPU code
             index = local_rank % max(1, torch.cuda.device_count())
+        elif world > 1 and local_rank >= torch.cuda.device_count():
+            print(f"[sceneego dist] rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} HIP device(s) visible "
+                  f"(one rank per GPU; SCENEEGO_SHARE_GPU=1 + SCENEEGO_DIST_BACKEND=gloo for shared-device readiness runs)",
+                  file=sys.stderr, flush=True)
+            sys.exit(4)
         torch.cuda.set_device(index)
         device = torch.device("cuda", index)
     else:
         device = torch.device("cpu")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:
+            print(f"[sceneego dist] rank {rank}: WORLD_SIZE={world} but MASTER_PORT is not set - start the ranks with "
+                  f"torch.distributed.run (or `python bench.py --gpus N`, which does)", file=sys.stderr, flush=True)
+            sys.exit(4)
         backend = backend or os.environ.get("SCENEEGO_DIST_BACKEND") or None
         if backend is None:
             backend = "nccl" if device_type == "cuda" else "gloo"
         kw = {}
         if backend == "nccl":
             kw["device_id"] = device
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        timeout_s = float(os.environ.get("SCENEEGO_DIST_TIMEOUT_S", "120")) if timeout_s is None else timeout_s
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        threads, cores = _pin_host_threads(local_rank, local_world)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timedelta(seconds=timeout_s), **kw)
+            if backend == "nccl":
+                # form the ring NOW, under the timeout, instead of inside the first timed collective
+                probe = torch.zeros(1, device=device)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize(device)
+        except Exception as e:       # RCCL / store errors: say which rank, which device, what the backend said - and stop
+            print(f"[sceneego dist] rank {rank}/{world} on {device}: {backend} process group failed within {timeout_s:.0f} s: "
+                  f"{type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            sys.exit(4)
+        if os.environ.get("SCENEEGO_DIST_QUIET") != "1":
+            print(f"[sceneego dist] rank {rank}/{world} device {device} backend {dist.get_backend()} "
+                  f"master {os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']} host threads {threads}"
+                  + (f" cores {cores[0]}-{cores[-1]}" if cores else ""), file=sys.stderr, flush=True)
     return rank, world, device
 
 
@@ -99,3 +150,21 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_values(value: float, device) -> list:
+    """``value`` of every rank, in rank order, on every rank ([value] without a process group)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    on = "cpu" if dist.get_backend() == "gloo" else device
+    t = torch.tensor([value], dtype=torch.float64, device=on)
+    out = torch.empty(dist.get_world_size(), dtype=torch.float64, device=on)
+    dist.all_gather_into_tensor(out, t)
+    return [float(v) for v in out.tolist()]
+
+
+def describe() -> dict:
+    """What the collective really ran on: {"world_size", "backend"} of the live process group (backend "nccl" = RCCL on ROCm)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"world_size": 1, "backend": None}
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend()}

@@ -59,7 +59,14 @@ class PipelinedForward:
             raise RuntimeError("PipelinedForward needs the module on a HIP device")
         self.nets = [net]
         for _ in range(n_streams - 1):
-            rep = copy.deepcopy(net)
+            # the compiled state (packed V2V program with its split-K workspace, folded backbone, graphs, input caches) is per replica
+            # and rebuilt below: detach it for the copy instead of duplicating several hundred MB that would be dropped right after
+            held = (net.volume_net._program, net._folded, net._graphs, net._xbuf)
+            net.volume_net._program, net._folded, net._graphs, net._xbuf = None, None, {}, {}
+            try:
+                rep = copy.deepcopy(net)
+            finally:
+                net.volume_net._program, net._folded, net._graphs, net._xbuf = held
             for a, b in zip(rep.parameters(), net.parameters()):
                 a.data = b.data                                   # alias, do not duplicate
             for a, b in zip(rep.buffers(), net.buffers()):

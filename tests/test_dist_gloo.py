@@ -120,3 +120,46 @@ def test_bench_refuses_world_size_mismatch():
                        timeout=300)
     assert r.returncode != 0
     assert "refusing" in r.stderr
+
+
+def test_eight_ranks_gather_order_and_thread_pinning():
+    """configs[3] runs 8 ranks per node: the same init + sharding + ONE all-gather with world_size 8 (gloo), every rank pinned to
+    its own share of the host cores."""
+    world, per_rank = 8, 1
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_fake_forward_worker, args=(world, _free_port(), per_rank, results), nprocs=world, join=True)
+    res = dict(results)
+    assert sorted(res) == list(range(world))
+    for r in range(1, world):
+        assert torch.equal(res[r], res[0])
+    assert tuple(res[0].shape) == (world * per_rank, 15, 3)
+    assert len({tuple(res[0][i].flatten().tolist()) for i in range(world)}) == world      # eight different shards, in rank order
+    g = torch.Generator().manual_seed(1234 + 5)
+    img = torch.randn((per_rank, 3, 8, 8), generator=g)
+    assert torch.equal(res[0][5, 0], img.mean(dim=(2, 3))[0])
+
+
+def test_init_without_master_port_exits_with_a_message():
+    """No fixed default rendezvous port: a rank started with WORLD_SIZE > 1 and no MASTER_PORT stops with exit code 4."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_PORT", "MASTER_ADDR")}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2")
+    code = ("import sys; sys.path.insert(0, %r); from sceneego_amd import dist as d; d.init_from_env(backend='gloo', device_type='cpu')"
+            % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 4, (r.returncode, r.stderr[-300:])
+    assert "MASTER_PORT" in r.stderr
+
+
+def test_init_timeout_reports_and_exits():
+    """A ring that cannot form (the peer never arrives) ends the rank with exit code 4 and the backend's message within the
+    configured timeout instead of hanging."""
+    import subprocess
+    env = dict(os.environ, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               SCENEEGO_DIST_TIMEOUT_S="3")
+    code = ("import sys; sys.path.insert(0, %r); from sceneego_amd import dist as d; d.init_from_env(backend='gloo', device_type='cpu')"
+            % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 4, (r.returncode, r.stderr[-300:])
+    assert "process group failed" in r.stderr

@@ -201,6 +201,9 @@ def test_v2v_stagewise_vs_oracle(net64, oracle_constants):
     l_err = float((lg - taps["logits"]).abs().max())
     assert l_err < 1e-4 * scale, (l_err, scale)
     assert float((kp.cpu() - oj).abs().max()) <= JOINT_TOL
+    # ... and against the reference formula's own float32 evaluation on this host (einsum noise of the host included): same bar
+    oj32, _ = O.integrate(taps["logits"], const.coord, softmax=True)
+    assert float((kp.cpu() - oj32).abs().max()) <= JOINT_TOL
     assert float((vols.cpu() - ovols).abs().max()) <= 2e-3 * float(ovols.max())
 
 
@@ -331,6 +334,8 @@ def test_scene_volumes_from_dataset_side_voxeliser(net64, oracle_constants):
     sd = synthetic_state_dict()
     oj, _, _ = O.forward(sd, c, img, None, scene_volumes=want, accumulate64=True)
     assert float((kp.cpu() - oj).abs().max()) <= JOINT_TOL
+    oj32, _, _ = O.forward(sd, c, img, None, scene_volumes=want)          # the reference's float32 soft-argmax on this host: same bar
+    assert float((kp.cpu() - oj32).abs().max()) <= JOINT_TOL
 
 
 def test_planar3_input_layout_matches_channels_last(net64):
