@@ -54,6 +54,8 @@ K3_ALGOS = {
     0: ("conv3d_tiled_kernel / conv3d_direct_kernel: direct implicit GEMM", 1.0),
     1: ("conv3d_k3_wino43pp_kernel: 1-D Winograd F(4,3) along z, ping-pong wave groups", 0.5),
     2: ("conv3d_k3_wino2d_kernel: 2-D Winograd F(4,3) x F(2,3) along z, y; register accumulators over all input channels", 1.0 / 3.0),
+    3: ("conv3d_k3_wino44pp_kernel: 2-D Winograd F(4,3) x F(4,3) along z, y, ping-pong wave groups, LDS-DMA weight stream; register "
+        "accumulators over all input channels", 0.25),
 }
 
 
@@ -387,7 +389,7 @@ def main():
     if key in launches:
         ms = launches[key]
         avg_ms = sum(ms) / len(ms)
-        algo = int(lib.se_conv3d_f32_algo(G, 32, 32, 3))
+        algo = int(lib.se_conv3d_f32_variant(args.batch, G, 32, 32, 3))       # the kernel a launch of this batch really runs on
         kname, exec_ratio = K3_ALGOS.get(algo, K3_ALGOS[0])
         direct_flop = 2.0 * args.batch * G ** 3 * 27 * 32 * 32          # direct-convolution FLOP of one launch
         exec_flop = direct_flop * exec_ratio                            # FLOP the matrix cores execute
@@ -442,7 +444,7 @@ def main():
     if args.dump_launch_order and prof:
         order = _lib.last_launch_order[:len(_lib.last_launch_order) // psteps]
         with open(args.dump_launch_order, "w") as f:
-            json.dump([list(k) + [int(lib.se_conv3d_f32_algo(k[4], k[2], k[3], k[1])) if k[0] == "conv3d" else -1] for k in order], f)
+            json.dump([list(k) + [int(lib.se_conv3d_f32_variant(args.batch, k[4], k[2], k[3], k[1])) if k[0] == "conv3d" else -1] for k in order], f)
     if args.dump_kernel_events:
         for k in sorted(launches, key=lambda k: -sum(launches[k])):
             v = launches[k]

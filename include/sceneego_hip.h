@@ -277,6 +277,10 @@ int se_bias_act_nchw_bf16(const se_bf16* x, const se_bf16* bias, const se_bf16* 
  *   7 1-D Winograd along z for the 7x7x7 front layer: F(6,7) (12/42 of the direct products) when dim % 16 == 0, else F(4,7) (10/28).
  * Pure function of the arguments; no device access. */
 int se_conv3d_f32_algo(int dim, int cin, int cout, int ksize);
+/* Which kernel a 3x3x3 launch of `batch` samples really runs on: se_conv3d_f32_algo()'s value, except 3 = the F(4,3) x F(4,3)
+ * ping-pong kernel (a member of the 2-D Winograd family: every layout / flag / fused form of algo 2 applies; it executes 1/4 of the
+ * direct convolution's MFMAs, algo 2 executes 1/3).  bench.py prices its roofline with it. */
+int se_conv3d_f32_variant(int batch, int dim, int cin, int cout, int ksize);
 
 #ifdef SE_DEVTOOLS
 /* Development builds only (csrc/build.sh --devtools; absent from the production library): A/B kernel selection for

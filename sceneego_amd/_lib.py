@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -62,6 +62,7 @@ SIGNATURES = {
     "se_preprocess_image_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "se_bias_act_nchw_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_conv3d_f32_algo": (_i, [_i, _i, _i, _i]),
+    "se_conv3d_f32_variant": (_i, [_i, _i, _i, _i, _i]),
     "se_conv3d_split3_packed_elems": (_ll, [_i, _i]),
     "se_conv3d_split3_pack": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "se_conv3d_k3_split3_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

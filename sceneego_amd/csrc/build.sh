@@ -21,13 +21,14 @@ newer() {  # source $1, a shared header or (development builds) a devtools/ incl
   return 1
 }
 OBJS=()
-for f in voxelize gather softargmax conv3d conv3d_tiled conv3d_wino conv3d_wino2d conv3d_wino67 conv3d_bf16 conv3d_bf16_tiled conv3d_split; do
+for f in voxelize gather softargmax conv3d conv3d_tiled conv3d_wino conv3d_wino2d conv3d_wino44pp conv3d_wino67 conv3d_bf16 conv3d_bf16_tiled conv3d_split; do
   [ -f $f.hip ] || { echo "build.sh: source $f.hip is missing" >&2; exit 1; }
   OBJS+=($OBJ/$f.o)
   extra=""
   [ "$f" = voxelize ] && extra="-ffp-contract=off"
   # no SLP packing of float32 arithmetic into v_pk_*_f32: packed VALU beside an MFMA stream is an anti-lever (see commit() there)
   [ "$f" = conv3d_wino2d ] && extra="-fno-slp-vectorize"
+  [ "$f" = conv3d_wino44pp ] && extra="-fno-slp-vectorize"
   if newer $f.hip $OBJ/$f.o; then
     hipcc $FLAGS $extra -c $f.hip -o $OBJ/$f.o &
     pids+=($!)

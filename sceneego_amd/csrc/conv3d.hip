@@ -868,7 +868,7 @@ int launch_direct(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int se_abi_version(void) { return 10; }
+extern "C" int se_abi_version(void) { return 11; }
 
 // Mirrors the dispatch of se_conv3d_f32 -> se_conv3d_tiled_try -> se_conv3d_wino_try / se_conv3d_k7_wino_try for the
 // default channels-last call (no SE_EPI_OUT_PLANAR / SE_EPI_RES_POST_RELU flags).
@@ -877,6 +877,15 @@ extern "C" int se_conv3d_f32_algo(int dim, int cin, int cout, int ksize) {
     if (ksize == 3 && dim >= 16 && (dim & 7) == 0 && (cout & 31) == 0 && (cin & 15) == 0) return 1;
     if (ksize == 7 && dim >= 16 && (dim & 7) == 0 && cout == 16) return 7;
     return 0;
+}
+
+// Which 3x3x3 kernel a launch of `batch` samples runs on: se_conv3d_f32_algo's value, except 3 = the F(4,3) x F(4,3) ping-pong kernel
+// (conv3d_wino44pp.hip; a member of the 2-D Winograd family: same layouts, flags and fused forms as algo 2).
+bool se_conv3d_wino44pp_shape(int batch, int dim, int cout);      // conv3d_wino44pp.hip
+extern "C" int se_conv3d_f32_variant(int batch, int dim, int cin, int cout, int ksize) {
+    const int algo = se_conv3d_f32_algo(dim, cin, cout, ksize);
+    if (algo == 2 && g_variant != 64 && se_conv3d_wino44pp_shape(batch, dim, cout)) return 3;
+    return algo;
 }
 
 static long long packed_elems_a(int cout, int cin_pad, int ksize, int transposed) {
@@ -892,9 +901,7 @@ extern "C" long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, in
     if (!transposed && ksize == 3 && cout % 32 == 0)
         n += (long long)(cin_pad / 16) * (cout / 32) * (SE_WINO_CHUNK_FLOATS + SE_WINO43_CHUNK_FLOATS);
     if (!transposed && ksize == 3 && cout % 32 == 0) n += (long long)(cin_pad / 8) * (cout / 32) * SE_WINO2D_CHUNK_FLOATS;   // section G
-#ifdef SE_DEVTOOLS
-    if (!transposed && ksize == 3 && cout % 32 == 0) n += (long long)(cin_pad / 4) * (cout / 32) * SE_WINO44_CHUNK_FLOATS;   // section I (last; development builds)
-#endif
+    if (!transposed && ksize == 3 && cout % 32 == 0) n += (long long)(cin_pad / 4) * (cout / 32) * SE_WINO44_CHUNK_FLOATS;   // section I (last)
     return n;
 }
 
@@ -920,23 +927,15 @@ extern "C" int se_conv3d_pack_f32(const float* w, const float* b, const float* g
     long long total_main = total;
     if (!transposed && ksize == 7 && cout <= 16) total_main -= (long long)((cin_pad + 2) / 3) * (SE_K7F_CHUNK_FLOATS + SE_K7H_CHUNK_FLOATS);
     const long long n_g = (!transposed && ksize == 3 && cout % 32 == 0) ? (long long)(cin_pad / 8) * (cout / 32) * SE_WINO2D_CHUNK_FLOATS : 0;
-#ifdef SE_DEVTOOLS
     const long long n_i = n_g ? (long long)(cin_pad / 4) * (cout / 32) * SE_WINO44_CHUNK_FLOATS : 0;
-#else
-    const long long n_i = 0;
-#endif
     total_main -= n_g + n_i;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, se_stream(stream), w, b,
                        gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_pad, taps, transposed, total_a, total_main);
     SE_CHECK_LAUNCH();
     if (n_g) {
         const int rc = se_conv3d_pack_wino2d(w, gamma, var, eps, wpack + total_main, cout, cin, cin_pad, se_stream(stream));
-#ifdef SE_DEVTOOLS
         if (rc) return rc;
         return se_conv3d_pack_wino44(w, gamma, var, eps, wpack + total_main + n_g, cout, cin, cin_pad, se_stream(stream));
-#else
-        return rc;
-#endif
     }
     if (total_main != total) {
         const long long nf = (long long)((cin_pad + 2) / 3) * SE_K7F_CHUNK_FLOATS, nh = total - total_main - nf;
@@ -982,9 +981,7 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
     a.wpack_g = nullptr;
     if (ksize == 3 && cout % 32 == 0) a.wpack_g = a.wpack_e + (long long)(cin_pad / 16) * (cout / 32) * SE_WINO43_CHUNK_FLOATS;
     a.wpack_i = nullptr;
-#ifdef SE_DEVTOOLS
     if (ksize == 3 && cout % 32 == 0) a.wpack_i = a.wpack_g + (long long)(cin_pad / 8) * (cout / 32) * SE_WINO2D_CHUNK_FLOATS;
-#endif
     a.pool_out = pool_out;
     a.skip_w = skip_w;
     if (!skip_w && (flags & SE_EPI_SKIPCONV16)) return SE_ERR_BAD_ARG;

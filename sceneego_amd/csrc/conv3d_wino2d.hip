@@ -746,6 +746,8 @@ int se_conv3d_pack_wino2d(const float* w, const float* gamma, const float* var, 
     return 0;
 }
 
+bool se_conv3d_wino44pp_takes(const ConvArgs& a, int batch);                  // conv3d_wino44pp.hip: F(4,3) x F(4,3), ping-pong form
+int se_conv3d_wino44pp_launch(const ConvArgs& a, int batch, hipStream_t s);
 #ifdef SE_DEVTOOLS
 bool se_conv3d_wino44_takes(const ConvArgs& a);                               // conv3d_wino44.hip (development builds)
 int se_conv3d_wino44_launch(const ConvArgs& a, int batch, hipStream_t s);
@@ -760,6 +762,9 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
     // experiment (round 3, se_debug_set_variant(63)): F(4,3) x F(4,3), lockstep form with an LDS-DMA weight stream (conv3d_wino44.hip)
     if (g_variant == 63 && se_conv3d_wino44_takes(a)) return se_conv3d_wino44_launch(a, batch, s);
 #endif
+    // round 4: the 64^3 / 32^3 levels run on the F(4,3) x F(4,3) ping-pong kernel (1/4 of the direct MFMAs; this kernel: 1/3);
+    // development builds: se_debug_set_variant(64) keeps them here (A/B)
+    if (g_variant != 64 && g_variant < 41 && se_conv3d_wino44pp_takes(a, batch)) return se_conv3d_wino44pp_launch(a, batch, s);
     const int tx = dim / 16, ty = dim / 8, tz = dim / 4;
     const long long total_tiles = (long long)batch * tx * ty * tz;
     const long long n_units = total_tiles * (a.cout / 32);

@@ -424,50 +424,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44_kernel(ConvArgs a, const
 
 }  // namespace
 
-// Section I of the packed 3x3x3 weights (appended by se_conv3d_pack_f32): per (32-cout block cb, 4-channel chunk)
-//   [q 9][dx 3][ct 2][lane 64][j 4] = U[xi = 4 q + j][dx] of cout cb*32 + ct*16 + (lane & 15), cin chunk*4 + (lane >> 4);
-//   xi = 6 xi_y + xi_z;  U = (G43 (x) G43) g over (dz, dy), times the folded BatchNorm scale.
-__global__ void pack_k3_wino44_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
-                                      float eps, float* __restrict__ out, int cout, int cin, int cin_pad, long long total) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    const int j = (int)(t & 3);
-    const int lane = (int)((t >> 2) & 63);
-    long long r = t >> 8;
-    const int ct = (int)(r % 2); r /= 2;
-    const int dx = (int)(r % 3); r /= 3;
-    const int q = (int)(r % 9); r /= 9;
-    const int chunks = cin_pad / 4;
-    const int chunk = (int)(r % chunks);
-    const int cb = (int)(r / chunks);
-    const int xi = 4 * q + j, xy = xi / 6, xz = xi % 6;
-    const int co = cb * 32 + ct * 16 + (lane & 15);
-    const int ci = chunk * 4 + (lane >> 4);
-    float v = 0.f;
-    if (co < cout && ci < cin) {
-        const float sc = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
-        const float* wp = w + ((size_t)co * cin + ci) * 27 + dx;
-        // G of F(4,3), points {0, 1, -1, 2, -2, inf}
-        const float g43[6][3] = {{0.25f, 0.f, 0.f},          {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
-                                 {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
-        double u = 0.0;
-#pragma unroll
-        for (int kz = 0; kz < 3; ++kz)
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) u += (double)g43[xz][kz] * (double)g43[xy][ky] * (double)wp[kz * 9 + ky * 3];
-        v = (float)(u * (double)sc);
-    }
-    out[t] = v;
-}
-
-int se_conv3d_pack_wino44(const float* w, const float* gamma, const float* var, float eps, float* out, int cout, int cin,
-                          int cin_pad, hipStream_t s) {
-    const long long total = (long long)(cout / 32) * (cin_pad / 4) * SE_WINO44_CHUNK_FLOATS;
-    hipLaunchKernelGGL(pack_k3_wino44_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, gamma, var, eps, out, cout,
-                       cin, cin_pad, total);
-    SE_CHECK_LAUNCH();
-    return 0;
-}
+// (section I of the packed weights is written by conv3d_wino44pp.hip, the production form of this experiment)
 
 // Shapes / flag sets this kernel takes (the caller, se_conv3d_wino2d_try, has checked se_wino2d_shape_ok and cin_pad == cin):
 // no pooled output, no fused skip convolution, dim >= 32 (at 16^3 a batch of 8 has only 128 tiles of 8 x 8 x 16).

@@ -47,8 +47,12 @@ def test_pure_host_entry_points():
     # the 2-D Winograd family (2) is reported exactly for the shapes its launcher takes: 32-bit offsets inside one sample
     assert lib.se_conv3d_f32_algo(128, 32, 32, 3) == 2 and lib.se_conv3d_f32_algo(256, 32, 32, 3) != 2
     assert lib.se_conv3d_f32_algo(256, 8, 32, 3) != 2 and lib.se_conv3d_f32_algo(64, 36, 32, 3) != 2
+    # which kernel a launch runs on: 3 = F(4,3) x F(4,3) ping-pong at the 64^3 / 32^3 levels, 2 = F(4,3) x F(2,3) at 16^3
+    assert lib.se_conv3d_f32_variant(8, 64, 32, 32, 3) == 3 and lib.se_conv3d_f32_variant(8, 16, 128, 128, 3) == 2
+    assert lib.se_conv3d_f32_variant(8, 64, 33, 16, 7) == 7 and lib.se_conv3d_f32_variant(1, 64, 32, 32, 3) == 3
     # packed weight sizes: taps * cin_pad/16 * ceil(cout/16) * 256 floats
-    assert lib.se_conv3d_packed_elems(32, 32, 3, 0) == 27 * 2 * 2 * 256 + 2 * 9 * 4 * 2 * 256 + 2 * 9 * 6 * 2 * 256 + 4 * 24 * 3 * 2 * 128   # + F(2,3), F(4,3), F(4,3)xF(2,3)
+    assert lib.se_conv3d_packed_elems(32, 32, 3, 0) == 27 * 2 * 2 * 256 + 2 * 9 * 4 * 2 * 256 + 2 * 9 * 6 * 2 * 256 + 4 * 24 * 3 * 2 * 128 \
+        + 8 * 9 * 3 * 2 * 256   # + F(2,3), F(4,3), F(4,3)xF(2,3), F(4,3)xF(4,3) (section I: 8 four-channel chunks of 55,296 B)
     assert lib.se_conv3d_packed_elems(15, 32, 1, 0) == 1 * 2 * 1 * 256
     assert lib.se_conv3d_packed_elems(16, 48, 7, 0) == 343 * 3 * 256 + 12 * 86 * 256 + 12 * 13 * 8 * 256 + 16 * 13 * 10 * 64 * 3 + 16 * 37 * 64 * 12   # sections A, B, D, F (F(4,7): 3-channel chunks), H (F(6,7))
     assert lib.se_conv3d_packed_elems(64, 128, 2, 1) == 8 * 8 * 4 * 256

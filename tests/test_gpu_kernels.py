@@ -783,10 +783,10 @@ def test_conv7_front_layer_64_planar3_vs_torch():
     yy = (pos[:, 1, None] + ar)[:, None, :, None]
     xx = (pos[:, 2, None] + ar)[:, None, None, :]
     patches = xp[bi[:, None, None, None], :, zz, yy, xx]                         # [n,7,7,7,33]
-    w64 = conv.weight.double().permute(2, 3, 4, 1, 0)                            # [7,7,7,33,16]
-    y64 = torch.einsum("nzyxc,zyxco->no", patches, w64) + conv.bias.double()
-    sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).double()
-    y64 = F.relu((y64 - bn.running_mean.double()) * sc + bn.bias.double())
+    cw, cb = conv.weight.detach().cpu().double(), conv.bias.detach().cpu().double()       # (the modules moved to the device above)
+    bw, bb, bm, bv = (t.detach().cpu().double() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    y64 = torch.einsum("nzyxc,zyxco->no", patches, cw.permute(2, 3, 4, 1, 0)) + cb
+    y64 = F.relu((y64 - bm) * (bw / torch.sqrt(bv + bn.eps)) + bb)
     got_s = got[bi, :, pos[:, 0], pos[:, 1], pos[:, 2]].double()
     want_s = want[bi, :, pos[:, 0], pos[:, 1], pos[:, 2]].double()
     e_hip, e_cpu = float((got_s - y64).abs().max()), float((want_s - y64).abs().max())
