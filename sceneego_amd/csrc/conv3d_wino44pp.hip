@@ -44,13 +44,16 @@ __device__ __forceinline__ void for_each_c(F&& f, std::integer_sequence<int, S..
     (f(std::integral_constant<int, S>{}), ...);
 }
 
-constexpr int P_QA = 5;                                  // half A = xi quads 0..4, half B = quads 5..8
+#ifndef SE_K44P_QA
+#define SE_K44P_QA 4
+#endif
+constexpr int P_QA = SE_K44P_QA;                         // half A = xi quads 0..P_QA-1, half B = the rest (4 | 5: the slot holds 5 quads)
 constexpr int P_HALF_A = P_QA * 3 * 2 * 256;             // 7680 floats
 constexpr int P_HALF_B = (9 - P_QA) * 3 * 2 * 256;       // 6144 floats
 static_assert(P_HALF_A + P_HALF_B == SE_WINO44_CHUNK_FLOATS, "chunk = two halves");
-constexpr int P_SLOT = P_HALF_A;                         // floats per weight slot
-constexpr int P_NA = P_HALF_A / 256;                     // wave-instructions (64 lanes x 16 B) of half A: 30
-constexpr int P_NB = P_HALF_B / 256;                     // 24
+constexpr int P_SLOT = P_HALF_A > P_HALF_B ? P_HALF_A : P_HALF_B;      // floats per weight slot
+constexpr int P_NA = P_HALF_A / 256;                     // wave-instructions (64 lanes x 16 B) of half A
+constexpr int P_NB = P_HALF_B / 256;
 constexpr int P_RS = 148;                                // floats per x record of V: 4 channels x 36 xi + 4 pad (37 x 16 B: odd -> bank spread)
 constexpr int P_VT = 18 * P_RS;                          // one (G, zt) tile of V
 constexpr int P_V_FLOATS = 4 * P_VT;                     // 10,656 floats
@@ -60,6 +63,21 @@ constexpr int P_GROUPS = 27;                             // (quad, dx) groups of
 constexpr int P_GA = P_QA * 3;                           // groups that read half A: 15
 constexpr int P_DMA_A = (P_NA + 3) / 4;                  // LDS-DMA instructions per wave of a group for half A: 8
 constexpr int P_DMA_B = (P_NB + 3) / 4;                  // 6
+
+#ifndef SE_K44P_EXP      // attribution builds only (results wrong): 1 no weight DMAs, 2 no input-row loads, 4 no transform passes, 8 no epilogue,
+#define SE_K44P_EXP 0    // 16 no skip-tensor loads, 32 no output stores
+#endif
+
+#ifndef SE_K44P_EPRIO
+#define SE_K44P_EPRIO 0      // s_setprio of a staging wave while it runs a tile end (its SIMD partner, the other group's MFMA wave, runs at 3)
+#endif
+#ifndef SE_K44P_PK
+#define SE_K44P_PK 1         // 1: the output transform of the epilogue on whole f32x4 vectors (v_pk_add_f32 / v_pk_fma_f32)
+#endif
+
+#ifndef SE_K44P_PKT
+#define SE_K44P_PKT 0        // 1: the per-step B^T transforms on float pairs as well
+#endif
 
 #ifdef SE_STAMP44P   // cycle stamps (development builds with -DSE_STAMP44P; tools/stamp_k44p.py)
 #define TP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
@@ -76,6 +94,31 @@ struct UnitP {
 // F(4,3) B^T (points 0, +-1, +-2, inf) on six values, per component (scalar float arithmetic: packed VALU beside the partner
 // wave's MFMA stream is an anti-lever, see conv3d_wino2d.hip)
 __device__ __forceinline__ void bt43p(const f32x4 (&d)[6], f32x4 (&o)[6]) {
+    if (SE_K44P_PKT) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            f2 v[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = hf ? (f2){d[i].z, d[i].w} : (f2){d[i].x, d[i].y};
+            const f2 c4 = {4.f, 4.f}, cm5 = {-5.f, -5.f}, cm4 = {-4.f, -4.f}, c2 = {2.f, 2.f}, cm2 = {-2.f, -2.f};
+            f2 r[6];
+            r[0] = __builtin_elementwise_fma(c4, v[0], __builtin_elementwise_fma(cm5, v[2], v[4]));
+            r[5] = __builtin_elementwise_fma(c4, v[1], __builtin_elementwise_fma(cm5, v[3], v[5]));
+            const f2 e1 = __builtin_elementwise_fma(cm4, v[2], v[4]), o1 = __builtin_elementwise_fma(cm4, v[1], v[3]);
+            r[1] = e1 + o1;
+            r[2] = e1 - o1;
+            const f2 e2 = v[4] - v[2], o2 = v[3] - v[1];
+            r[3] = __builtin_elementwise_fma(c2, o2, e2);
+            r[4] = __builtin_elementwise_fma(cm2, o2, e2);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                if (hf) { o[i].z = r[i].x; o[i].w = r[i].y; }
+                else { o[i].x = r[i].x; o[i].y = r[i].y; }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c], d4 = d[4][c], d5 = d[5][c];
@@ -92,6 +135,23 @@ __device__ __forceinline__ void bt43p(const f32x4 (&d)[6], f32x4 (&o)[6]) {
 // F(4,3) A^T on six values -> four outputs
 __device__ __forceinline__ void at43p(const f32x4& m0, const f32x4& m1, const f32x4& m2, const f32x4& m3, const f32x4& m4, const f32x4& m5,
                                       f32x4 (&y)[4]) {
+    if (SE_K44P_PK) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const f2 a0 = hf ? (f2){m0.z, m0.w} : (f2){m0.x, m0.y}, a1 = hf ? (f2){m1.z, m1.w} : (f2){m1.x, m1.y},
+                     a2 = hf ? (f2){m2.z, m2.w} : (f2){m2.x, m2.y}, a3 = hf ? (f2){m3.z, m3.w} : (f2){m3.x, m3.y},
+                     a4 = hf ? (f2){m4.z, m4.w} : (f2){m4.x, m4.y}, a5 = hf ? (f2){m5.z, m5.w} : (f2){m5.x, m5.y};
+            const f2 s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
+            const f2 y0 = (a0 + s12) + s34;
+            const f2 y1 = __builtin_elementwise_fma((f2){2.f, 2.f}, d34, d12);
+            const f2 y2 = __builtin_elementwise_fma((f2){4.f, 4.f}, s34, s12);
+            const f2 y3 = __builtin_elementwise_fma((f2){8.f, 8.f}, d34, d12) + a5;
+            if (hf) { y[0].z = y0.x; y[0].w = y0.y; y[1].z = y1.x; y[1].w = y1.y; y[2].z = y2.x; y[2].w = y2.y; y[3].z = y3.x; y[3].w = y3.y; }
+            else { y[0].x = y0.x; y[0].y = y0.y; y[1].x = y1.x; y[1].y = y1.y; y[2].x = y2.x; y[2].y = y2.y; y[3].x = y3.x; y[3].y = y3.y; }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float s12 = m1[c] + m2[c], d12 = m1[c] - m2[c], s34 = m3[c] + m4[c], d34 = m3[c] - m4[c];
@@ -178,7 +238,13 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
     // The task coordinates are recomputed from the thread index where they are used (a few VALU outside the MFMA phase): kept in
     // registers across the loop they are spilled, and a scratch reload waits for every older vector-memory operation.
     const bool p1_on = tg < 180, p2_on = tg < 216;
-    auto opaque_tg = [&]() { int t = tg; asm volatile("" : "+v"(t)); return t; };
+#ifndef SE_K44P_KEEP
+#define SE_K44P_KEEP 1       // 1: the pass-1 / pass-2 LDS offsets live in three registers; 0: recomputed from the thread index per step
+#endif
+    auto opaque_tg = [&]() { int t = tg; if (!SE_K44P_KEEP) asm volatile("" : "+v"(t)); return t; };
+    const int k_p1 = ((min(tg, 179) / 18) * 18 + min(tg, 179) % 18) * 4;                                    // pass 1: T offset of (z1, x1)
+    const int k_p2s = ((((min(tg, 215) / 18) % 6) * 10 + 4 * (min(tg, 215) / 108)) * 18 + min(tg, 215) % 18) * 4;   // pass 2: T offset
+    const int k_p2d = (G * 2 + min(tg, 215) / 108) * P_VT + (min(tg, 215) % 18) * P_RS + ((min(tg, 215) / 18) % 6) * 6;   // pass 2: V offset
 
     // ---- input rows of the next step: raw buffer loads.  Everything uniform - sample, chunk, the ROW (the six rows of a group
     // are the same for all of its lanes) - sits in the descriptor base, built with scalar instructions; a row outside the volume is
@@ -205,13 +271,14 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
         const bool ok = (unsigned)gy < (unsigned)dim;
         const float* p = row_base(u, c4) + (long long)gy * dim * vfl;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, ok ? (int)in_bytes : 0, 0x00020000);
+        if (SE_K44P_EXP & 2) { raw[r] = (f32x4){(float)ok, 0.f, 0.f, 0.f}; return; }
         raw[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)f_voff, 0, 0));
     };
     auto pass1 = [&](float* tdst) {
-        if (!p1_on) return;
+        if (!p1_on || (SE_K44P_EXP & 4)) return;
         const int t = opaque_tg();
         const int x1 = t % 18, z1 = t / 18;
-        float* dst = tdst + (z1 * 18 + x1) * 4;                                       // + xi_y * 720
+        float* dst = tdst + (SE_K44P_KEEP ? k_p1 : (z1 * 18 + x1) * 4);               // + xi_y * 720
         f32x4 o[6];
         bt43p(raw, o);
 #pragma unroll
@@ -219,11 +286,11 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto pass2 = [&](const float* tsrc) {
-        if (!p2_on) return;
+        if (!p2_on || (SE_K44P_EXP & 4)) return;
         const int t = opaque_tg();
         const int x2 = t % 18, xy2 = (t / 18) % 6, zt2 = t / 108;
-        const float* src = tsrc + ((xy2 * 10 + 4 * zt2) * 18 + x2) * 4;               // + s * 72 (z slab)
-        float* vdst = vt + (G * 2 + zt2) * P_VT + x2 * P_RS + xy2 * 6;                // + channel * 36
+        const float* src = tsrc + (SE_K44P_KEEP ? k_p2s : ((xy2 * 10 + 4 * zt2) * 18 + x2) * 4);      // + s * 72 (z slab)
+        float* vdst = vt + (SE_K44P_KEEP ? k_p2d : (G * 2 + zt2) * P_VT + x2 * P_RS + xy2 * 6);     // + channel * 36
         f32x4 d[6], o[6];
 #pragma unroll
         for (int s = 0; s < 6; ++s) d[s] = *reinterpret_cast<const f32x4*>(src + s * 72);
@@ -252,6 +319,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
         const float* sp = src + piece * 256;        // uniform: the per-lane part of every LDS-DMA address is the same lane * 16 bytes
         const unsigned dst = __builtin_amdgcn_readfirstlane(
             (unsigned)(__UINTPTR_TYPE__)((float __attribute__((address_space(3)))*)(region + piece * 256)));      // LDS byte address
+        if (SE_K44P_EXP & 1) return;
         const int l16 = lane16;                    // (asm operands do not capture: name a local of the lambda)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(l16), "s"(sp));
     };
@@ -312,7 +380,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
         int l = lane;
         asm volatile("" : "+v"(l));
         const int r_lane = skc ? (l & 15) * 16 + 4 * (l >> 4) : lane_off(res_oct);
-        const bool on = skc || use_res;
+        const bool on = (skc || use_res) && !(SE_K44P_EXP & 16);
         const auto rs = __builtin_amdgcn_make_buffer_rsrc((float*)rb, 0, on ? 0x7fffffff : 0, 0x00020000);
 #pragma unroll
         for (int y = 0; y < 4; ++y)
@@ -365,7 +433,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], relu_lo);
-                *reinterpret_cast<gf32x4*>(ob + z * o_zs + y * o_ys + o_lane) = v;
+                if (!(SE_K44P_EXP & 32) || v.x == 12345.f) *reinterpret_cast<gf32x4*>(ob + z * o_zs + y * o_ys + o_lane) = v;
                 if constexpr (pool) acc[y * 6 + z] = v;      // (acc[6 y + 0..5] are dead behind this y's transform)
             }
         }
@@ -514,12 +582,12 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
             const bool epi = ccur == chunks - 1;
             // rows: group 0's are its youngest vector-memory operations; behind group 1's fly the six LDS-DMAs of half B
             if constexpr (GG == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(P_DMA_B) : "memory");
             pass1(tt);
             // The two forms of the rest of the phase are separate arms of ONE branch, each with its own barriers: with the epilogue's
             // halves behind two tests of the same flag the allocator has to assume "transformed along y, never stored" and keeps all
             // 144 accumulator registers live through the tile end (the skip tensor was then spilled behind its loads).
-            if (!epi) {
+            if (!epi || (SE_K44P_EXP & 8)) {
                 if constexpr (GG == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight half this group issued has landed
                 TP(4)
                 barrier();                                            // mid-phase barrier
@@ -529,6 +597,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
                 TP(7)
             } else {
                 f32x4 rv[4][4];
+                if (SE_K44P_EPRIO) __builtin_amdgcn_s_setprio(SE_K44P_EPRIO);
                 epilogue_y(ucur, rv);
                 // group 1: the weight half it issued has landed before anybody reads it (sixteen skip-tensor loads are younger)
                 if constexpr (GG == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -538,6 +607,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
                 pass2(tt);
                 TP(6)
                 epilogue_z(ucur, rv);
+                if (SE_K44P_EPRIO) __builtin_amdgcn_s_setprio(0);
                 TP(7)
             }
             ucur = unx; ccur = cnx;
@@ -618,7 +688,12 @@ bool se_conv3d_wino44pp_shape(int batch, int dim, int cout) {
     const long long units = (long long)batch * (dim / 16) * (dim / 8) * (dim / 8) * (cout / 32);
     return units >= se_num_cus() || dim >= 64;
 }
-bool se_conv3d_wino44pp_takes(const ConvArgs& a, int batch) { return a.wpack_i && se_conv3d_wino44pp_shape(batch, a.dim, a.cout); }
+// A channels-last input with >= 32 channels stays on the F(4,3) x F(2,3) kernel: a 4-channel chunk is 16 bytes of every 128-byte
+// record there (measured 0.578 against 0.506 ms at 32->32 @64^3; one launch per step has such an input, back_layers.0).
+bool se_conv3d_wino44pp_takes(const ConvArgs& a, int batch) {
+    if (!(a.flags & SE_IN_OCTET) && a.cin >= 32) return false;
+    return a.wpack_i && se_conv3d_wino44pp_shape(batch, a.dim, a.cout);
+}
 
 #if defined(SE_STAMP44P)
 extern "C" void se_debug_set_stamp_buffer_44p(void* p) { g_w44p_dbg = reinterpret_cast<unsigned long long*>(p); }
