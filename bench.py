@@ -20,7 +20,7 @@ Extra objects on the line:
                  achieved = EXECUTED matrix-core FLOP per launch / mean launch duration, frac = achieved / 157.3 TFLOP/s
                  (<= 1); the Winograd saving over the direct convolution is reported separately as algorithmic_speedup.
                  "hbm" compares the algorithmic bytes of the launch with the rocprofv3 FETCH_SIZE/WRITE_SIZE counters of
-                 the committed PMC pass (profiles/r03_pmc.json; counters cannot be read from inside this process).  The
+                 the committed PMC pass (profiles/r04_pmc.json; counters cannot be read from inside this process).  The
                  record carries the ABI version and a hash of sceneego_amd/csrc it was taken on; when either differs from
                  this checkout `traffic` is null (a stale record is never printed).
                  "stage_ms" = backbone / gather / voxelise / v2v / softargmax (median over the profiling pass).
@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0
 # algorithmic work of V2V + soft-argmax per frame at 64^3 / 128^3, fp32
 V2V_GFLOP_PER_FRAME = {64: 299.1, 128: 2393.0}
 V2V_GB_PER_FRAME = {64: 1.372, 128: 10.98}
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
 JOINT_TOL = 1e-3               # BASELINE.json north_star: joints within 1e-3 m of the reference's CPU forward
 # se_conv3d_f32_algo() -> (kernel name, executed MFMA FLOP / direct-convolution FLOP)
 K3_ALGOS = {
@@ -139,7 +139,7 @@ def effective_cores():
 
 
 def pmc_record(batch, G, algo):
-    """Counters of the dominant kernel from the committed rocprofv3 PMC passes (tools/pmc_r03.py), or (None, why) when the
+    """Counters of the dominant kernel from the committed rocprofv3 PMC passes (tools/pmc_round.py), or (None, why) when the
     record was taken for another shape / kernel family, on another ABI version or on other kernel sources than this checkout."""
     from sceneego_amd import _lib
     try:
@@ -154,7 +154,7 @@ def pmc_record(batch, G, algo):
         return None, f"libsceneego_hip.so was built from other sources (csrc {built}) than this checkout (csrc {fp}): rebuild"
     if d.get("abi_version") != _lib.ABI_VERSION or d.get("csrc_sha256_16") != fp:
         return None, (f"stale counter record: taken on ABI {d.get('abi_version')} / csrc {d.get('csrc_sha256_16')}, this build is "
-                      f"ABI {_lib.ABI_VERSION} / csrc {fp}; re-run tools/pmc_r03.py on the GPU box")
+                      f"ABI {_lib.ABI_VERSION} / csrc {fp}; re-run tools/pmc_round.py on the GPU box")
     return d, None
 
 

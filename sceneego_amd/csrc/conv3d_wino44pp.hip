@@ -64,7 +64,7 @@ constexpr int P_GA = P_QA * 3;                           // groups that read hal
 constexpr int P_DMA_A = (P_NA + 3) / 4;                  // LDS-DMA instructions per wave of a group for half A: 8
 constexpr int P_DMA_B = (P_NB + 3) / 4;                  // 6
 
-#ifndef SE_K44P_EXP      // attribution builds only (results wrong): 1 no weight DMAs, 2 no input-row loads, 4 no transform passes, 8 no epilogue,
+#ifndef SE_K44P_EXP      // attribution builds only (results wrong): 1 no weight DMAs, 2 no input-row loads, 4 no transform passes,
 #define SE_K44P_EXP 0    // 16 no skip-tensor loads, 32 no output stores
 #endif
 
@@ -407,13 +407,21 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
         for (int e = 0; e < 24; ++e) asm volatile("" : "+v"(acc[e]) : : "memory");
         load_rv(rv, res_ptr(u));
     };
+    // Part 2 does NOT store: the 16 output vectors of the tile are PARKED in acc[20 + 4 y + z] - the registers of xi quads 5..8, which
+    // the next tile's first MFMA phase does not touch before its group 15 - and leave as riders of that phase's first 15 groups
+    // (park_store below): a vector-memory instruction costs a staging wave ~200 cycles next to the partner's MFMA stream, an MFMA
+    // wave next to nothing (attribution build without the stores: -5.6 % per launch).  The next tile needs no zeroed accumulators
+    // either: the first MFMA of every accumulator in a tile's first step takes an inline-constant zero as its C operand.
+    // y runs 3..0: y = 3 reads acc[18..23] before y = 0 parks into acc[20..23].
+    gfloat* p_ob = nullptr;             // output rows of the tile whose outputs are parked
+    const int o_lane = lane_off(out_oct);
     auto epilogue_z = [&](const UnitP& u, f32x4 (&rv)[4][4]) {
-        gfloat* ob = tile_base(a.out, u, out_oct);
-        const int o_lane = lane_off(out_oct);
+        p_ob = tile_base(a.out, u, out_oct);
         const f32x4 bias = *reinterpret_cast<const gf32x4*>(uniform_ptr(a.bpack + u.cb * 32 + ct * 16) + 4 * h);
         if constexpr (skc) wsk = *reinterpret_cast<const gf32x4*>(uniform_ptr(a.skip_w + (u.cb * 32 + ct * 16) * 16) + px * 16 + 4 * h);
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
+        for (int yy = 0; yy < 4; ++yy) {
+            const int y = 3 - yy;
             f32x4 o[4];
             at43p(acc[y * 6 + 0], acc[y * 6 + 1], acc[y * 6 + 2], acc[y * 6 + 3], acc[y * 6 + 4], acc[y * 6 + 5], o);
             if constexpr (skc) {
@@ -433,8 +441,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], relu_lo);
-                if (!(SE_K44P_EXP & 32) || v.x == 12345.f) *reinterpret_cast<gf32x4*>(ob + z * o_zs + y * o_ys + o_lane) = v;
-                if constexpr (pool) acc[y * 6 + z] = v;      // (acc[6 y + 0..5] are dead behind this y's transform)
+                acc[20 + 4 * y + z] = v;
             }
         }
         // fused 2x2x2 max-pool (se_conv3d_pool_f32): the wave's tile is 4 (z) x 4 (y) x 16 (x) outputs = 2 x 2 x 8 pooled voxels; z and y
@@ -452,19 +459,23 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
                     f32x4 m;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float m4 = fmaxf(fmaxf(acc[(2 * py) * 6 + 2 * pz][c], acc[(2 * py) * 6 + 2 * pz + 1][c]),
-                                               fmaxf(acc[(2 * py + 1) * 6 + 2 * pz][c], acc[(2 * py + 1) * 6 + 2 * pz + 1][c]));
+                        const float m4 = fmaxf(fmaxf(acc[20 + 4 * (2 * py) + 2 * pz][c], acc[20 + 4 * (2 * py) + 2 * pz + 1][c]),
+                                               fmaxf(acc[20 + 4 * (2 * py + 1) + 2 * pz][c], acc[20 + 4 * (2 * py + 1) + 2 * pz + 1][c]));
                         const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m4), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
                         m[c] = fmaxf(m4, nb);
                     }
                     if (!(px & 1)) *reinterpret_cast<f32x4*>(pb + ((long long)pz * hd + py) * hd * a.cout) = m;
                 }
         }
-        // the next tile starts from zero.  Done HERE, not at the top of its first step: the allocator then sees the accumulators
-        // dead from their last use in the transforms above (a conditional zeroing at the loop head keeps all 144 registers live
-        // through this epilogue - round-3 experiment: the skip tensor was spilled right behind its loads)
+        // accumulators 0..19 are dead from here (the next tile's first step defines them): say so, or they stay live around the loop
 #pragma unroll
-        for (int e = 0; e < 36; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 20; ++e) asm volatile("" : "=v"(acc[e]));
+    };
+    // parked output k = 4 y + z of the tile behind p_ob
+    auto park_store = [&](auto k_tag) {
+        constexpr int k = decltype(k_tag)::value;
+        constexpr int y = k >> 2, z = k & 3;
+        if (!(SE_K44P_EXP & 32) || acc[20 + k].x == 12345.f) *reinterpret_cast<gf32x4*>(p_ob + z * o_zs + y * o_ys + o_lane) = acc[20 + k];
     };
 
     // State of the walk: (ucur, ccur) = the step this group computes next, (unx, cnx) = the step after it.
@@ -480,10 +491,15 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
 
     // ---- MFMA phase of group GG: 27 groups (quad, dx) of 4 MFMAs; the workgroup's mid-phase barrier sits in front of the first
     // access to weight half B.  Riders (a few per group of MFMAs, where they are nearly free for the issuing wave):
-    //   group 0: 8 LDS-DMAs of half A of the NEXT step in groups 1..8, then the six input rows of its next step in groups 10..15;
-    //   group 1: its six input rows in groups 1..6, 6 LDS-DMAs of half B of the next step in groups 16..21 (behind the mid barrier).
-    auto mfma_phase = [&](auto gg_tag) {
+    //   group 0: the LDS-DMAs of half A of the NEXT step (6 per wave) from group 1 on, then the six input rows of its next step from group 8;
+    //   group 1: its six input rows in groups 1..6, the LDS-DMAs of half B of the next step (8 per wave) right behind the mid barrier
+    //   (A/B in one process, 32->32 @64^3: rows from group 8 instead of 10 -2 %, DMAs one group earlier -1 %, no wave priorities +4 %);
+    //   the first step of a tile also carries the 16 parked output stores of the tile before it (groups 0..14).
+    // KIND: 0 = first step of the workgroup's first tile, 1 = first step of a later tile (carries the 16 parked output stores of the
+    // tile before it), 2 = middle step, 3 = last step of a tile.  In the first step every accumulator's first MFMA (dx = 0) takes C = 0.
+    auto mfma_phase = [&](auto gg_tag, auto kind_tag) {
         constexpr int GG = decltype(gg_tag)::value;
+        constexpr int KIND = decltype(kind_tag)::value;
         const int s_a = slot, s_b = slot == 2 ? 0 : slot + 1, s_n = slot == 0 ? 2 : slot - 1;      // s_n = (slot + 2) mod 3: half A of the next step
         const float* a_h0 = a_lane + s_a * P_SLOT;
         const float* a_h1 = a_lane + s_b * P_SLOT;
@@ -503,8 +519,17 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
         auto group = [&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
             constexpr int q = g / 3, b = g % 3;
-            constexpr int dma0 = GG == 0 ? 1 : P_GA + 1;                    // first group that carries an LDS-DMA
-            constexpr int row0 = GG == 0 ? 10 : 1;                         // ... an input row
+#ifndef SE_K44P_DMA1
+#define SE_K44P_DMA1 P_GA
+#endif
+#ifndef SE_K44P_ROW0
+#define SE_K44P_ROW0 8
+#endif
+#ifndef SE_K44P_PRIO
+#define SE_K44P_PRIO 3
+#endif
+            constexpr int dma0 = GG == 0 ? 1 : SE_K44P_DMA1;               // first group that carries an LDS-DMA
+            constexpr int row0 = GG == 0 ? SE_K44P_ROW0 : 1;               // ... an input row
             constexpr bool dma = g >= dma0 && g < dma0 + (GG == 0 ? P_DMA_A : P_DMA_B);
             constexpr bool row = g >= row0 && g < row0 + 6;
             if constexpr (g == P_GA) {
@@ -523,13 +548,20 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
             if constexpr (row) fetch_one(unx, cnx, std::integral_constant<int, row ? g - row0 : 0>{});
             constexpr bool pre = g + 2 < P_GROUPS && g + 2 != P_GA && g + 2 != P_GA + 1;
             if constexpr (pre) read_ops(std::integral_constant<int, g + 2>{});
+            // parked outputs of the previous tile: one store per group in groups 0..13, two in group 14 (quad 5 = acc[20..23] starts at 15)
+            constexpr int nst = KIND == 1 ? (g < 14 ? 1 : g == 14 ? 2 : 0) : 0;
+            if constexpr (nst >= 1) park_store(std::integral_constant<int, nst ? g : 0>{});
+            if constexpr (nst == 2) park_store(std::integral_constant<int, 15>{});
+            constexpr bool zero_c = KIND <= 1 && g % 3 == 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[4 * q + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][j], ov[b][j], acc[4 * q + j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+                acc[4 * q + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[b][j], ov[b][j], zero_c ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[4 * q + j], 0, 0, 0);
             // issue order inside the group: operand reads and the rider between the MFMAs
             if constexpr (pre) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             if constexpr (pre) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if constexpr (row) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if constexpr (nst > 0) __builtin_amdgcn_sched_group_barrier(0x040, nst, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         };
         for_each_c(group, std::make_integer_sequence<int, P_GROUPS>{});
@@ -555,61 +587,38 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
     if (cnx == 0) fetch_setup(unx);
     __syncthreads();
 
-    // The main loop exists once per group (its MFMA phase differs): one uniform branch in front of the loops instead of one inside
-    // every iteration.
+    // The main loop exists once per group (its MFMA phase differs).  A workgroup walks whole tiles, so the loop is a tile loop with
+    // the first and the last step of a tile peeled: which step carries the parked stores, which one ends in an epilogue and which
+    // accumulators are dead where is then control flow the compiler sees, not a run-time flag.
     auto run = [&](auto gg_tag) {
         constexpr int GG = decltype(gg_tag)::value;
-#pragma unroll
-        for (int e = 0; e < 36; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (GG == 1) {          // group 1 runs one phase behind group 0
-            barrier();
-            barrier();
-        }
-        for (int i = 0; i < n_steps; ++i) {
-            // ------------------------------ MFMA phase of step i = (ucur, ccur) ------------------------------
-#ifdef SE_STAMP44P
-            { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory"); __builtin_amdgcn_sched_barrier(0); }
-#endif
-            __builtin_amdgcn_s_setprio(3);
-            mfma_phase(gg_tag);
-            __builtin_amdgcn_s_setprio(0);
-            TP(2)
-            barrier();                                                // end of the MFMA phase
-            TP(3)
-            // ------------------------------ staging phase ------------------------------
-            // `raw` holds the group's input rows of step i+1, loaded during the MFMA phase.  Half 1: B^T along y into T (and the first
-            // half of a finished tile's skip tensor goes out); half 2: B^T along z into V, the epilogue of a finished tile, the walk.
-            const bool epi = ccur == chunks - 1;
-            // rows: group 0's are its youngest vector-memory operations; behind group 1's fly the six LDS-DMAs of half B
+        // staging phase behind an MFMA phase; `raw` holds the group's input rows of the next step.  Half 1: B^T along y into T; half 2:
+        // B^T along z into V and the walk.  LAST: the epilogue of the finished tile around them.
+        auto staging = [&](auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            // rows: group 0's are its youngest vector-memory operations; behind group 1's fly the LDS-DMAs of half B
             if constexpr (GG == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(P_DMA_B) : "memory");
             pass1(tt);
-            // The two forms of the rest of the phase are separate arms of ONE branch, each with its own barriers: with the epilogue's
-            // halves behind two tests of the same flag the allocator has to assume "transformed along y, never stored" and keeps all
-            // 144 accumulator registers live through the tile end (the skip tensor was then spilled behind its loads).
-            if (!epi || (SE_K44P_EXP & 8)) {
-                if constexpr (GG == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight half this group issued has landed
-                TP(4)
-                barrier();                                            // mid-phase barrier
-                TP(5)
-                pass2(tt);
-                TP(6)
-                TP(7)
-            } else {
-                f32x4 rv[4][4];
+            f32x4 rv[4][4];
+            if constexpr (LAST) {
                 if (SE_K44P_EPRIO) __builtin_amdgcn_s_setprio(SE_K44P_EPRIO);
                 epilogue_y(ucur, rv);
                 // group 1: the weight half it issued has landed before anybody reads it (sixteen skip-tensor loads are younger)
                 if constexpr (GG == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                TP(4)
-                barrier();                                            // mid-phase barrier
-                TP(5)
-                pass2(tt);
-                TP(6)
+            } else {
+                if constexpr (GG == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight half this group issued has landed
+            }
+            TP(4)
+            barrier();                                                // mid-phase barrier
+            TP(5)
+            pass2(tt);
+            TP(6)
+            if constexpr (LAST) {
                 epilogue_z(ucur, rv);
                 if (SE_K44P_EPRIO) __builtin_amdgcn_s_setprio(0);
-                TP(7)
             }
+            TP(7)
             ucur = unx; ccur = cnx;
             slot = slot == 0 ? 2 : slot - 1;                          // (slot + 2) mod 3
             step_after(unx, cnx, inx);
@@ -617,7 +626,33 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
             TP(8)
             barrier();                                                // end of the staging phase
             TP(9)
+        };
+        auto step = [&](auto kind_tag) {
+            constexpr int KIND = decltype(kind_tag)::value;
+#ifdef SE_STAMP44P
+            { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#endif
+            if (SE_K44P_PRIO) __builtin_amdgcn_s_setprio(SE_K44P_PRIO);
+            mfma_phase(gg_tag, kind_tag);
+            if (SE_K44P_PRIO) __builtin_amdgcn_s_setprio(0);
+            TP(2)
+            barrier();                                                // end of the MFMA phase
+            TP(3)
+            staging(std::integral_constant<bool, KIND == 3>{});
+        };
+        if constexpr (GG == 1) {          // group 1 runs one phase behind group 0
+            barrier();
+            barrier();
         }
+        const int n_tiles = u_end - u_begin;
+        for (int t = 0; t < n_tiles; ++t) {
+            if (t == 0) step(std::integral_constant<int, 0>{});
+            else step(std::integral_constant<int, 1>{});
+            for (int c = 1; c + 1 < chunks; ++c) step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{});
+        }
+        // the last tile's outputs are still parked
+        for_each_c(park_store, std::make_integer_sequence<int, 16>{});
         if constexpr (GG == 0) {          // group 0 idles through group 1's last MFMA phase
             barrier();
             barrier();

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""Round-3 counter passes over ONE bench step at HEAD, per dispatch.  Run on the GPU box (gpurun): `python3 tools/pmc_r03.py`.
+"""Counter passes over ONE bench step at HEAD, per dispatch.  Run on the GPU box (gpurun): `python3 tools/pmc_round.py [batch] [grid]`
+(output files are tagged with the round, TAG below).
 
 This process never touches the GPU: it starts `rocprofv3 --kernel-trace --pmc <pass> -- python3 bench.py ...` once per counter
 pass (separate runs, --kernel-trace only: MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots"), reads the counter_collection CSVs,
 cuts the dispatch stream into steps at the gather / voxelise launch that opens a forward, labels every dispatch position of the
 last step with the launch key bench.py's own profiling pass recorded (--dump-launch-order) and writes
 
-    gpurun_out/r03_pmc.json        - what bench.py prints as roofline.traffic / roofline.hbm (copy to profiles/r03_pmc.json)
-    gpurun_out/r03_pmc_table.txt   - every library dispatch of one step with all counters (copy to profiles/)
+    gpurun_out/<TAG>_pmc.json        - what bench.py prints as roofline.traffic / roofline.hbm (copy to profiles/<TAG>_pmc.json)
+    gpurun_out/<TAG>_pmc_table.txt   - every library dispatch of one step with all counters (copy to profiles/)
 
 Both carry the ABI version and the hash of sceneego_amd/csrc they were taken on (sceneego_amd/_lib.py: source_fingerprint);
 bench.py refuses a record whose fingerprint differs from the checkout it runs in.
@@ -26,6 +27,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
+TAG = "r04"
 PASSES = [
     ["FETCH_SIZE"],
     ["WRITE_SIZE"],
@@ -45,12 +47,12 @@ def short(n):
 
 def run_pass(counters, batch, G):
     tag = counters[0]
-    d = os.path.join(OUT, "r03pmc_" + tag)
+    d = os.path.join(OUT, TAG + "pmc_" + tag)
     shutil.rmtree(d, ignore_errors=True)
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--"] + BENCH + \
           ["--batch", str(batch), "--volume-size", str(G)]
     env = dict(os.environ, TMPDIR="/tmp")
-    with open(os.path.join(OUT, f"r03pmc_{tag}.log"), "w") as log:
+    with open(os.path.join(OUT, f"{TAG}pmc_{tag}.log"), "w") as log:
         rc = subprocess.run(cmd, cwd=ROOT, env=env, stdout=log, stderr=subprocess.STDOUT).returncode
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if rc != 0 or not files:
@@ -91,7 +93,7 @@ def calibrate():
         return {}
     res = collections.defaultdict(dict)
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = os.path.join(OUT, "r03cal_" + c)
+        d = os.path.join(OUT, TAG + "cal_" + c)
         shutil.rmtree(d, ignore_errors=True)
         subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d, "--", exe],
                        cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -137,12 +139,12 @@ def main():
     abi = int(re.search(r"^ABI_VERSION = (\d+)", open(os.path.join(ROOT, "sceneego_amd", "_lib.py")).read(), re.M).group(1))
 
     # launch keys in issue order, from bench.py's own HIP-event pass (no profiler attached)
-    order_file = os.path.join(OUT, "r03_launch_order.json")
+    order_file = os.path.join(OUT, TAG + "_launch_order.json")
     rc = subprocess.run(["python3", "bench.py", "--steps", "3", "--warmup", "2", "--streams", "1", "--no-cpu-baseline", "--no-parity",
                          "--no-extras", "--batch", str(batch), "--volume-size", str(G), "--dump-launch-order", order_file],
-                        cwd=ROOT, stdout=open(os.path.join(OUT, "r03_order_bench.log"), "w"), stderr=subprocess.STDOUT).returncode
+                        cwd=ROOT, stdout=open(os.path.join(OUT, TAG + "_order_bench.log"), "w"), stderr=subprocess.STDOUT).returncode
     order = json.load(open(order_file)) if rc == 0 and os.path.isfile(order_file) else []
-    w2d_keys = [k for k in order if k[0] == "conv3d" and k[1] == 3 and k[-1] == 2]
+    w2d_keys = [k for k in order if k[0] == "conv3d" and k[1] == 3 and k[-1] in (2, 3)]      # the 2-D Winograd family: F(4,3)xF(2,3) = 2, F(4,3)xF(4,3) = 3
 
     table = None
     for counters in PASSES:
@@ -164,10 +166,11 @@ def main():
         sys.exit(1)
     # label the 2-D Winograd and 7^3 dispatches with their shape
     it = iter(w2d_keys)
-    n_w2d = sum(1 for t in table if "wino2d" in t["kernel"])
+    is_w2d = lambda t: "wino2d" in t["kernel"] or "wino44pp" in t["kernel"]
+    n_w2d = sum(1 for t in table if is_w2d(t))
     for t in table:
         t["shape"] = ""
-        if "wino2d" in t["kernel"] and n_w2d == len(w2d_keys):
+        if is_w2d(t) and n_w2d == len(w2d_keys):
             k = next(it)
             t["shape"] = f"{k[2]}->{k[3]}@{k[4]}^3"
         elif "conv3d_k7" in t["kernel"]:
@@ -181,16 +184,18 @@ def main():
         hbm = (2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024 / 1e6
         lines.append(f"{t['pos']:3d} {t['kernel']:48s} {t['shape']:16s} {t['vgpr']:4d} {hbm:9.1f} " +
                      " ".join(f"{c.get(n, float('nan')):24.1f}" for n in names))
-    with open(os.path.join(OUT, "r03_pmc_table.txt"), "w") as f:
+    with open(os.path.join(OUT, TAG + "_pmc_table.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
     dom = [t for t in table if t["shape"] == f"32->32@{G}^3"]
+    dom_algo = 3 if sum("wino44pp" in t["kernel"] for t in dom) * 2 > len(dom) else 2
     k7 = [t for t in table if "conv3d_k7" in t["kernel"]]
     rec = {"source": "tools/pmc_r03.py on the GPU box: separate rocprofv3 --kernel-trace --pmc passes over one bench.py step, per dispatch "
-                     "(profiles/r03_pmc_table.txt)",
-           "abi_version": abi, "csrc_sha256_16": fingerprint, "batch": batch, "volume_size": G, "algo": 2,
-           "kernel": f"conv3d_k3_wino2d_kernel, 3x3x3 32->32 @{G}^3, B={batch}: the {len(dom)} launches of this shape in one step",
+                     "(profiles/<TAG>_pmc_table.txt)",
+           "abi_version": abi, "csrc_sha256_16": fingerprint, "batch": batch, "volume_size": G, "algo": dom_algo,
+           "kernel": f"3x3x3 32->32 @{G}^3, B={batch}: the {len(dom)} launches of this shape in one step (" +
+                     ", ".join(sorted({t["kernel"] for t in dom})) + ")",
            "correction": "FETCH_SIZE x 2 (gfx950 counts 64 B per 128-B request; tools/diag/copy_calib: 1 GiB read reports 524 298 KiB), "
                          "WRITE_SIZE as is; both in KiB",
            "algorithmic_bytes_per_launch": 4 * batch * G ** 3 * 32 * 3}
@@ -208,7 +213,7 @@ def main():
     if cal:
         rec["calibration_kib_per_launch"] = dict(cal, note="tools/diag/copy_calib: copy16 / copy8 read and write 1 GiB = 1 048 576 KiB per "
                                                  "launch, gather32of128 touches every line of 1 GiB and writes 256 MiB")
-        with open(os.path.join(OUT, "r03_pmc_table.txt"), "a") as f:
+        with open(os.path.join(OUT, TAG + "_pmc_table.txt"), "a") as f:
             f.write("# calibration (KiB per launch; 1 GiB = 1048576 KiB read and written by copy16 / copy8): " + json.dumps(cal) + "\n")
     if k7:
         c = k7[0]["counters"]
@@ -217,7 +222,7 @@ def main():
                         "algorithmic_bytes_per_launch": 4 * batch * G ** 3 * (33 + 16),
                         "mfma_busy_cycles": c.get("SQ_VALU_MFMA_BUSY_CYCLES"),
                         "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"), "lds_active_cycles": c.get("SQ_LDS_IDX_ACTIVE")}
-    with open(os.path.join(OUT, "r03_pmc.json"), "w") as f:
+    with open(os.path.join(OUT, TAG + "_pmc.json"), "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec)[:600])
 
