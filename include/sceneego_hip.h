@@ -96,6 +96,14 @@ int se_intersection_f32(float* buf, const float* occ, int batch, int voxels, int
 int se_bias_act_nchw_f32(const float* x, const float* bias, const float* residual, float* out,
                          int batch, int channels, int hw, int relu, void* stream);
 
+/* Output side of the 2-D pose head's transposed convolutions - ConvTranspose2d(k=4, s=2, p=1) + BatchNorm2d + ReLU,
+ * network/pose_resnet.py:205-224 (built), :238 (run) - when the layer is computed as ONE GEMM over the un-shifted input:
+ *   z    [batch][4 ky][4 kx][cout][h][w] = W_tap [cout x cin] @ x[b] [cin x h*w] for each of the 16 taps (any GEMM library;
+ *        the host side uses rocBLAS through torch.matmul), BatchNorm scale folded into W
+ *   out  [batch][cout][2h][2w] = bias[co] + the four taps that reach each output pixel (zero outside the map), ReLU if `relu`. */
+int se_deconv2d_k4s2_assemble_f32(const float* z, const float* bias, float* out, int batch, int cout, int h, int w,
+                                  int relu, void* stream);
+
 /* Weight preparation: folds an eval-mode BatchNorm3d into the convolution and re-orders the weights
  * into the MFMA fragment order the conv kernels read (v_mfma_f32_16x16x4_f32 A-operand blocks).
  * Replaces nothing at run time in the reference — it is what makes Conv3d+BatchNorm3d(+ReLU)

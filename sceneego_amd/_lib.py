@@ -38,6 +38,7 @@ SIGNATURES = {
     "se_voxelize_planar3_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "se_intersection_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "se_bias_act_nchw_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "se_deconv2d_k4s2_assemble_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_packed_elems": (_ll, [_i, _i, _i, _i]),
     "se_conv3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
@@ -256,12 +257,30 @@ def bias_act_nchw(x, bias, residual, relu):
     return x
 
 
+def deconv2d_k4s2_assemble(z, bias, batch, cout, h, w, relu=True):
+    """``z`` [B,16,cout,h,w] (per-tap GEMM results of a ConvTranspose2d(4, 2, 1), tap = 4 ky + kx) -> relu?(y + bias) [B,cout,2h,2w]."""
+    require_hip(z, bias)
+    _chk_f32(z, bias)
+    assert z.is_contiguous() and z.numel() == batch * 16 * cout * h * w
+    out = torch.empty((batch, cout, 2 * h, 2 * w), device=z.device, dtype=torch.float32)
+    _check(load().se_deconv2d_k4s2_assemble_f32(_ptr(z), _ptr(bias), _ptr(out), batch, cout, h, w, 1 if relu else 0, _stream()),
+           "se_deconv2d_k4s2_assemble_f32")
+    return out
+
+
 def conv3d_packed_elems(cout, cin_pad, ksize, transposed, bf16=False) -> int:
     fn = load().se_conv3d_packed_elems_bf16 if bf16 else load().se_conv3d_packed_elems
     n = int(fn(cout, cin_pad, ksize, 1 if transposed else 0))
     if n <= 0:
         raise HipExtensionError(f"unsupported conv shape cout={cout} cin_pad={cin_pad} k={ksize}")
     return n
+
+
+def conv3d_variant(batch, dim, cin, cout, ksize) -> int:
+    """The kernel a PLAIN channels-last launch of ``batch`` samples runs on: conv3d_algo()'s value, except 3 = the F(4,3) x F(4,3)
+    member of the 2-D Winograd family (same flags / layouts as 2) and 0 for a 2-D Winograd shape with <= 4096 voxels in the batch
+    (16^3 at batch 1), which the in-workgroup split-K kernel serves better; the V2V program keeps such a level channels-last."""
+    return int(load().se_conv3d_f32_variant(batch, dim, cin, cout, ksize))
 
 
 def conv3d_algo(dim, cin, cout, ksize) -> int:

@@ -35,8 +35,11 @@ inline int se_current_device() {
     return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : 0;
 }
 // soft-argmax pass-1 partials (softargmax.hip, conv3d.hip): chunks per (sample, joint) row and floats per record (m, l, sx, sy, sz, pad)
-#define SE_SA_SPLITS 32
 #define SE_SA_PART 8
+// chunks per row: 32 from batch 8 on (15 rows per sample: 120 rows x 32 chunks = 3840 workgroups for the two-pass form, 256 for the
+// fused tail, which runs one workgroup per (chunk, sample)); fewer rows get more chunks so that the fused tail still has ~256
+// workgroups (batch 1: 256 chunks of 1024 voxels at 64^3 - it ran 32 workgroups on 256 CUs before: 116 us of a 3.3 ms frame)
+inline int se_sa_splits(int rows) { return rows >= 120 ? 32 : rows >= 60 ? 64 : rows >= 30 ? 128 : 256; }
 
 inline int se_num_cus() {
     static std::atomic<int> cus[64];

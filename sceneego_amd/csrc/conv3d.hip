@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void pointwise_chain3_kernel(const float* __re
 // The same chain with pass 1 of the soft-argmax (reference utils/op.py:83-96) folded in: the workgroup (chunk s, sample b) owns the
 // voxels [s * chunk, (s+1) * chunk) of its sample - the chunking of softargmax_partial_kernel - keeps a running
 // (max, sum exp, sum exp * coord) per lane and joint while the logits are still in registers (online softmax: a new maximum
-// rescales the sums), folds the lanes in a fixed order and writes the SE_SA_PART record softargmax_finish_kernel reads.  The
+// rescales the sums), folds the lanes in a fixed order and writes the SE_SA_PART record softargmax_finish_kernel reads (se_sa_splits(batch * cout3) chunks per row).  The
 // logits are stored as before (forward() returns the softmaxed volumes, pass 2 reads them) but are not read back for pass 1.
 constexpr int PW_SA_WAVES = 16;      // waves per workgroup of pointwise_chain3_sa_kernel (one workgroup per CU: 4 waves per SIMD)
 __global__ __launch_bounds__(PW_SA_WAVES * 64) void pointwise_chain3_sa_kernel(const float* __restrict__ in, const float* __restrict__ w1,
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(PW_SA_WAVES * 64) void pointwise_chain3_sa_kernel(c
                                                                   const float* __restrict__ b2, const float* __restrict__ w3,
                                                                   const float* __restrict__ b3, float* __restrict__ out,
                                                                   const float* __restrict__ coord, float* __restrict__ scratch,
-                                                                  int vox_per_b, int chunk, int cout3) {
+                                                                  int vox_per_b, int chunk, int cout3, int splits) {
     extern __shared__ __attribute__((aligned(16))) float pw_sa_lds[];
     float (*red)[64][20] = reinterpret_cast<float (*)[64][20]>(pw_sa_lds);        // [PW_SA_WAVES][64][20]
     const int lane = threadIdx.x & 63;
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(PW_SA_WAVES * 64) void pointwise_chain3_sa_kernel(c
                 const float f = (e[0] == -INFINITY) ? 0.f : __expf(e[0] - M);     // a lane that saw no voxel contributes nothing
                 L += e[1] * f; SX += e[2] * f; SY += e[3] * f; SZ += e[4] * f;
             }
-        float* p = scratch + (((size_t)b * cout3 + j) * SE_SA_SPLITS + s) * SE_SA_PART;
+        float* p = scratch + (((size_t)b * cout3 + j) * splits + s) * SE_SA_PART;
         p[0] = M; p[1] = L; p[2] = SX; p[3] = SY; p[4] = SZ;
     }
 }
@@ -884,6 +884,7 @@ extern "C" int se_conv3d_f32_algo(int dim, int cin, int cout, int ksize) {
 bool se_conv3d_wino44pp_shape(int batch, int dim, int cout);      // conv3d_wino44pp.hip
 extern "C" int se_conv3d_f32_variant(int batch, int dim, int cin, int cout, int ksize) {
     const int algo = se_conv3d_f32_algo(dim, cin, cout, ksize);
+    if (algo == 2 && se_conv3d_small_volume(batch, dim)) return 0;       // a plain channels-last call runs the in-workgroup split-K form
     if (algo == 2 && g_variant != 64 && se_conv3d_wino44pp_shape(batch, dim, cout)) return 3;
     return algo;
 }
@@ -1133,12 +1134,13 @@ extern "C" int se_pointwise_chain3_softargmax_f32(const float* in, const float* 
     if (batch <= 0 || dim <= 0 || cout3 <= 0 || cout3 > 16 || !coord || !scratch) return SE_ERR_BAD_ARG;
     const long long vox_per_b = (long long)dim * dim * dim;
     if (vox_per_b >= (1LL << 31) || (vox_per_b & 3)) return SE_ERR_BAD_ARG;
-    const int chunk = (int)((((vox_per_b + SE_SA_SPLITS - 1) / SE_SA_SPLITS) + 3) & ~3LL);      // as softargmax.hip
+    const int splits = se_sa_splits(batch * cout3);                                               // as softargmax.hip
+    const int chunk = (int)((((vox_per_b + splits - 1) / splits) + 3) & ~3LL);
     if (chunk & 15) return SE_ERR_BAD_ARG;                                                       // whole 16-voxel tiles per chunk
     constexpr int LDS = PW_SA_WAVES * 64 * 20 * 4;
     SE_ENSURE_LDS(pointwise_chain3_sa_kernel, LDS);
-    hipLaunchKernelGGL(pointwise_chain3_sa_kernel, dim3(SE_SA_SPLITS, batch), dim3(PW_SA_WAVES * 64), LDS, se_stream(stream), in, wpack1, bpack1,
-                       wpack2, bpack2, wpack3, bpack3, out, coord, scratch, (int)vox_per_b, chunk, cout3);
+    hipLaunchKernelGGL(pointwise_chain3_sa_kernel, dim3(splits, batch), dim3(PW_SA_WAVES * 64), LDS, se_stream(stream), in, wpack1, bpack1,
+                       wpack2, bpack2, wpack3, bpack3, out, coord, scratch, (int)vox_per_b, chunk, cout3, splits);
     SE_CHECK_LAUNCH();
     return 0;
 }

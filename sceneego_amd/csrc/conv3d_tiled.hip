@@ -220,6 +220,13 @@ int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) 
 
 static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s) {
     const int dim = a.dim;
+    // tiny volumes of 2-D Winograd shapes (16^3 at batch 1: 32 work units for 256 CUs): a plain channels-last call is left to the
+    // in-workgroup split-K kernel of the 8^3 level (conv_common.h: se_conv3d_small_volume; 47 against 92 us per 128 -> 128 launch);
+    // a caller that asks for an octet-planar / pooled / fused-skip form gets the 2-D kernel as before
+    if (ksize == 3 && g_variant == 0 && se_conv3d_small_volume(batch, dim) && a.cin_pad == a.cin && se_wino2d_shape_ok(dim, a.cin, a.cout) &&
+        !(a.flags & (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET | SE_EPI_SKIPCONV16 | SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR)) && !a.pool_out &&
+        !a.skip_w && (a.nts % 2) == 0)
+        return SE_TILED_NOT_TAKEN;
     if (ksize == 3 && (g_variant == 0 || (g_variant >= 40 && g_variant < 70))) {   // production: 2-D Winograd F(4,3) x F(2,3), register accumulators
         const int rc = se_conv3d_wino2d_try(a, batch, s);
         if (rc != SE_TILED_NOT_TAKEN) return rc;

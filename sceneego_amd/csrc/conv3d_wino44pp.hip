@@ -54,7 +54,10 @@ static_assert(P_HALF_A + P_HALF_B == SE_WINO44_CHUNK_FLOATS, "chunk = two halves
 constexpr int P_SLOT = P_HALF_A > P_HALF_B ? P_HALF_A : P_HALF_B;      // floats per weight slot
 constexpr int P_NA = P_HALF_A / 256;                     // wave-instructions (64 lanes x 16 B) of half A
 constexpr int P_NB = P_HALF_B / 256;
-constexpr int P_RS = 148;                                // floats per x record of V: 4 channels x 36 xi + 4 pad (37 x 16 B: odd -> bank spread)
+#ifndef SE_K44P_RS
+#define SE_K44P_RS 148
+#endif
+constexpr int P_RS = SE_K44P_RS;                         // floats per x record of V: 4 channels x 36 xi + 4 pad (37 x 16 B: odd -> bank spread)
 constexpr int P_VT = 18 * P_RS;                          // one (G, zt) tile of V
 constexpr int P_V_FLOATS = 4 * P_VT;                     // 10,656 floats
 constexpr int P_T_FLOATS = 6 * 10 * 18 * 4;              // scratch of pass 1: [xi_y 6][z 10][x 18][4 channels] = 4320 floats

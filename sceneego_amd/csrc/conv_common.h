@@ -52,6 +52,12 @@ inline bool se_wino2d_shape_ok(int dim, int cin, int cout) {
     return (long long)dim * dim * dim * (cin > cout ? cin : cout) * 4 < (1LL << 31);
 }
 
+// A 2-D Winograd shape with so few voxels that its 4 x 8 x 16 tiles leave most of the chip idle (16^3 at batch 1: 8 tiles x 4 cout
+// blocks on 256 CUs, 92 us per 128 -> 128 launch): a call WITHOUT octet-planar / pooled / fused-skip forms then runs on the
+// in-workgroup split-K kernel of the 8^3 level (32-voxel tiles, 512 workgroups, 47 us).  se_conv3d_f32_variant() reports it, the
+// V2V program asks per (batch, level).
+inline bool se_conv3d_small_volume(int batch, int dim) { return (long long)batch * dim * dim * dim <= 4096; }
+
 struct ConvArgs {
     const float* in;
     const float* wpack;    // section A: [cg][tap][nt][lane][4]

@@ -170,6 +170,60 @@ extern "C" int se_bias_act_nchw_f32(const float* x, const float* bias, const flo
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ConvTranspose2d(k = 4, stride 2, padding 1) + folded BatchNorm + ReLU of the 2-D pose head (network/pose_resnet.py:205-224,238)
+// as ONE GEMM over the un-shifted input plus this assembly pass.  With Z[b][ky][kx][co][j][i] = sum_ci w[ci][co][ky][kx] x[b][ci][j][i]
+// (a plain [16 co x ci] x [ci x HW] GEMM per sample: no gathered / shifted copies of x, which for the 2048-channel layer were
+// 16 x the input), output row 2j+a / column 2i+c only sees 2 x 2 of the 16 taps:
+//     a = 0: (ky, dy) in {(1, 0), (3, -1)}     a = 1: {(0, +1), (2, 0)}          (same table for c, kx, dx)
+//     y[b][co][2j+a][2i+c] = bias[co] + sum Z[b][ky][kx][co][j+dy][i+dx]           (terms outside the map are zero)
+// One thread per output pixel pair (c = 0, 1): 8 coalesced loads of Z, one 8-byte store.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void deconv2d_k4s2_assemble_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                                     float* __restrict__ out, long long total_pairs, int cout, int h,
+                                                                     int w, int relu) {
+    typedef float f32x2a __attribute__((ext_vector_type(2)));
+    const long long plane = (long long)h * w;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total_pairs; t += (long long)gridDim.x * 256) {
+        const int i = (int)(t % w);
+        long long r = t / w;
+        const int oy = (int)(r % (2 * h)); r /= 2 * h;
+        const int co = (int)(r % cout);
+        const long long b = r / cout;
+        const int a = oy & 1, j = oy >> 1;
+        // rows: (ky0, j0) always inside the map; (ky1, j1) may fall outside
+        const int ky0 = a ? 2 : 1, ky1 = a ? 0 : 3, j1 = a ? j + 1 : j - 1;
+        const bool r1 = (unsigned)j1 < (unsigned)h;
+        const float* zb = z + (b * 16 * cout + co) * plane;                     // + (ky * 4 + kx) * cout * plane + jj * w + ii
+        auto at = [&](int ky, int kx, int jj, int ii) { return zb[(long long)(ky * 4 + kx) * cout * plane + (long long)jj * w + ii]; };
+        const float bv = bias[co];
+        // column c = 0: kx 1 at i, kx 3 at i - 1;  c = 1: kx 2 at i, kx 0 at i + 1
+        float y0 = bv + at(ky0, 1, j, i), y1 = bv + at(ky0, 2, j, i);
+        if (i > 0) y0 += at(ky0, 3, j, i - 1);
+        if (i + 1 < w) y1 += at(ky0, 0, j, i + 1);
+        if (r1) {
+            y0 += at(ky1, 1, j1, i);
+            y1 += at(ky1, 2, j1, i);
+            if (i > 0) y0 += at(ky1, 3, j1, i - 1);
+            if (i + 1 < w) y1 += at(ky1, 0, j1, i + 1);
+        }
+        if (relu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
+        *reinterpret_cast<f32x2a*>(out + ((b * cout + co) * 2 * h + oy) * 2 * w + 2 * i) = (f32x2a){y0, y1};
+    }
+}
+}  // namespace
+
+extern "C" int se_deconv2d_k4s2_assemble_f32(const float* z, const float* bias, float* out, int batch, int cout, int h, int w,
+                                             int relu, void* stream) {
+    if (batch <= 0 || cout <= 0 || h <= 0 || w <= 0 || !z || !bias || !out) return SE_ERR_BAD_ARG;
+    const long long pairs = (long long)batch * cout * 2 * h * w;
+    const unsigned grid = (unsigned)((pairs + 255) / 256 < 8192 ? (pairs + 255) / 256 : 8192);
+    hipLaunchKernelGGL(deconv2d_k4s2_assemble_kernel, dim3(grid), dim3(256), 0, se_stream(stream), z, bias, out, pairs, cout, h, w, relu);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
 // bfloat16 form (BASELINE config 3 backbone): 8 elements per lane, float32 arithmetic, one rounding
 namespace {
 typedef unsigned short u16x8g __attribute__((ext_vector_type(8)));

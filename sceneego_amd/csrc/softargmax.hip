@@ -2,13 +2,13 @@
 // expectation of the voxel-centre coordinates.  HBM-bound: 4 B/voxel/row read (twice, second pass is
 // L2/MALL resident at 64^3) + 4 B written (the softmaxed volumes are part of forward()'s return value).
 //
-// Two launches, split-row so that B*15 rows x SE_SA_SPLITS chunks fill the 256 CUs:
+// Two launches, split-row so that B*15 rows x se_sa_splits(rows) chunks fill the 256 CUs:
 //   pass 1: per chunk  m = max v, l = sum exp(v-m), s = sum exp(v-m) * coord      -> scratch
-//   pass 2: every chunk re-derives the row's (M, L) from the SE_SA_SPLITS partials in a fixed order
+//   pass 2: every chunk re-derives the row's (M, L) from the row's partials in a fixed order
 //           (bitwise deterministic), writes exp(v-M)/L; chunk 0 also writes the joint.
 #include "common.h"
 
-// SE_SA_SPLITS / SE_SA_PART (chunks per row, floats per partial record: m, l, sx, sy, sz, pad): common.h - the fused V2V tail
+// se_sa_splits() / SE_SA_PART (chunks per row, floats per partial record: m, l, sx, sy, sz, pad): common.h - the fused V2V tail
 // (pointwise_chain3_sa_kernel in conv3d.hip) writes the same records
 
 namespace {
@@ -30,14 +30,14 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sm) {
     return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-// grid (SE_SA_SPLITS, rows), block 256
+// grid (splits, rows), block 256
 __global__ __launch_bounds__(256) void softargmax_partial_kernel(const float* __restrict__ vol,
                                                                  const float* __restrict__ coord,
                                                                  float* __restrict__ scratch, int voxels,
-                                                                 int mode) {
+                                                                 int mode, int splits) {
     __shared__ float sm[4];
     const int row = blockIdx.y, s = blockIdx.x;
-    const int chunk = (((voxels + SE_SA_SPLITS - 1) / SE_SA_SPLITS) + 3) & ~3;
+    const int chunk = (((voxels + splits - 1) / splits) + 3) & ~3;
     const int c0 = s * chunk;
     const int c1 = min(c0 + chunk, voxels);
     const float* v = vol + (size_t)row * voxels;
@@ -72,34 +72,46 @@ __global__ __launch_bounds__(256) void softargmax_partial_kernel(const float* __
     sy = block_reduce_sum(sy, sm);
     sz = block_reduce_sum(sz, sm);
     if (threadIdx.x == 0) {
-        float* p = scratch + ((size_t)row * SE_SA_SPLITS + s) * SE_SA_PART;
+        float* p = scratch + ((size_t)row * splits + s) * SE_SA_PART;
         p[0] = m; p[1] = l; p[2] = sx; p[3] = sy; p[4] = sz;
     }
 }
 
-// grid (SE_SA_SPLITS, rows), block 256
+// grid (splits, rows), block 256
 __global__ __launch_bounds__(256) void softargmax_finish_kernel(const float* __restrict__ vol,
                                                                 const float* __restrict__ scratch,
                                                                 float* __restrict__ out_vol,
-                                                                float* __restrict__ joints, int voxels, int mode) {
+                                                                float* __restrict__ joints, int voxels, int mode, int splits) {
     const int row = blockIdx.y, s = blockIdx.x;
-    const float* part = scratch + (size_t)row * SE_SA_SPLITS * SE_SA_PART;
-    // every thread folds the partials in the same fixed order -> identical (M, L) everywhere
-    // a chunk is skipped only when it is EMPTY (k * chunk >= voxels), never for the value of its partial sums: a NaN logit
-    // makes its chunk's l NaN, and that must reach L, the joints and the whole row of volumes as it does through
-    // torch.softmax + einsum in the reference (utils/op.py:83-96)
-    const int chunk = (((voxels + SE_SA_SPLITS - 1) / SE_SA_SPLITS) + 3) & ~3;
-    float M = -INFINITY;
-    if (mode == 1)
-        for (int k = 0; k < SE_SA_SPLITS; ++k)
-            if (k * chunk < voxels) M = fmaxf(M, part[k * SE_SA_PART + 0]);
-    float L = 0.f, SX = 0.f, SY = 0.f, SZ = 0.f;
-    for (int k = 0; k < SE_SA_SPLITS; ++k) {
-        if (k * chunk >= voxels) continue;
-        const float* p = part + k * SE_SA_PART;
-        const float f = (mode == 1) ? expf(p[0] - M) : 1.f;
-        L += p[1] * f; SX += p[2] * f; SY += p[3] * f; SZ += p[4] * f;
+    const float* part = scratch + (size_t)row * splits * SE_SA_PART;
+    // The first wave folds the row's partials ONCE per workgroup, in a fixed order (lane k takes chunks k, k + 64, ... in sequence, then
+    // a butterfly over the lanes): bitwise deterministic, every workgroup of the row gets the identical (M, L).  (Until round 4 every
+    // thread folded all partials itself: with 256 chunks per row - batch 1 - that was 256 expf per thread, 214 us per launch.)
+    // A chunk is skipped only when it is EMPTY (k * chunk >= voxels), never for the value of its partial sums: a NaN logit makes its
+    // chunk's l NaN, and that must reach L, the joints and the whole row of volumes as it does through torch.softmax + einsum in
+    // the reference (utils/op.py:83-96)
+    __shared__ float fold[5];
+    const int chunk = (((voxels + splits - 1) / splits) + 3) & ~3;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        float M = -INFINITY;
+        if (mode == 1) {
+            for (int k = lane; k < splits; k += 64)
+                if (k * chunk < voxels) M = fmaxf(M, part[k * SE_SA_PART + 0]);
+            M = wave_reduce_max(M);
+        }
+        float L = 0.f, SX = 0.f, SY = 0.f, SZ = 0.f;
+        for (int k = lane; k < splits; k += 64) {
+            if (k * chunk >= voxels) continue;
+            const float* p = part + k * SE_SA_PART;
+            const float f = (mode == 1) ? expf(p[0] - M) : 1.f;
+            L += p[1] * f; SX += p[2] * f; SY += p[3] * f; SZ += p[4] * f;
+        }
+        L = wave_reduce_sum(L); SX = wave_reduce_sum(SX); SY = wave_reduce_sum(SY); SZ = wave_reduce_sum(SZ);
+        if (lane == 0) { fold[0] = M; fold[1] = L; fold[2] = SX; fold[3] = SY; fold[4] = SZ; }
     }
+    __syncthreads();
+    const float M = fold[0], L = fold[1], SX = fold[2], SY = fold[3], SZ = fold[4];
     const float invL = (mode == 1) ? 1.f / L : 1.f;
     if (s == 0 && threadIdx.x == 0) {
         joints[row * 3 + 0] = SX * invL;
@@ -126,17 +138,18 @@ __global__ __launch_bounds__(256) void softargmax_finish_kernel(const float* __r
 }  // namespace
 
 extern "C" long long se_softargmax3d_scratch_elems(int rows) {
-    return (long long)rows * SE_SA_SPLITS * SE_SA_PART;
+    return rows > 0 ? (long long)rows * se_sa_splits(rows) * SE_SA_PART : 0;
 }
 
 extern "C" int se_softargmax3d_f32(const float* vol, const float* coord, float* out_vol, float* joints,
                                    float* scratch, int rows, int voxels, int mode, void* stream) {
     if (rows <= 0 || voxels <= 0 || (voxels & 3) || (mode != 0 && mode != 1)) return SE_ERR_BAD_ARG;
     hipStream_t s = se_stream(stream);
-    dim3 grid(SE_SA_SPLITS, rows);
-    hipLaunchKernelGGL(softargmax_partial_kernel, grid, dim3(256), 0, s, vol, coord, scratch, voxels, mode);
+    const int splits = se_sa_splits(rows);
+    dim3 grid(splits, rows);
+    hipLaunchKernelGGL(softargmax_partial_kernel, grid, dim3(256), 0, s, vol, coord, scratch, voxels, mode, splits);
     SE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(softargmax_finish_kernel, grid, dim3(256), 0, s, vol, scratch, out_vol, joints, voxels, mode);
+    hipLaunchKernelGGL(softargmax_finish_kernel, grid, dim3(256), 0, s, vol, scratch, out_vol, joints, voxels, mode, splits);
     SE_CHECK_LAUNCH();
     return 0;
 }
@@ -146,7 +159,8 @@ extern "C" int se_softargmax3d_finish_f32(const float* vol, const float* scratch
                                           int voxels, int mode, void* stream) {
     if (rows <= 0 || voxels <= 0 || (voxels & 3) || (mode != 0 && mode != 1)) return SE_ERR_BAD_ARG;
     hipStream_t s = se_stream(stream);
-    hipLaunchKernelGGL(softargmax_finish_kernel, dim3(SE_SA_SPLITS, rows), dim3(256), 0, s, vol, scratch, out_vol, joints, voxels, mode);
+    const int splits = se_sa_splits(rows);
+    hipLaunchKernelGGL(softargmax_finish_kernel, dim3(splits, rows), dim3(256), 0, s, vol, scratch, out_vol, joints, voxels, mode, splits);
     SE_CHECK_LAUNCH();
     return 0;
 }

@@ -198,41 +198,30 @@ class FoldedBackbone:
             x = ba(y, c3[1], sc, True)
         for li, (w, b) in enumerate(self.ups):
             B, _, H, W = x.shape
-            if B * H * W <= self.DECONV_GEMM_MAX_POSITIONS:
-                x = ba(self._deconv_gemm(li, x), b, None, True)
+            if B * H * W <= self.DECONV_GEMM_MAX_POSITIONS and x.dtype == torch.float32:
+                x = self._deconv_gemm(li, x, b)
             else:
                 x = ba(F.conv_transpose2d(x, w, None, stride=2, padding=1), b, None, True)
         return x
 
-    # ConvTranspose2d(k=4, s=2, p=1) of the pose head (reference network/pose_resnet.py:_make_deconv_layer) as 16 batched GEMMs:
-    # output parity (a, b) of row 2j+a / column 2i+b only sees 2 x 2 of the 16 taps (a = 0: kernel rows 1, 3 on input rows j, j-1;
-    # a = 1: rows 0, 2 on j+1, j), so  y[parity] = sum over its 4 taps of  W_tap [co x ci] @ X_tap [ci x B*H*W]  with X_tap the input
-    # shifted by the tap's offset.  MIOpen's backward-data igemm takes 286 us for the 2048 -> 256 layer at 8 x 8 (B = 8, 30 TFLOP/s);
-    # one gather of the 16 shifted copies + one batched rocBLAS GEMM + the parity interleave take 123 us (tools/diag/deconv_gemm.py;
-    # 256 -> 256 at 16 x 16: 84 vs 100 us; at 32 x 32 MIOpen's Winograd form is faster, 188 vs 265 us, and stays).
+    # ConvTranspose2d(k=4, s=2, p=1) of the pose head (reference network/pose_resnet.py:205-224) as ONE GEMM + an assembly pass:
+    # Z[b] = W_all [16 co x ci] @ x[b] [ci x HW] holds, for each of the 16 taps, that tap's contribution at the UN-shifted input
+    # position; output row 2j+a / column 2i+b only sees 2 x 2 of the taps (a = 0: kernel rows 1, 3 on input rows j, j-1; a = 1: rows
+    # 0, 2 on j+1, j), which ``se_deconv2d_k4s2_assemble_f32`` sums together with the bias and the ReLU.  Round 2 gathered the 16
+    # shifted copies of x first (index_select: 67 MB for the 2048-channel layer) and summed four batched GEMMs per parity - 8 launches,
+    # ~150 us for the 2048 -> 256 layer at 8 x 8; MIOpen's backward-data igemm takes 300 us there (profiles/r04_backbone_solvers.txt).
+    # At 32 x 32 MIOpen's Winograd form (204 us, 84 TFLOP/s) is faster than any GEMM of Z's size and stays.
     DECONV_GEMM_MAX_POSITIONS = 2048
-    _KD = {0: ((1, 0), (3, -1)), 1: ((0, 1), (2, 0))}          # output parity -> ((kernel index, input offset), ...)
 
-    def _deconv_gemm(self, li, x):
+    def _deconv_gemm(self, li, x, bias):
+        from . import _lib
         B, C, H, W = x.shape
-        key = (li, B, H, W, x.device)
         cache = self.__dict__.setdefault("_deconv_gemm_cache", {})
+        key = (li, x.device)
         if key not in cache:
             w = self.ups[li][0]                                  # [ci, co, 4, 4]
-            mats, idx = [], []
-            bb = torch.arange(B).view(B, 1, 1)
-            jj = torch.arange(H).view(1, H, 1)
-            ii = torch.arange(W).view(1, 1, W)
-            for a in (0, 1):
-                for c in (0, 1):
-                    for ky, dy in self._KD[a]:
-                        for kx, dx in self._KD[c]:
-                            mats.append(w[:, :, ky, kx].t().contiguous())
-                            idx.append((bb * (H + 2) * (W + 2) + (jj + 1 + dy) * (W + 2) + (ii + 1 + dx)).reshape(-1))
-            cache[key] = (torch.stack(mats).contiguous(), torch.cat(idx).to(x.device))
-        w16, idx = cache[key]
-        co = w16.shape[1]
-        xp = F.pad(x, (1, 1, 1, 1)).permute(1, 0, 2, 3).reshape(C, -1)            # [C, B*(H+2)*(W+2)]
-        xg = xp.index_select(1, idx).view(C, 16, B * H * W)                          # the 16 shifted copies
-        y = torch.bmm(w16, xg.permute(1, 0, 2)).view(4, 4, co, B * H * W).sum(1)     # [4 parities, co, B*H*W]
-        return y.view(2, 2, co, B, H, W).permute(3, 2, 4, 0, 5, 1).reshape(B, co, 2 * H, 2 * W)
+            cache[key] = w.permute(2, 3, 1, 0).reshape(16 * w.shape[1], C).contiguous()      # row = (4 ky + kx) * co + co_idx
+        w_all = cache[key]
+        co = w_all.shape[0] // 16
+        z = torch.matmul(w_all, x.reshape(B, C, H * W))         # [B, 16 co, HW]: one strided-batched rocBLAS GEMM
+        return _lib.deconv2d_k4s2_assemble(z, bias, B, co, H, W, relu=True)

@@ -261,7 +261,7 @@ class V2VProgram:
         convolutions is always octet-planar [B][C/8][D][D][D][8]; ``x_oct`` says the block input is, ``out_oct`` asks for an
         octet-planar block output (4x fewer cache lines per halo load of the reader; see run() for who reads what)."""
         c1, c2, sk = blk
-        w2d = self._oct_ok(blk, dim)       # both convolutions take the octet-planar flags (2-D Winograd, or the split-bf16 kernel)
+        w2d = self._oct_ok(blk, dim, B)    # both convolutions take the octet-planar flags (2-D Winograd, or the split-bf16 kernel)
         assert w2d or not (x_oct or out_oct)
         assert sk is None or not x_oct           # the 1x1x1 skip convolution reads channels-last
         mid = _lib.OUT_OCTET if w2d else 0
@@ -279,13 +279,16 @@ class V2VProgram:
             f2 |= _lib.OUT_OCTET
         return self._conv(a, c2, B, dim, f2, residual=s, pool_out=pool_out)      # pool_out: the block's 2x max-pool, written by the same launch
 
-    def _oct_ok(self, blk, dim):
+    def _oct_ok(self, blk, dim, B):
+        """Do both convolutions of the block take the octet-planar / pooled / fused-skip forms at this (batch, level)?  (2-D Winograd
+        family: variants 2 and 3; a level with so few voxels that the plain split-K kernel is faster - 16^3 at batch 1 - says no and
+        stays channels-last.)"""
         c1, c2, _ = blk
         if self.dtype != torch.float32:
             return False
         if self.split3:
             return c1.w_split is not None and c2.w_split is not None and dim % 16 == 0
-        return _lib.conv3d_algo(dim, c1.cin_pad, c1.cout, 3) == 2 and _lib.conv3d_algo(dim, c2.cin_pad, c2.cout, 3) == 2
+        return _lib.conv3d_variant(B, dim, c1.cin_pad, c1.cout, 3) in (2, 3) and _lib.conv3d_variant(B, dim, c2.cin_pad, c2.cout, 3) in (2, 3)
 
     def _pool(self, x, B, dim, c, x_oct=False):
         out = self._new(B, dim // 2, c)
@@ -321,7 +324,7 @@ class V2VProgram:
         x_oct = False
         pooled = None
         for i, blk in enumerate(self.front_res):
-            ok = self._oct_ok(blk, G)
+            ok = self._oct_ok(blk, G, B)
             if ok and not self.split3 and i == len(self.front_res) - 1:      # (the split-bf16 kernel has no pooled form)
                 pooled = self._new(B, G // 2, blk[1].cout)
             x = self._res(x, blk, B, G, x_oct=x_oct, out_oct=ok, pool_out=pooled)
@@ -334,7 +337,7 @@ class V2VProgram:
             x = pooled if pooled is not None else self._pool(x, B, dim, x.numel() // (B * dim ** 3), x_oct=x_oct)
             pooled = None
             dim //= 2
-            ok = self._oct_ok(self.enc[k], dim)
+            ok = self._oct_ok(self.enc[k], dim, B)
             if ok and not self.split3 and k < 4:
                 pooled = self._new(B, dim // 2, self.enc[k][1].cout)
             x = self._res(x, self.enc[k], B, dim, x_oct=False, out_oct=ok, pool_out=pooled)

@@ -420,6 +420,25 @@ def test_bias_act_and_fused_backbone():
     assert float((fused - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-5
 
 
+@pytest.mark.parametrize("B,ci,co,H,W", [(2, 24, 8, 5, 3), (8, 2048, 256, 8, 8), (1, 256, 256, 16, 16)])
+def test_deconv2d_gemm_plus_assemble_vs_torch(B, ci, co, H, W):
+    """se_deconv2d_k4s2_assemble_f32: the pose head's ConvTranspose2d(4, 2, 1) + folded BN + ReLU (reference
+    network/pose_resnet.py:205-224,238) as one GEMM over the un-shifted input + the assembly pass, against torch-CPU
+    F.conv_transpose2d (odd sizes: every edge case of the 2 x 2 tap table; then the two production shapes)."""
+    g = torch.Generator().manual_seed(ci + H)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(ci, co, 4, 4, generator=g) * (1.0 / (4 * ci)) ** 0.5
+    bias = torch.randn(co, generator=g)
+    want = F.relu(F.conv_transpose2d(x, w, bias, stride=2, padding=1))
+    w_all = w.permute(2, 3, 1, 0).reshape(16 * co, ci).contiguous().to(DEV)
+    z = torch.matmul(w_all, x.to(DEV).reshape(B, ci, H * W))
+    got = _lib.deconv2d_k4s2_assemble(z, bias.to(DEV), B, co, H, W, relu=True).cpu()
+    assert tuple(got.shape) == (B, co, 2 * H, 2 * W)
+    assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    lin = _lib.deconv2d_k4s2_assemble(z, bias.to(DEV), B, co, H, W, relu=False).cpu()
+    assert float((lin - F.conv_transpose2d(x, w, bias, stride=2, padding=1)).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
 def test_pointwise_chain_matches_separate_layers():
     """Fused back_layers.1/.2 + output_layer (one launch) == the three separate 1x1x1 launches == torch CPU."""
     c1, c2, c3 = nn.Conv3d(32, 32, 1), nn.Conv3d(32, 32, 1), nn.Conv3d(32, 15, 1)
@@ -631,15 +650,23 @@ def test_conv3d_octet_planar_forms_match_channels_last(B, dim, cin, cout):
     x = torch.randn(B, dim, dim, dim, cin, device=DEV)
     res = torch.randn(B, dim, dim, dim, cout, device=DEV)
     flags = _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU
-    ref = torch.empty(B, dim, dim, dim, cout, device=DEV)
-    _lib.conv3d(x, pc.w, pc.b, res, ref, B, dim, cin, cin, cout, 3, flags)
+    # reference of the bit-for-bit comparisons: the octet-planar-output form (always the 2-D Winograd family); the plain channels-last
+    # call runs the same kernel - identical bits - unless the batch has <= 4096 voxels (16^3 at batch 1), where it is served by the
+    # in-workgroup split-K kernel (se_conv3d_f32_variant == 0): then equal to rounding
+    out_oct = torch.empty(B, cout // 8, dim, dim, dim, 8, device=DEV)
+    _lib.conv3d(x, pc.w, pc.b, res, out_oct, B, dim, cin, cin, cout, 3, flags | _lib.OUT_OCTET)
+    ref = out_oct.permute(0, 2, 3, 4, 1, 5).reshape(B, dim, dim, dim, cout).contiguous()
+    plain = torch.empty(B, dim, dim, dim, cout, device=DEV)
+    _lib.conv3d(x, pc.w, pc.b, res, plain, B, dim, cin, cin, cout, 3, flags)
+    if _lib.conv3d_variant(B, dim, cin, cout, 3) in (2, 3):
+        assert torch.equal(plain, ref)
+    else:
+        assert _lib.conv3d_variant(B, dim, cin, cout, 3) == 0 and B * dim ** 3 <= 4096
+        assert float((plain - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
     x_oct = x.view(B, dim, dim, dim, cin // 8, 8).permute(0, 4, 1, 2, 3, 5).contiguous()
     out = torch.empty_like(ref)
     _lib.conv3d(x_oct, pc.w, pc.b, res, out, B, dim, cin, cin, cout, 3, flags | _lib.IN_OCTET)
     assert torch.equal(out, ref)
-    out_oct = torch.empty(B, cout // 8, dim, dim, dim, 8, device=DEV)
-    _lib.conv3d(x, pc.w, pc.b, res, out_oct, B, dim, cin, cin, cout, 3, flags | _lib.OUT_OCTET)
-    assert torch.equal(out_oct.permute(0, 2, 3, 4, 1, 5).reshape(B, dim, dim, dim, cout), ref)
     _lib.conv3d(x_oct, pc.w, pc.b, res, out_oct, B, dim, cin, cin, cout, 3, flags | _lib.IN_OCTET | _lib.OUT_OCTET)
     assert torch.equal(out_oct.permute(0, 2, 3, 4, 1, 5).reshape(B, dim, dim, dim, cout), ref)
     if cin == cout:     # octet-planar skip tensor (SE_RES_OCTET): the block input doubles as skip tensor in Res3DBlock
