@@ -191,7 +191,7 @@ def main():
     dom = [t for t in table if t["shape"] == f"32->32@{G}^3"]
     dom_algo = 3 if sum("wino44pp" in t["kernel"] for t in dom) * 2 > len(dom) else 2
     k7 = [t for t in table if "conv3d_k7" in t["kernel"]]
-    rec = {"source": "tools/pmc_r03.py on the GPU box: separate rocprofv3 --kernel-trace --pmc passes over one bench.py step, per dispatch "
+    rec = {"source": "tools/pmc_round.py on the GPU box: separate rocprofv3 --kernel-trace --pmc passes over one bench.py step, per dispatch "
                      "(profiles/<TAG>_pmc_table.txt)",
            "abi_version": abi, "csrc_sha256_16": fingerprint, "batch": batch, "volume_size": G, "algo": dom_algo,
            "kernel": f"3x3x3 32->32 @{G}^3, B={batch}: the {len(dom)} launches of this shape in one step (" +
