@@ -413,7 +413,7 @@ def main():
                     "source": ("builder-side rocprofv3 pass, NOT measured in this run: " + os.path.relpath(PMC_FILE, ROOT) +
                                ": separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) on these kernel "
                                f"sources (csrc {pmc.get('csrc_sha256_16')}), " + pmc.get("correction", "")) if pmc else pmc_why,
-                    "counters": {k: pmc.get(k) for k in ("fetch_kib_raw", "write_kib", "mfma_busy_cycles_per_launch",
+                    "counters": {k: pmc.get(k) for k in ("fetch_kib_raw", "write_kib", "mfma_busy_cycles_per_launch", "mfma_pipe_busy_frac_of_launch",
                                                          "lds_bank_conflict_cycles", "lds_active_cycles")} if pmc else None},
             "stage": {"v2v_conv_ms_per_step": round(conv_ms_per_step, 3),
                       "v2v_tflops_algorithmic": round(V2V_GFLOP_PER_FRAME.get(G, 0) * args.batch / (conv_ms_per_step * 1e-3) / 1e3, 2)

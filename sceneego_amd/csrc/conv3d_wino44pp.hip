@@ -184,7 +184,10 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int G = wave >> 2;                    // group: y-tile of the tile
+#ifndef SE_K44P_SWAP
+#define SE_K44P_SWAP 0     // experiment: 1 = waves 4..7 are group 0 (does the asymmetry between the groups follow the role or the wave slot?)
+#endif
+    const int G = SE_K44P_SWAP ? 1 - (wave >> 2) : wave >> 2;      // group: y-tile of the tile
     const int wq = wave & 3;
     const int ct = wq >> 1;                     // cout tile of the 32-cout block
     const int zt = wq & 1;                      // z-tile
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
         const float* sp = src + piece * 256;        // uniform: the per-lane part of every LDS-DMA address is the same lane * 16 bytes
         const unsigned dst = __builtin_amdgcn_readfirstlane(
             (unsigned)(__UINTPTR_TYPE__)((float __attribute__((address_space(3)))*)(region + piece * 256)));      // LDS byte address
-        if (SE_K44P_EXP & 1) return;
+        if ((SE_K44P_EXP & 1) || ((SE_K44P_EXP & 64) && G == 1) || ((SE_K44P_EXP & 128) && G == 0)) return;      // 64 / 128: no DMAs of group 1 / 0
         const int l16 = lane16;                    // (asm operands do not capture: name a local of the lambda)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(l16), "s"(sp));
     };
@@ -528,10 +531,13 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
 #ifndef SE_K44P_ROW0
 #define SE_K44P_ROW0 8
 #endif
+#ifndef SE_K44P_DMA0
+#define SE_K44P_DMA0 1       // first group of group 0's phase that carries an LDS-DMA (behind its row loads when > SE_K44P_ROW0)
+#endif
 #ifndef SE_K44P_PRIO
 #define SE_K44P_PRIO 3
 #endif
-            constexpr int dma0 = GG == 0 ? 1 : SE_K44P_DMA1;               // first group that carries an LDS-DMA
+            constexpr int dma0 = GG == 0 ? SE_K44P_DMA0 : SE_K44P_DMA1;    // first group that carries an LDS-DMA
             constexpr int row0 = GG == 0 ? SE_K44P_ROW0 : 1;               // ... an input row
             constexpr bool dma = g >= dma0 && g < dma0 + (GG == 0 ? P_DMA_A : P_DMA_B);
             constexpr bool row = g >= row0 && g < row0 + 6;
@@ -600,17 +606,18 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
         auto staging = [&](auto last_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
             // rows: group 0's are its youngest vector-memory operations; behind group 1's fly the LDS-DMAs of half B
-            if constexpr (GG == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(P_DMA_B) : "memory");
+            constexpr bool dma_young = GG == 1 || SE_K44P_DMA0 > SE_K44P_ROW0;       // this group's DMAs were issued behind its rows
+            if constexpr (!dma_young) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(GG == 0 ? P_DMA_A : P_DMA_B) : "memory");
             pass1(tt);
             f32x4 rv[4][4];
             if constexpr (LAST) {
                 if (SE_K44P_EPRIO) __builtin_amdgcn_s_setprio(SE_K44P_EPRIO);
                 epilogue_y(ucur, rv);
-                // group 1: the weight half it issued has landed before anybody reads it (sixteen skip-tensor loads are younger)
-                if constexpr (GG == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                // the weight half this group issued has landed before anybody reads it (sixteen skip-tensor loads are younger)
+                if constexpr (dma_young) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             } else {
-                if constexpr (GG == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight half this group issued has landed
+                if constexpr (dma_young) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the weight half this group issued has landed
             }
             TP(4)
             barrier();                                                // mid-phase barrier
@@ -635,9 +642,11 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
 #ifdef SE_STAMP44P
             { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory"); __builtin_amdgcn_sched_barrier(0); }
 #endif
-            if (SE_K44P_PRIO) __builtin_amdgcn_s_setprio(SE_K44P_PRIO);
+            if (SE_K44P_PRIO > 0) __builtin_amdgcn_s_setprio(SE_K44P_PRIO);
+            if (SE_K44P_PRIO < 0) __builtin_amdgcn_s_setprio(0);                 // experiment: the STAGING wave above the MFMA wave
             mfma_phase(gg_tag, kind_tag);
-            if (SE_K44P_PRIO) __builtin_amdgcn_s_setprio(0);
+            if (SE_K44P_PRIO > 0) __builtin_amdgcn_s_setprio(0);
+            if (SE_K44P_PRIO < 0) __builtin_amdgcn_s_setprio(-(SE_K44P_PRIO));
             TP(2)
             barrier();                                                // end of the MFMA phase
             TP(3)

@@ -206,6 +206,9 @@ def main():
                     "write_bytes_per_launch": int(mean("WRITE_SIZE") * 1024),
                     "mfma_busy_cycles_per_launch": int(mean("SQ_VALU_MFMA_BUSY_CYCLES")),
                     "lds_bank_conflict_cycles": int(mean("SQ_LDS_BANK_CONFLICT")), "lds_active_cycles": int(mean("SQ_LDS_IDX_ACTIVE")),
+                    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES over the 256 x 4 SIMDs
+                    "gui_active_cycles_all_xcds": int(mean("GRBM_GUI_ACTIVE")),
+                    "mfma_pipe_busy_frac_of_launch": round(mean("SQ_VALU_MFMA_BUSY_CYCLES") / 1024.0 / max(1.0, mean("GRBM_GUI_ACTIVE") / 8.0), 4),
                     "per_launch": [{"pos": t["pos"], "kernel": t["kernel"],
                                     "hbm_bytes": int((2 * t["counters"].get("FETCH_SIZE", 0) + t["counters"].get("WRITE_SIZE", 0)) * 1024)}
                                    for t in dom]})
