@@ -569,6 +569,28 @@ def batch_extra(net, pipe, batch, rank, device, depth_kind, graphs):
                 torch.cuda.synchronize()
                 dtp = (time.perf_counter() - t0) / (steps * 2)
             r["pipelined"] = {"value": round(batch / dtp, 2), "ms_per_step": round(dtp * 1e3, 3), "streams": len(pipe)}
+            if graphs:
+                # ... and with every replica's forward replayed as a captured hipGraph: at batch 1 the eager pipeline is bound by the
+                # host's launch rate (~175 launches per frame from one Python thread), a replay is one call per frame
+                for n in pipe.nets:
+                    n.enable_graphs(True)
+                try:
+                    with torch.no_grad():
+                        for _ in range(2 * len(pipe)):
+                            pipe(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth, inputs_ready=False)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(steps * 3):
+                            out_g, _ = pipe(img, net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth, inputs_ready=False)
+                        torch.cuda.synchronize()
+                        dtg = (time.perf_counter() - t0) / (steps * 3)
+                    kp_e = net.__class__.forward(pipe.nets[0].enable_graphs(False), img, net.grid_coord_proj_batch, net.coord_volumes,
+                                                 depth_map_batch=depth)[0]
+                    r["pipelined_hipgraph"] = {"value": round(batch / dtg, 2), "ms_per_step": round(dtg * 1e3, 3), "streams": len(pipe),
+                                               "max_joint_diff_to_eager_m": round(float((out_g[0] - kp_e).abs().max()), 9)}
+                finally:
+                    for n in pipe.nets:
+                        n.enable_graphs(False)
         return r
     except Exception as e:      # never let the side measurement break the headline line
         return {"error": repr(e)[:200]}

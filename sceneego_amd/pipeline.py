@@ -82,6 +82,15 @@ class PipelinedForward:
     def __len__(self):
         return len(self.nets)
 
+    def enable_graphs(self, flag: bool = True):
+        """Replay every replica's forward as a captured hipGraph (``VoxelNetwork_depth.enable_graphs``).  At batch 1 the eager pipeline is
+        bound by the host's launch rate (~175 launches per frame from one Python thread): three streams give 357 frames/s eager and 567
+        with graph replay on one MI355X (tools/diag/streams_graphs_sweep.py; batch 8: 910 / 915).  A replayed forward returns the replica's
+        STATIC output tensors: they are overwritten by that replica's next call (``len(self)`` calls later) - consume or copy them before."""
+        for n in self.nets:
+            n.enable_graphs(flag)
+        return self
+
     @torch.no_grad()
     def __call__(self, *args, inputs_ready=None, **kwargs):
         k = self._next
