@@ -401,3 +401,16 @@ def test_pipelined_forward_matches_plain_forward(net64):
         PipelinedForward.hand_over(out, done)
         err = float((out[0] - ref[n % 2][0]).abs().max())
         assert err < 1e-4, (n, err)
+    # round 4: every replica replayed as a captured hipGraph (the throughput mode of batch 1, where the eager pipeline is bound by the
+    # host's launch rate).  A replayed forward returns the replica's static output tensors: read them before that replica runs again
+    pf.enable_graphs(True)
+    try:
+        for rep in range(3):
+            for n, (i, d) in enumerate(dev_in):
+                out, done = pf(i, net64.grid_coord_proj_batch, net64.coord_volumes, depth_map_batch=d)
+                done.synchronize()
+                err = float((out[0] - ref[n][0]).abs().max())
+                assert err < 1e-4, (rep, n, err)
+        assert all(len(r._graphs) == 1 for r in pf.nets)
+    finally:
+        pf.enable_graphs(False)
