@@ -50,6 +50,12 @@ def test_pure_host_entry_points():
     # which kernel a launch runs on: 3 = F(4,3) x F(4,3) ping-pong at the 64^3 / 32^3 levels, 2 = F(4,3) x F(2,3) at 16^3
     assert lib.se_conv3d_f32_variant(8, 64, 32, 32, 3) == 3 and lib.se_conv3d_f32_variant(8, 16, 128, 128, 3) == 2
     assert lib.se_conv3d_f32_variant(8, 64, 33, 16, 7) == 7 and lib.se_conv3d_f32_variant(1, 64, 32, 32, 3) == 3
+    # <= 4096 voxels in the batch (16^3 at batch 1): the plain call of a 2-D Winograd shape is served by the in-workgroup split-K kernel
+    assert lib.se_conv3d_f32_variant(1, 16, 128, 128, 3) == 0 and lib.se_conv3d_f32_variant(2, 16, 128, 128, 3) == 2
+    # soft-argmax partial records: 8 floats per (row, chunk); 256 chunks per row at batch 1 (15 rows), 32 from batch 8 (120 rows) on
+    lib.se_softargmax3d_scratch_elems.restype = ctypes.c_longlong
+    assert lib.se_softargmax3d_scratch_elems(15) == 15 * 256 * 8 and lib.se_softargmax3d_scratch_elems(30) == 30 * 128 * 8
+    assert lib.se_softargmax3d_scratch_elems(60) == 60 * 64 * 8 and lib.se_softargmax3d_scratch_elems(120) == 120 * 32 * 8
     # packed weight sizes: taps * cin_pad/16 * ceil(cout/16) * 256 floats
     assert lib.se_conv3d_packed_elems(32, 32, 3, 0) == 27 * 2 * 2 * 256 + 2 * 9 * 4 * 2 * 256 + 2 * 9 * 6 * 2 * 256 + 4 * 24 * 3 * 2 * 128 \
         + 8 * 9 * 3 * 2 * 256   # + F(2,3), F(4,3), F(4,3)xF(2,3), F(4,3)xF(4,3) (section I: 8 four-channel chunks of 55,296 B)
