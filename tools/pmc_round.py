@@ -34,6 +34,8 @@ PASSES = [
     ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES"],
     ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"],
     ["GRBM_GUI_ACTIVE"],
+    ["SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS"],      # round 4: how busy the vector ALUs are beside the MFMAs
+    ["SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_ACTIVE_INST_VMEM", "SQ_INST_CYCLES_SALU"],
 ]
 BENCH = ["python3", "bench.py", "--steps", "2", "--warmup", "1", "--streams", "1", "--no-cpu-baseline", "--no-parity",
          "--no-kernel-events", "--no-extras"]
