@@ -1,0 +1,75 @@
+"""Soak test of the F(4,3) x F(4,3) ping-pong 3^3 kernel (conv3d_wino44pp.hip: LDS-DMA weight halves in three rotating slots with
+hand-written counted vmcnt waits, four workgroup barriers per step, output stores parked in accumulator registers across a tile
+boundary): the kernel is deterministic, so N launches on the same input must be bit-identical to the first; any difference is a race.
+Every third launch runs beside memory traffic on a second stream (it stretches the DMA landing times), and the first output is
+compared with torch's float32 convolution once per form.  usage: python tools/diag/k44p_race_soak.py [N]"""
+import os, sys
+import torch
+import torch.nn.functional as F
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
+from sceneego_amd import _lib
+from sceneego_amd.v2v import _PackedConv
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+dev = "cuda:0"
+oct_ = lambda t: t.view(t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.shape[4] // 8, 8).permute(0, 4, 1, 2, 3, 5).contiguous()
+unoct = lambda t: t.permute(0, 2, 3, 4, 1, 5).reshape(t.shape[0], t.shape[2], t.shape[3], t.shape[4], t.shape[1] * 8)
+bad = 0
+#          B  dim cin cout  skip   pool   skip16 in_oct
+FORMS = [(8, 64, 32, 32, True, False, False, True), (8, 64, 32, 32, False, False, False, True), (8, 64, 32, 32, True, True, False, True),
+         (8, 64, 32, 32, False, False, True, True), (8, 64, 16, 32, False, False, False, False), (8, 32, 64, 64, True, False, False, True),
+         (8, 32, 32, 64, False, False, False, True), (1, 64, 32, 32, True, False, False, True), (3, 64, 32, 32, True, False, False, True),
+         (2, 128, 32, 32, True, False, False, True)]
+for B, dim, cin, cout, skip, pool, skip16, in_oct in FORMS:
+    torch.manual_seed(dim + cin + cout)
+    conv = torch.nn.Conv3d(cin, cout, 3, padding=1).to(dev)
+    pc = _PackedConv(conv, None, None, torch.float32)
+    assert _lib.conv3d_variant(B, dim, cin, cout, 3) == 3
+    x = torch.randn(B, dim, dim, dim, cin, device=dev)
+    res = torch.randn(B, dim, dim, dim, cout, device=dev) if skip else None
+    flags = _lib.EPI_RELU | _lib.OUT_OCTET | (_lib.IN_OCTET if in_oct else 0) | ((_lib.EPI_RES_PRE_RELU | _lib.RES_OCTET) if skip else 0)
+    xin = oct_(x) if in_oct else x
+    rin = oct_(res) if skip else None
+    pooled = torch.empty(B, dim // 2, dim // 2, dim // 2, cout, device=dev) if pool else None
+    xs = torch.randn(B, dim, dim, dim, 16, device=dev) if skip16 else None
+    wsk = (torch.randn(cout, 16, device=dev) * 0.2).contiguous() if skip16 else None
+
+    def launch(o):
+        if skip16:
+            _lib.conv3d_skip16(xin, pc.w, pc.b, xs, wsk, o, B, dim, cin, cout, _lib.EPI_RELU | _lib.IN_OCTET | _lib.OUT_OCTET)
+        else:
+            _lib.conv3d(xin, pc.w, pc.b, rin, o, B, dim, cin, cin, cout, 3, flags, None, pool_out=pooled)
+
+    ref = torch.empty(B, cout // 8, dim, dim, dim, 8, device=dev)
+    launch(ref)
+    pref = pooled.clone() if pool else None
+    if dim <= 64 and B <= 3 or (B, dim, cin, skip, pool, skip16) == (8, 64, 32, True, False, False):
+        with torch.no_grad():
+            want = F.conv3d(x[:1].permute(0, 4, 1, 2, 3).cpu(), conv.weight.cpu(), conv.bias.cpu(), padding=1)
+            if skip:
+                want = want + res[:1].permute(0, 4, 1, 2, 3).cpu()
+            if skip16:
+                want = want + torch.einsum("oc,bzyxc->bozyx", wsk.cpu(), xs[:1].cpu())
+            want = F.relu(want)
+        err = float((unoct(ref)[:1].permute(0, 4, 1, 2, 3).cpu() - want).abs().max())
+        assert err < 2e-5 * max(1.0, float(want.abs().max())), err
+    out = torch.empty_like(ref)
+    n_bad = 0
+    s2 = torch.cuda.Stream()
+    junk = torch.randn(64 << 20, device=dev)
+    n = N if dim < 128 else max(8, N // 10)
+    for i in range(n):
+        out.fill_(-1.0)
+        if pool:
+            pooled.fill_(-1.0)
+        if i % 3 == 1:      # memory traffic on a second stream beside the kernel
+            with torch.cuda.stream(s2):
+                junk.mul_(1.0001)
+        launch(out)
+        if not torch.equal(out, ref) or (pool and not torch.equal(pooled, pref)):
+            n_bad += 1
+    torch.cuda.synchronize()
+    print(f"3^3 {cin}->{cout} @{dim}^3 B={B} skip={skip} pool={pool} skip16={skip16} input {'octet-planar' if in_oct else 'channels-last'}: "
+          f"{n_bad} of {n} launches differed from the first", flush=True)
+    bad += n_bad
+assert bad == 0
+print("soak ok")
