@@ -187,8 +187,19 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
         constexpr int NWI = decltype(n_tag)::value, J = decltype(j_tag)::value;
         int piece = J * 8 + wave_u;
         piece = piece < NWI ? piece : NWI - 1;
+#ifndef SE_K67_DMA_BUILTIN
+        // Inline assembly, not __builtin_amdgcn_global_load_lds (round 4, found on the F(4,3) x F(4,3) kernel): hipcc models the builtin
+        // as an LDS access of unknown address, after which every operand wait of the item is an s_waitcnt lgkmcnt(0) - for the reads just
+        // issued three groups ahead as well (disassembly: 50 of them per 444 MFMAs).  The landing of the DMAs is covered by the counted
+        // vmcnt waits in front of the two barriers below, as before.
+        const float* sp = src + piece * 256;        // uniform; the per-lane part of every LDS-DMA address is the same lane * 16 bytes
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)((float __attribute__((address_space(3)))*)(region + piece * 256)));
+        const int l16 = lane * 16;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(l16), "s"(sp));
+#else
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (piece * 64 + lane) * 4),
                                          (void __attribute__((address_space(3)))*)(region + piece * 256), 16, 0, 0);
+#endif
     };
     using NA = std::integral_constant<int, S_GA * 3>;
     using NB = std::integral_constant<int, (S_G - S_GA) * 3>;
