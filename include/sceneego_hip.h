@@ -44,6 +44,11 @@ extern "C" {
 #define SE_OUT_OCTET         64  /* [B][C/8][D][D][D][8] (channel c at octet c/8, slot c%8) / `out` is written that way /          */
 #define SE_RES_OCTET         128 /* the skip tensor `residual` is read that way                                                 */
 #define SE_EPI_SKIPCONV16    256 /* set by se_conv3d_skip16_f32 only (not a caller flag of se_conv3d_f32)                       */
+#define SE_WS_COUNTERS       512 /* se_conv3d_f32 / se_conv3d_pool_f32: `workspace` was prepared by se_conv3d_workspace_init() and
+                                  * is used by launches of ONE stream at a time: the split-K levels then reduce in the last-arriving
+                                  * workgroup (arrival counters in the last SE_WS_COUNTER_ELEMS floats of the workspace, zero between
+                                  * launches) instead of a second launch.  Same sums in the same order as without the flag.       */
+#define SE_WS_COUNTER_ELEMS  1024
 
 /* ABI version; bumped on any signature change. */
 int se_abi_version(void);
@@ -134,6 +139,11 @@ long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, int transpose
 int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
                   float* out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
                   float* workspace, long long workspace_elems, void* stream);
+
+/* Zeroes the arrival counters in the tail of a split-K workspace (once, before the first launch that passes SE_WS_COUNTERS; every
+ * such launch leaves them zero).  workspace_elems >= 2 * SE_WS_COUNTER_ELEMS.  The reference has no counterpart: it is part of what
+ * lets a Conv3d + BatchNorm3d (+ReLU) (+skip) of the 4^3 / 2^3 levels (network/v2v.py:80-87,100-102) be ONE launch. */
+int se_conv3d_workspace_init(float* workspace, long long workspace_elems, void* stream);
 
 /* se_conv3d_f32 that also writes max_pool3d(out, kernel 2, stride 2) from the kernel's epilogue: `pool_out` is channels-last
  * [B][D/2][D/2][D/2][cout] float32.  Stands in for a Res3DBlock's last convolution followed by encoder_pool (reference
@@ -285,10 +295,15 @@ int se_bias_act_nchw_bf16(const se_bf16* x, const se_bf16* bias, const se_bf16* 
  *   7 1-D Winograd along z for the 7x7x7 front layer: F(6,7) (12/42 of the direct products) when dim % 16 == 0, else F(4,7) (10/28).
  * Pure function of the arguments; no device access. */
 int se_conv3d_f32_algo(int dim, int cin, int cout, int ksize);
-/* Which kernel a 3x3x3 launch of `batch` samples really runs on: se_conv3d_f32_algo()'s value, except 3 = the F(4,3) x F(4,3)
- * ping-pong kernel (a member of the 2-D Winograd family: every layout / flag / fused form of algo 2 applies; it executes 1/4 of the
- * direct convolution's MFMAs, algo 2 executes 1/3).  bench.py prices its roofline with it. */
-int se_conv3d_f32_variant(int batch, int dim, int cin, int cout, int ksize);
+/* Which kernel a launch of `batch` samples with these flags really runs on: se_conv3d_f32_algo()'s value, except
+ *   3 = the F(4,3) x F(4,3) ping-pong kernel (a member of the 2-D Winograd family: every layout / flag / fused form of algo 2 applies;
+ *       it executes 1/4 of the direct convolution's MFMAs, algo 2 executes 1/3).  It takes an octet-planar input (SE_IN_OCTET) or a
+ *       channels-last one with fewer than 32 channels; a channels-last input with >= 32 channels stays on algo 2;
+ *   0 for a 2-D Winograd shape with <= 4096 voxels in the batch when `flags` asks for none of the octet-planar forms (such a call
+ *       runs on the in-workgroup split-K kernel).
+ * `flags`: the SE_IN_OCTET / SE_OUT_OCTET / SE_RES_OCTET bits of the launch (others ignored).  bench.py prices every launch of its
+ * roofline with it. */
+int se_conv3d_f32_variant(int batch, int dim, int cin, int cout, int ksize, int flags);
 
 #ifdef SE_DEVTOOLS
 /* Development builds only (csrc/build.sh --devtools; absent from the production library): A/B kernel selection for

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -23,6 +23,8 @@ EPI_OUT_PLANAR = 8
 IN_OCTET = 32       # se_conv3d_f32, 2-D Winograd 3x3x3 shapes: octet-planar input [B][C/8][D][D][D][8]
 OUT_OCTET = 64      # ... octet-planar output
 RES_OCTET = 128     # ... octet-planar skip tensor
+WS_COUNTERS = 512   # se_conv3d_f32: the workspace carries zeroed arrival counters (conv3d_workspace_init): split-K levels in one launch
+WS_COUNTER_ELEMS = 1024
 IN_PLANAR3 = 16     # se_conv3d_f32, k = 7: triplet-planar input [B][ceil(cin/3)][D][D][D][3]
 
 _vp, _i, _f, _d, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong
@@ -63,7 +65,8 @@ SIGNATURES = {
     "se_preprocess_image_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "se_bias_act_nchw_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_conv3d_f32_algo": (_i, [_i, _i, _i, _i]),
-    "se_conv3d_f32_variant": (_i, [_i, _i, _i, _i, _i]),
+    "se_conv3d_f32_variant": (_i, [_i, _i, _i, _i, _i, _i]),
+    "se_conv3d_workspace_init": (_i, [_vp, _ll, _vp]),
     "se_conv3d_split3_packed_elems": (_ll, [_i, _i]),
     "se_conv3d_split3_pack": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "se_conv3d_k3_split3_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -276,11 +279,19 @@ def conv3d_packed_elems(cout, cin_pad, ksize, transposed, bf16=False) -> int:
     return n
 
 
-def conv3d_variant(batch, dim, cin, cout, ksize) -> int:
-    """The kernel a PLAIN channels-last launch of ``batch`` samples runs on: conv3d_algo()'s value, except 3 = the F(4,3) x F(4,3)
-    member of the 2-D Winograd family (same flags / layouts as 2) and 0 for a 2-D Winograd shape with <= 4096 voxels in the batch
-    (16^3 at batch 1), which the in-workgroup split-K kernel serves better; the V2V program keeps such a level channels-last."""
-    return int(load().se_conv3d_f32_variant(batch, dim, cin, cout, ksize))
+def conv3d_variant(batch, dim, cin, cout, ksize, flags=0) -> int:
+    """The kernel a launch of ``batch`` samples with these layout flags (IN_OCTET ...) runs on: conv3d_algo()'s value, except 3 = the
+    F(4,3) x F(4,3) member of the 2-D Winograd family (same flags / layouts as 2; it takes an octet-planar input or a channels-last one
+    with < 32 channels) and 0 for a 2-D Winograd shape with <= 4096 voxels in the batch (16^3 at batch 1) called without octet-planar
+    forms, which the in-workgroup split-K kernel serves better; the V2V program keeps such a level channels-last."""
+    return int(load().se_conv3d_f32_variant(batch, dim, cin, cout, ksize, flags))
+
+
+def conv3d_workspace_init(workspace):
+    """Zero the arrival counters in the tail of a split-K workspace (once; launches with WS_COUNTERS leave them zero)."""
+    require_hip(workspace)
+    _chk_f32(workspace)
+    _check(load().se_conv3d_workspace_init(_ptr(workspace), workspace.numel(), _stream()), "se_conv3d_workspace_init")
 
 
 def conv3d_algo(dim, cin, cout, ksize) -> int:
@@ -305,6 +316,7 @@ def conv3d_pack(w, b, gamma, beta, mean, var, eps, wpack, bpack, cout, cin, cin_
 # Optional per-launch timing (bench.py's roofline leg): HIP events recorded on the launch stream around every
 # conv launch, keyed by shape.  None = off (the default; nothing is recorded in normal operation).
 _prof = None
+last_launch_detail = []     # (key, flags or None, ms) of every launch of the last profiled pass, in issue order (bench.py: per-launch kernel variant)
 last_launch_order = []      # launch keys of the last profiled pass, in issue order (tools/pmc_r03.py labels rocprofv3 dispatches with it)
 
 
@@ -315,12 +327,18 @@ def start_profile():
 
 def stop_profile():
     """-> {key: [ms, ...]} ; caller must have synchronised the device."""
-    global _prof, last_launch_order
+    global _prof, last_launch_order, last_launch_detail
     rec, _prof = _prof, None
     out = {}
-    for key, e0, e1 in rec or []:
-        out.setdefault(key, []).append(e0.elapsed_time(e1))
-    last_launch_order = [key for key, _, _ in rec or [] if key[0] != "stage"]
+    detail = []
+    for r in rec or []:
+        key, e0, e1 = r[0], r[1], r[2]
+        ms = e0.elapsed_time(e1)
+        out.setdefault(key, []).append(ms)
+        if key[0] != "stage":
+            detail.append((key, r[3] if len(r) > 3 else None, ms))
+    last_launch_order = [d[0] for d in detail]
+    last_launch_detail = detail
     return out
 
 
@@ -346,8 +364,9 @@ class stage:
 class _timed:
     """HIP events around one launch when profiling is on (bench.py); a no-op otherwise."""
 
-    def __init__(self, key):
+    def __init__(self, key, flags=None):
         self.key = key
+        self.flags = flags
 
     def __enter__(self):
         if _prof is not None:
@@ -357,7 +376,7 @@ class _timed:
     def __exit__(self, *exc):
         if _prof is not None and exc[0] is None:
             self.e1.record()
-            _prof.append((self.key, self.e0, self.e1))
+            _prof.append((self.key, self.e0, self.e1, self.flags))
         return False
 
 
@@ -390,7 +409,7 @@ def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksi
                                     0 if workspace is None else workspace.numel(), _stream()), "se_conv3d_f32")
     if _prof is not None:
         e1.record()
-        _prof.append((("conv3d" if inp.dtype == torch.float32 else "conv3d_bf16", ksize, cin_pad, cout, dim), e0, e1))
+        _prof.append((("conv3d" if inp.dtype == torch.float32 else "conv3d_bf16", ksize, cin_pad, cout, dim), e0, e1, flags))
 
 
 def conv3d_split3_pack(w_folded, cout, cin, cin_pad):
@@ -422,7 +441,7 @@ def conv3d_skip16(inp, wpack, bpack_sum, skip_in, skip_w, out, batch, dim, cin, 
     require_hip(inp, out, skip_in, skip_w, bpack_sum)
     _chk_f32(inp, out, skip_in, skip_w, bpack_sum)
     assert skip_in.shape[-1] == 16 and tuple(skip_w.shape) == (cout, 16) and skip_w.is_contiguous() and skip_in.is_contiguous()
-    with _timed(("conv3d", 3, cin, cout, dim)):
+    with _timed(("conv3d", 3, cin, cout, dim), flags | 256):        # 256 = SE_EPI_SKIPCONV16 (the entry point sets it)
         _check(load().se_conv3d_skip16_f32(_ptr(inp), _ptr(wpack), _ptr(bpack_sum), _ptr(skip_in), _ptr(skip_w), _ptr(out), batch,
                                            dim, cin, cout, flags, _stream()), "se_conv3d_skip16_f32")
 

@@ -28,7 +28,8 @@ for f in voxelize gather softargmax conv3d conv3d_tiled conv3d_wino conv3d_wino2
   [ "$f" = voxelize ] && extra="-ffp-contract=off"
   # no SLP packing of float32 arithmetic into v_pk_*_f32: packed VALU beside an MFMA stream is an anti-lever (see commit() there)
   [ "$f" = conv3d_wino2d ] && extra="-fno-slp-vectorize"
-  [ "$f" = conv3d_wino44pp ] && extra="-fno-slp-vectorize"
+  [ "$f" = conv3d_wino44pp ] && extra="-fno-slp-vectorize -Wno-inline-asm"      # -Wno-inline-asm: the "m0" clobber of the LDS-DMA asm (reserved register)
+  [ "$f" = conv3d_wino67 ] && extra="-Wno-inline-asm"
   if newer $f.hip $OBJ/$f.o; then
     hipcc $FLAGS $extra -c $f.hip -o $OBJ/$f.o &
     pids+=($!)
@@ -53,6 +54,14 @@ done
 rc=0
 for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait $p || rc=1; }; done
 [ $rc -eq 0 ] || { echo "build.sh: compilation failed" >&2; exit 1; }
+# the kernels with hand-counted vmcnt waits around inline-assembly LDS-DMAs: no VGPR spill, no scratch, M0 written only
+# by the asm - or the build fails (check_codeobj.py says why).  Attribution builds (extra flags) may spill: checked, not fatal, there.
+for f in conv3d_wino44pp conv3d_wino67; do
+  if ! python3 check_codeobj.py $OBJ/$f.o; then
+    if [ -z "$*" ]; then echo "build.sh: $f.hip violates the conditions its hand-counted waits rely on" >&2; exit 1; fi
+    echo "build.sh: (extra flags given: continuing)" >&2
+  fi
+done
 # explicit object list: a stale object of a removed / renamed source in the same key directory is never linked
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT "${OBJS[@]}"
 # the hash of the sources this binary was built from (sceneego_amd/_lib.py: built_fingerprint / source_fingerprint): counter records

@@ -405,8 +405,13 @@ __global__ __launch_bounds__(256) void deconv3d_k2s2_kernel(ConvArgs a) {
 // (voxel tile, cout tile, tap slice) is its own workgroup writing a partial sum to the workspace, and a second
 // tiny kernel adds the slices in a FIXED order (bitwise deterministic, no atomics) and applies the epilogue.
 // ------------------------------------------------------------------------------------------------
-template <int N_T>
-__global__ __launch_bounds__(256) void conv3d_k3_splitk_kernel(ConvArgs a, float* __restrict__ ws, int taps_per_split) {
+// FUSED (round 5; SE_WS_COUNTERS): no second launch - every (voxel tile, cout pair) has an arrival counter in the tail of the workspace
+// (zero before the first launch, se_conv3d_workspace_init; the last block leaves it zero again); the block that arrives LAST for its
+// tile adds the `splits` partials in the same fixed order 0, 1, ... as splitk_reduce_kernel (bit-identical, deterministic whichever
+// block is last) and applies the epilogue.  Partials cross XCDs: release fence (L2 write-back) in front of the arrival, acquire fence
+// (invalidate) behind it - the pattern of a kernel boundary, without the boundary.
+template <int N_T, bool FUSED>
+__global__ __launch_bounds__(256) void conv3d_k3_splitk_kernel(ConvArgs a, float* __restrict__ ws, int taps_per_split, unsigned* __restrict__ counters) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int vl = lane & 15;
@@ -457,10 +462,46 @@ __global__ __launch_bounds__(256) void conv3d_k3_splitk_kernel(ConvArgs a, float
             }
         }
     }
-    if (!vok) return;
-    float* o = ws + ((size_t)split * a.total_vox + vid) * a.cout;
+    if (vok) {
+        float* o = ws + ((size_t)split * a.total_vox + vid) * a.cout;
 #pragma unroll
-    for (int n = 0; n < N_T; ++n) *reinterpret_cast<f32x4*>(o + (nt0 + n) * 16 + 4 * h) = acc[n];
+        for (int n = 0; n < N_T; ++n) *reinterpret_cast<f32x4*>(o + (nt0 + n) * 16 + 4 * h) = acc[n];
+    }
+    if constexpr (FUSED) {
+        __shared__ int s_last;
+        const int splits = (int)gridDim.z;
+        __threadfence();                                   // release: this thread's partials are visible device-wide ...
+        __syncthreads();                                   // ... before the block's arrival is counted
+        unsigned* cnt = counters + blockIdx.y * gridDim.x + blockIdx.x;
+        if (threadIdx.x == 0) {
+            const unsigned old = atomicAdd(cnt, 1u);
+            s_last = old == (unsigned)(splits - 1);
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();                                   // acquire: the other blocks' partials
+        if (threadIdx.x == 0) *cnt = 0;                    // ready for the next launch (stream order)
+        // the tile: 64 voxels x N_T * 16 couts = 64 x N_T * 4 (voxel, cout quad) items for 256 threads
+        const long long per_b = (long long)dim * dim * dim;
+        const size_t sstride = (size_t)a.total_vox * a.cout;
+        constexpr int QUADS = N_T * 4;
+        for (int it = threadIdx.x; it < 64 * QUADS; it += 256) {
+            const long long v2 = (long long)blockIdx.x * 64 + it / QUADS;
+            if (v2 >= a.total_vox) continue;
+            const int co = nt0 * 16 + (it % QUADS) * 4;
+            const float* p0 = ws + v2 * a.cout + co;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < splits; s0 += 9) {       // all partials of a group requested before the first add; the order of the sum is fixed
+                f32x4 part[9];
+#pragma unroll
+                for (int u = 0; u < 9; ++u) part[u] = (s0 + u < splits) ? *reinterpret_cast<const f32x4*>(p0 + (size_t)(s0 + u) * sstride) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 9; ++u) v += part[u];
+            }
+            const int b = (int)(v2 / per_b);
+            conv_epilogue(a, v, b, v2 - (long long)b * per_b, per_b, co);
+        }
+    }
 }
 
 // In-workgroup split-K for the small pyramid levels (8^3, 4^3, 2^3; 128 -> 128 channels): the WAVES waves of a workgroup share ONE
@@ -868,7 +909,7 @@ int launch_direct(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int se_abi_version(void) { return 11; }
+extern "C" int se_abi_version(void) { return 12; }
 
 // Mirrors the dispatch of se_conv3d_f32 -> se_conv3d_tiled_try -> se_conv3d_wino_try / se_conv3d_k7_wino_try for the
 // default channels-last call (no SE_EPI_OUT_PLANAR / SE_EPI_RES_POST_RELU flags).
@@ -879,13 +920,18 @@ extern "C" int se_conv3d_f32_algo(int dim, int cin, int cout, int ksize) {
     return 0;
 }
 
-// Which 3x3x3 kernel a launch of `batch` samples runs on: se_conv3d_f32_algo's value, except 3 = the F(4,3) x F(4,3) ping-pong kernel
-// (conv3d_wino44pp.hip; a member of the 2-D Winograd family: same layouts, flags and fused forms as algo 2).
+// Which kernel a launch of `batch` samples with these layout flags (SE_IN_OCTET ...) runs on: se_conv3d_f32_algo's value, except
+//   3 = the F(4,3) x F(4,3) ping-pong kernel (conv3d_wino44pp.hip; a member of the 2-D Winograd family: same layouts, flags and fused
+//       forms as algo 2) - it declines a channels-last input with >= 32 channels, which stays on algo 2 (se_conv3d_wino44pp_takes);
+//   0 for a 2-D Winograd shape with <= 4096 voxels in the batch when the call asks for no octet-planar / pooled / fused form.
+// Mirrors se_conv3d_tiled_try / se_conv3d_wino2d_try for the WHOLE batch (a batch above 32 is cut into slices that keep this decision).
 bool se_conv3d_wino44pp_shape(int batch, int dim, int cout);      // conv3d_wino44pp.hip
-extern "C" int se_conv3d_f32_variant(int batch, int dim, int cin, int cout, int ksize) {
+bool se_conv3d_wino44pp_layout_ok(int cin, int flags);
+extern "C" int se_conv3d_f32_variant(int batch, int dim, int cin, int cout, int ksize, int flags) {
     const int algo = se_conv3d_f32_algo(dim, cin, cout, ksize);
-    if (algo == 2 && se_conv3d_small_volume(batch, dim)) return 0;       // a plain channels-last call runs the in-workgroup split-K form
-    if (algo == 2 && g_variant != 64 && se_conv3d_wino44pp_shape(batch, dim, cout)) return 3;
+    const bool forms = flags & (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET | SE_EPI_SKIPCONV16);
+    if (algo == 2 && !forms && se_conv3d_small_volume(batch, dim)) return 0;       // a plain channels-last call runs the in-workgroup split-K form
+    if (algo == 2 && g_variant != 64 && se_conv3d_wino44pp_shape(batch, dim, cout) && se_conv3d_wino44pp_layout_ok(cin, flags)) return 3;
     return algo;
 }
 
@@ -960,6 +1006,7 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
                            float* workspace, long long workspace_elems, void* stream) {
     if (batch <= 0 || dim <= 0 || cin <= 0 || cin_pad < cin || (cin_pad & 15) || cout <= 0) return SE_ERR_BAD_ARG;
     if (ksize != 1 && ksize != 3 && ksize != 7) return SE_ERR_BAD_ARG;
+    if ((flags & SE_WS_COUNTERS) && (!workspace || workspace_elems < 2 * SE_WS_COUNTER_ELEMS)) return SE_ERR_BAD_ARG;
     const bool planar = flags & SE_EPI_OUT_PLANAR;
     if (!planar && (cout & 15)) return SE_ERR_BAD_ARG;
     if (planar && (flags & (SE_EPI_RES_PRE_RELU | SE_EPI_RES_POST_RELU))) return SE_ERR_BAD_ARG;
@@ -968,7 +1015,7 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
     ConvArgs a;
     a.in = in; a.wpack = wpack; a.bpack = bpack; a.res = residual; a.out = out;
     a.total_vox = (long long)batch * dim * dim * dim;
-    a.dim = dim; a.cin = cin; a.cin_pad = cin_pad; a.cout = cout; a.nts = round_up16(cout) / 16; a.flags = flags;
+    a.dim = dim; a.cin = cin; a.cin_pad = cin_pad; a.cout = cout; a.nts = round_up16(cout) / 16; a.flags = flags & ~SE_WS_COUNTERS;
     a.wpack_b = wpack + packed_elems_a(cout, cin_pad, ksize, 0);
     a.wpack_d = nullptr;
     if (ksize == 7 && cout <= 16)
@@ -1015,11 +1062,20 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
         const long long wgs = m_blocks * (a.nts / 2);
         if (wgs < 1024) {
             int splits = 27;                                  // taps per split: 1, 3, 9 (or no split)
-            while (splits > 1 && (wgs * (splits / 3) >= 2048 || (long long)splits * a.total_vox * cout > workspace_elems))
+            const long long ws_partials = (flags & SE_WS_COUNTERS) ? workspace_elems - SE_WS_COUNTER_ELEMS : workspace_elems;
+            while (splits > 1 && (wgs * (splits / 3) >= 2048 || (long long)splits * a.total_vox * cout > ws_partials))
                 splits /= 3;
+            if (splits > 1 && (flags & SE_WS_COUNTERS)) {
+                // one launch: the last-arriving block of a tile reduces (counters in the workspace tail, zero between launches)
+                unsigned* counters = reinterpret_cast<unsigned*>(workspace + workspace_elems - SE_WS_COUNTER_ELEMS);
+                hipLaunchKernelGGL((conv3d_k3_splitk_kernel<2, true>), dim3((unsigned)m_blocks, a.nts / 2, splits), dim3(256), 0, s,
+                                   a, workspace, 27 / splits, counters);
+                SE_CHECK_LAUNCH();
+                return 0;
+            }
             if (splits > 1) {
-                hipLaunchKernelGGL((conv3d_k3_splitk_kernel<2>), dim3((unsigned)m_blocks, a.nts / 2, splits), dim3(256), 0, s,
-                                   a, workspace, 27 / splits);
+                hipLaunchKernelGGL((conv3d_k3_splitk_kernel<2, false>), dim3((unsigned)m_blocks, a.nts / 2, splits), dim3(256), 0, s,
+                                   a, workspace, 27 / splits, nullptr);
                 SE_CHECK_LAUNCH();
                 const long long threads = a.total_vox * (cout / 4);
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a,
@@ -1034,6 +1090,12 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
         case 3: return launch_direct<3>(a, s);
         default: return launch_direct<7>(a, s);
     }
+}
+
+extern "C" int se_conv3d_workspace_init(float* workspace, long long workspace_elems, void* stream) {
+    if (!workspace || workspace_elems < 2 * SE_WS_COUNTER_ELEMS) return SE_ERR_BAD_ARG;
+    const hipError_t e = hipMemsetAsync(workspace + workspace_elems - SE_WS_COUNTER_ELEMS, 0, SE_WS_COUNTER_ELEMS * sizeof(float), se_stream(stream));
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const float* residual,

@@ -187,10 +187,10 @@ int launch_tiled(const ConvArgs& a, int batch, hipStream_t s) {
 // Returns 0 if a tiled kernel took the launch, SE_TILED_NOT_TAKEN if the shape is left to the direct kernel,
 // otherwise the hipError_t of the failed launch.
 int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s);   // conv3d_wino.hip
-int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s); // conv3d_wino2d.hip
+int se_conv3d_wino2d_try(const ConvArgs& a, int batch, int launch_batch, hipStream_t s); // conv3d_wino2d.hip
 int se_conv3d_k7_wino_try(const ConvArgs& a, int batch, hipStream_t s);
 
-static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s);
+static int tiled_try_one(const ConvArgs& a, int batch, int launch_batch, int ksize, hipStream_t s);
 
 // The persistent kernels keep a per-workgroup table of their work units in the LDS left over beside weights and tiles
 // (a few hundred entries): large batches are cut into slices of 32 samples, one launch each (weak-scaling config 4 runs
@@ -201,7 +201,7 @@ int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) 
     const long long units_per_sample = ksize == 7 ? t8 * t8 * t8 : (long long)(a.cout >= 32 ? a.cout / 32 : 1) * (a.dim / 4) * t8 * t8;
     long long budget = units_per_sample > 0 ? 400LL * se_num_cus() / units_per_sample : 32;
     const int SLICE = (int)(budget < 1 ? 1 : budget > 32 ? 32 : budget);
-    if (batch <= SLICE) return tiled_try_one(a, batch, ksize, s);
+    if (batch <= SLICE) return tiled_try_one(a, batch, batch, ksize, s);
     const long long vox = (long long)a.dim * a.dim * a.dim;
     for (int b0 = 0; b0 < batch; b0 += SLICE) {
         const int nb = batch - b0 < SLICE ? batch - b0 : SLICE;
@@ -212,23 +212,26 @@ int se_conv3d_tiled_try(const ConvArgs& a, int batch, int ksize, hipStream_t s) 
         if (a.res) sl.res = a.res + (long long)b0 * vox * ((a.flags & SE_EPI_SKIPCONV16) ? 16 : a.cout);
         if (a.pool_out) sl.pool_out = a.pool_out + (long long)b0 * (vox / 8) * a.cout;
         sl.total_vox = (long long)nb * vox;
-        const int rc = tiled_try_one(sl, nb, ksize, s);
+        // batch-dependent decisions (small-volume early-out, which 2-D Winograd kernel) are taken on the WHOLE batch, so every slice
+        // decides alike (a one-sample tail slice used to say "not taken" after the first slices had been launched)
+        const int rc = tiled_try_one(sl, nb, batch, ksize, s);
         if (rc != 0) return rc;   // not taken (same decision for every slice: nothing launched yet) or an error
     }
     return 0;
 }
 
-static int tiled_try_one(const ConvArgs& a, int batch, int ksize, hipStream_t s) {
+// `batch` samples are launched; `launch_batch` = samples of the whole call this slice belongs to (what batch-dependent choices look at)
+static int tiled_try_one(const ConvArgs& a, int batch, int launch_batch, int ksize, hipStream_t s) {
     const int dim = a.dim;
     // tiny volumes of 2-D Winograd shapes (16^3 at batch 1: 32 work units for 256 CUs): a plain channels-last call is left to the
     // in-workgroup split-K kernel of the 8^3 level (conv_common.h: se_conv3d_small_volume; 47 against 92 us per 128 -> 128 launch);
     // a caller that asks for an octet-planar / pooled / fused-skip form gets the 2-D kernel as before
-    if (ksize == 3 && g_variant == 0 && se_conv3d_small_volume(batch, dim) && a.cin_pad == a.cin && se_wino2d_shape_ok(dim, a.cin, a.cout) &&
+    if (ksize == 3 && g_variant == 0 && se_conv3d_small_volume(launch_batch, dim) && a.cin_pad == a.cin && se_wino2d_shape_ok(dim, a.cin, a.cout) &&
         !(a.flags & (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET | SE_EPI_SKIPCONV16 | SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR)) && !a.pool_out &&
         !a.skip_w && (a.nts % 2) == 0)
         return SE_TILED_NOT_TAKEN;
     if (ksize == 3 && (g_variant == 0 || (g_variant >= 40 && g_variant < 70))) {   // production: 2-D Winograd F(4,3) x F(2,3), register accumulators
-        const int rc = se_conv3d_wino2d_try(a, batch, s);
+        const int rc = se_conv3d_wino2d_try(a, batch, launch_batch, s);
         if (rc != SE_TILED_NOT_TAKEN) return rc;
     }
     // octet-planar tensors, the pooled second output and the fused 16-channel skip convolution exist in the 2-D Winograd kernel only:

@@ -754,7 +754,7 @@ int se_conv3d_wino44_launch(const ConvArgs& a, int batch, hipStream_t s);
 #endif
 
 // Returns 0 on launch, SE_TILED_NOT_TAKEN if the shape/flags are not covered, else a hipError_t.
-int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
+int se_conv3d_wino2d_try(const ConvArgs& a, int batch, int launch_batch, hipStream_t s) {
     const int dim = a.dim;
     if (!a.wpack_g || a.cin_pad != a.cin || !se_wino2d_shape_ok(dim, a.cin, a.cout)) return SE_TILED_NOT_TAKEN;
     if (a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR)) return SE_TILED_NOT_TAKEN;
@@ -764,7 +764,7 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, hipStream_t s) {
 #endif
     // round 4: the 64^3 / 32^3 levels run on the F(4,3) x F(4,3) ping-pong kernel (1/4 of the direct MFMAs; this kernel: 1/3);
     // development builds: se_debug_set_variant(64) keeps them here (A/B)
-    if (g_variant != 64 && g_variant < 41 && se_conv3d_wino44pp_takes(a, batch)) return se_conv3d_wino44pp_launch(a, batch, s);
+    if (g_variant != 64 && g_variant < 41 && se_conv3d_wino44pp_takes(a, launch_batch)) return se_conv3d_wino44pp_launch(a, batch, s);
     const int tx = dim / 16, ty = dim / 8, tz = dim / 4;
     const long long total_tiles = (long long)batch * tx * ty * tz;
     const long long n_units = total_tiles * (a.cout / 32);

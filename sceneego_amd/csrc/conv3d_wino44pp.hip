@@ -327,7 +327,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
             (unsigned)(__UINTPTR_TYPE__)((float __attribute__((address_space(3)))*)(region + piece * 256)));      // LDS byte address
         if ((SE_K44P_EXP & 1) || ((SE_K44P_EXP & 64) && G == 1) || ((SE_K44P_EXP & 128) && G == 0)) return;      // 64 / 128: no DMAs of group 1 / 0
         const int l16 = lane16;                    // (asm operands do not capture: name a local of the lambda)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(l16), "s"(sp));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(l16), "s"(sp) : "m0");
     };
     using NA = std::integral_constant<int, P_NA>;
     using NB = std::integral_constant<int, P_NB>;
@@ -486,7 +486,6 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
 
     // State of the walk: (ucur, ccur) = the step this group computes next, (unx, cnx) = the step after it.
     UnitP ucur = decode(u_begin);
-    int ccur = 0;
     UnitP unx = ucur;
     int cnx = 0, inx = 0;
     int slot = 0;                   // slot of half A of step (ucur, ccur) = (2 step) mod 3; half B: slot + 1 (mod 3)
@@ -629,7 +628,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
                 if (SE_K44P_EPRIO) __builtin_amdgcn_s_setprio(0);
             }
             TP(7)
-            ucur = unx; ccur = cnx;
+            ucur = unx;
             slot = slot == 0 ? 2 : slot - 1;                          // (slot + 2) mod 3
             step_after(unx, cnx, inx);
             if (cnx == 0) fetch_setup(unx);                           // new unit (or, behind the last step, the same one again)
@@ -737,8 +736,9 @@ bool se_conv3d_wino44pp_shape(int batch, int dim, int cout) {
 }
 // A channels-last input with >= 32 channels stays on the F(4,3) x F(2,3) kernel: a 4-channel chunk is 16 bytes of every 128-byte
 // record there (measured 0.578 against 0.506 ms at 32->32 @64^3; one launch per step has such an input, back_layers.0).
+bool se_conv3d_wino44pp_layout_ok(int cin, int flags) { return (flags & SE_IN_OCTET) || cin < 32; }
 bool se_conv3d_wino44pp_takes(const ConvArgs& a, int batch) {
-    if (!(a.flags & SE_IN_OCTET) && a.cin >= 32) return false;
+    if (!se_conv3d_wino44pp_layout_ok(a.cin, a.flags)) return false;
     return a.wpack_i && se_conv3d_wino44pp_shape(batch, a.dim, a.cout);
 }
 

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
         const float* sp = src + piece * 256;        // uniform; the per-lane part of every LDS-DMA address is the same lane * 16 bytes
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)((float __attribute__((address_space(3)))*)(region + piece * 256)));
         const int l16 = lane * 16;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(l16), "s"(sp));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(l16), "s"(sp) : "m0");
 #else
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (piece * 64 + lane) * 4),
                                          (void __attribute__((address_space(3)))*)(region + piece * 256), 16, 0, 0);

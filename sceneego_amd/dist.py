@@ -16,6 +16,8 @@ from datetime import timedelta
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 
 def env_world():
     """(rank, local_rank, world_size) from the torchrun environment (defaults: single process)."""
@@ -111,16 +113,19 @@ def all_gather_joints(joints: torch.Tensor) -> torch.Tensor:
         return joints
     world = dist.get_world_size()
     joints = joints.contiguous()
-    if joints.is_cuda and dist.get_backend() == "gloo":
-        # shared-GPU readiness mode only (init_from_env): gloo moves host memory, so the shard goes through the host behind the
-        # producing stream; the production backend (RCCL) gathers device tensors in place, stream-ordered
-        host = joints.cpu()           # synchronises with the current stream, which the caller made wait for the forward
-        out = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
-        dist.all_gather_into_tensor(out, host)
-        return out.to(joints.device)
-    out = torch.empty((world * joints.shape[0],) + tuple(joints.shape[1:]), dtype=joints.dtype, device=joints.device)
-    dist.all_gather_into_tensor(out, joints)
-    return out
+    # bench.py's separate timing pass: HIP events on the issuing stream around the collective (RCCL runs it on its own stream, which
+    # waits for this one and which this one waits for: the bracket covers it) -> `allgather_us` on the bench line
+    with _lib._timed(("allgather", world, int(joints.numel()))):
+        if joints.is_cuda and dist.get_backend() == "gloo":
+            # shared-GPU readiness mode only (init_from_env): gloo moves host memory, so the shard goes through the host behind the
+            # producing stream; the production backend (RCCL) gathers device tensors in place, stream-ordered
+            host = joints.cpu()           # synchronises with the current stream, which the caller made wait for the forward
+            out = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+            dist.all_gather_into_tensor(out, host)
+            return out.to(joints.device)
+        out = torch.empty((world * joints.shape[0],) + tuple(joints.shape[1:]), dtype=joints.dtype, device=joints.device)
+        dist.all_gather_into_tensor(out, joints)
+        return out
 
 
 def all_gather_joints_ragged(joints: torch.Tensor, total: int) -> torch.Tensor:

@@ -8,6 +8,7 @@ bit-identical voxel set); the result is what ``VoxelNetwork_depth.forward(..., s
 """
 from __future__ import annotations
 
+import hashlib
 import json
 
 import numpy as np
@@ -15,7 +16,7 @@ import torch
 
 from . import _lib
 
-_TABLES = {}
+_TABLE = None       # (ray array - held, so its identity cannot be reused -, content digest, height, width, device, table)
 
 
 def calcualate_depth_scale(depth_scale_json_file, log_err=False):
@@ -31,13 +32,18 @@ def calcualate_depth_scale(depth_scale_json_file, log_err=False):
 
 def _ray_table(ray, height, width, device):
     """x-major reference rays [W*H,3] (index x*H + y) -> device table [H][W][3] float64."""
-    key = (id(ray), height, width, str(device))
-    tab = _TABLES.get(key)
-    if tab is None:
-        r = np.asarray(ray, dtype=np.float64).reshape(width, height, 3).transpose(1, 0, 2)
-        tab = torch.from_numpy(np.ascontiguousarray(r)).to(device)
-        _TABLES.clear()
-        _TABLES[key] = tab
+    global _TABLE
+    shape = (height, width, str(device))
+    if _TABLE is not None and _TABLE[0] is ray and _TABLE[2:5] == shape:
+        return _TABLE[5]            # the very same (still referenced) array object: nothing to hash
+    # another object: compare CONTENT (an `id()` key can be reused by a different calibration's array once the first one is freed)
+    r64 = np.ascontiguousarray(np.asarray(ray, dtype=np.float64))
+    digest = hashlib.blake2b(r64.view(np.uint8).reshape(-1), digest_size=16).digest()
+    if _TABLE is not None and _TABLE[1] == digest and _TABLE[2:5] == shape:
+        _TABLE = (ray,) + _TABLE[1:]
+        return _TABLE[5]
+    tab = torch.from_numpy(np.ascontiguousarray(r64.reshape(width, height, 3).transpose(1, 0, 2))).to(device)
+    _TABLE = (ray, digest) + shape + (tab,)
     return tab
 
 

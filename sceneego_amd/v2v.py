@@ -16,10 +16,16 @@ Two layers:
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
 from . import _lib
+
+
+# a level's skip block is forked onto the side stream when batch x voxels of the level is at most this (64^3 at batch 1)
+FORK_MAX_VOXELS = 64 ** 3
 
 
 def _round16(c):
@@ -226,8 +232,22 @@ class V2VProgram:
         self.back2 = basic(bl[2])
         self.out = _PackedConv(model.output_layer, None, None, dtype)
         self.out_scaled = self.out if self.output_scale == 1.0 else _PackedConv(model.output_layer, None, None, dtype, scale=self.output_scale)
-        # scratch for the split-K path of the small pyramid levels (se_conv3d_f32 workspace): 32 Mi floats
-        self.workspace = torch.empty(32 << 20, device=self.device, dtype=torch.float32) if dtype == torch.float32 else None
+        # scratch for the split-K path of the small pyramid levels (se_conv3d_f32 workspace): 32 Mi floats, arrival counters in its tail
+        # (se_conv3d_workspace_init + SE_WS_COUNTERS: the 4^3 / 2^3 levels reduce in the last-arriving workgroup, one launch per layer).
+        # A workspace serves ONE stream at a time: the forked skip branches (run()) have their own.
+        self.workspace = self._new_workspace() if dtype == torch.float32 else None
+        self.workspace_side = self._new_workspace() if dtype == torch.float32 else None     # (created here, never inside a graph capture)
+        self._side_stream = torch.cuda.Stream(device=self.device) if dtype == torch.float32 else None
+        self._ws = self.workspace              # the workspace of the stream run() is issuing on
+        # skip_res{k+1} of the levels in fork_levels run on a side stream beside the encoder chain (reference network/v2v.py:104-119:
+        # skip_x_k = skip_res_k(x) is not read before decoder_upsample_k).  None = decide per batch in run().
+        self.fork_levels = None
+
+    def _new_workspace(self):
+        ws = torch.empty(32 << 20, device=self.device, dtype=torch.float32)
+        _lib.conv3d_workspace_init(ws)
+        torch.cuda.current_stream(self.device).synchronize()      # set-up time only: the counters are zero before any stream uses them
+        return ws
 
     def _pack_res(self, m):
         c1 = _PackedConv(m.res_branch[0], m.res_branch[1], None, self.dtype, split3=self.split3)
@@ -251,7 +271,9 @@ class V2VProgram:
         if self.split3 and pc.w_split is not None and dim % 16 == 0 and pool_out is None:
             _lib.conv3d_k3_split3(x, pc.w_split, pc.b, residual, out, B, dim, pc.cin_pad, pc.cout, flags)
             return out
-        _lib.conv3d(x, pc.w, pc.b, residual, out, B, dim, pc.cin, pc.cin_pad, pc.cout, pc.k, flags, self.workspace, pool_out=pool_out)
+        ws = self._ws
+        _lib.conv3d(x, pc.w, pc.b, residual, out, B, dim, pc.cin, pc.cin_pad, pc.cout, pc.k, flags | (_lib.WS_COUNTERS if ws is not None else 0),
+                    ws, pool_out=pool_out)
         return out
 
     def _res(self, x, blk, B, dim, x_oct=False, out_oct=False, pool_out=None):
@@ -289,6 +311,22 @@ class V2VProgram:
         if self.split3:
             return c1.w_split is not None and c2.w_split is not None and dim % 16 == 0
         return _lib.conv3d_variant(B, dim, c1.cin_pad, c1.cout, 3) in (2, 3) and _lib.conv3d_variant(B, dim, c2.cin_pad, c2.cout, 3) in (2, 3)
+
+    def _fork_set(self, B, G):
+        """Levels (0 = G^3 ... 4 = (G/16)^3) whose skip block runs on the side stream.  Default: every level whose launches leave
+        CUs idle - all five at batch 1 (the demo.py case), the levels at or below 16^3-at-batch-8 size otherwise; the full-chip
+        persistent launches of the big levels gain nothing from a second stream (measured)."""
+        if self.dtype != torch.float32 or self.split3:
+            return frozenset()
+        if self.fork_levels is not None:
+            return frozenset(self.fork_levels)
+        env = os.environ.get("SCENEEGO_FORK_LEVELS")          # experiments (tools/diag/fork_sweep.py): "" = none, "0,1,2,3,4" = all
+        if env is not None:
+            return frozenset(int(t) for t in env.split(",") if t.strip())
+        return frozenset(k for k in range(5) if B * (G >> k) ** 3 <= FORK_MAX_VOXELS)
+
+    def _side(self, main):
+        return self._side_stream
 
     def _pool(self, x, B, dim, c, x_oct=False):
         out = self._new(B, dim // 2, c)
@@ -329,11 +367,34 @@ class V2VProgram:
                 pooled = self._new(B, G // 2, blk[1].cout)
             x = self._res(x, blk, B, G, x_oct=x_oct, out_oct=ok, pool_out=pooled)
             x_oct = ok
-        # encoder (v2v.py:104-119)
+        # encoder (v2v.py:104-119).  skip_res_k(x) is not read before decoder_upsample_k: the skip blocks of the levels in `fork` are
+        # issued on a side stream (event fork behind the producer of x, event join in front of the deconvolution that reads the
+        # result) and run beside the encoder / middle / decoder chain, which at small batches leaves most of the chip idle
+        # (16^3 at batch 1: 32 work units on 256 CUs).  Inside a hipGraph capture the fork and the joins become graph edges.
         skips = []
+        joins = [None] * 5
+        fork = self._fork_set(B, G)
+        main = torch.cuda.current_stream(self.device) if fork else None
         dim = G
         for k in range(5):
-            skips.append(self._res(x, self.skip[k], B, dim, x_oct=x_oct, out_oct=False))    # read by the decoder's deconvolution
+            if k in fork:
+                side = self._side(main)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                x.record_stream(side)
+                with torch.cuda.stream(side):
+                    self._ws = self.workspace_side
+                    try:
+                        sk = self._res(x, self.skip[k], B, dim, x_oct=x_oct, out_oct=False)
+                    finally:
+                        self._ws = self.workspace
+                    joins[k] = torch.cuda.Event()
+                    joins[k].record(side)
+                sk.record_stream(main)
+                skips.append(sk)
+            else:
+                skips.append(self._res(x, self.skip[k], B, dim, x_oct=x_oct, out_oct=False))    # read by the decoder's deconvolution
             x = pooled if pooled is not None else self._pool(x, B, dim, x.numel() // (B * dim ** 3), x_oct=x_oct)
             pooled = None
             dim //= 2
@@ -348,6 +409,8 @@ class V2VProgram:
         # decoder (v2v.py:121-137)
         for k in range(4, -1, -1):
             x = self._res(x, self.dec[k], B, dim)
+            if joins[k] is not None:
+                main.wait_event(joins[k])
             x = self._up(x, self.up[k], skips[k], B, dim)
             skips[k] = None
             dim *= 2

@@ -207,6 +207,35 @@ def test_v2v_stagewise_vs_oracle(net64, oracle_constants):
     assert float((vols.cpu() - ovols).abs().max()) <= 2e-3 * float(ovols.max())
 
 
+def test_forward_17_joints_unfused_tail_vs_oracle(oracle_constants):
+    """`num_joints` > 16 leaves the fused tail (one MFMA column block holds 16 output channels) and runs
+    back_layers.1 / .2 / output_layer as three launches with the planar store of the direct kernel (sceneego_amd/v2v.py, the branch
+    behind `if self.cout <= 16`) plus the stand-alone soft-argmax.  Whole forward with 17 joints against the oracle
+    (reference network/v2v.py:155-169, utils/op.py:83-96), B=2 so that the planar store's sample stride is exercised."""
+    cfg = load_config()
+    cfg.model.backbone.num_joints = 17
+    net = VoxelNetwork_depth(cfg, device="cpu", verbose=False)
+    sd = synth.make_state_dict(net.state_dict(), seed=0)
+    net.load_state_dict(sd, strict=True)
+    assert tuple(sd["volume_net.output_layer.weight"].shape) == (17, 32, 1, 1, 1)
+    net = net.to(DEV).eval()
+    img, depth = synth.make_inputs(1717, 2, "uniform")
+    taps = {}
+    oj, _, ovols = O.forward(sd, oracle_constants(64), img, depth, taps=taps, accumulate64=True)
+    kp, _, vols, _ = _forward(net, img, depth)
+    assert tuple(kp.shape) == (2, 17, 3) and tuple(vols.shape) == (2, 17, 64, 64, 64)
+    x = torch.cat([taps["feature_volume"], taps["occupancy"].unsqueeze(1)], dim=1)
+    with torch.no_grad():
+        lg = net.volume_net(x.to(DEV)).cpu()
+    scale = float(taps["logits"].abs().max())
+    l_err = float((lg - taps["logits"]).abs().max())
+    j_err = float((kp.cpu() - oj).abs().max())
+    print(f"17 joints (un-fused tail): logits {l_err:.2e} of max {scale:.2f}, joints {j_err:.2e} m")
+    assert l_err < 1e-4 * scale, (l_err, scale)
+    assert j_err <= JOINT_TOL
+    assert float((vols.cpu() - ovols).abs().max()) <= 2e-3 * float(ovols.max())
+
+
 def test_scene_volumes_branch_and_none(net64, oracle_constants):
     """Pre-voxelised input (voxel_net_depth.py:246-249) gives the same joints as the depth branch; no scene -> None."""
     const = oracle_constants(64)
@@ -318,6 +347,45 @@ def test_demo_cli_exr_depth(tmp_path, golden):
     res = d.run()
     err = float(np.abs(res[0]["predicted_keypoints"] - g["joints"][0]).max())
     assert err <= JOINT_TOL, err
+
+
+def test_demo_to_evaluate_mpjpe_on_gpu(tmp_path, golden, golden_meta):
+    """f4 on the GPU: the reference scores a run by collecting the forward's joints (test.py:42-57) and passing
+    them through utils/calculate_errors.py (align_skeleton :60-91, calculate_error :22-28).  Here: demo.Demo forward on two frames (the
+    demo frame with the reference's own EXR depth map, and with the seeded .npy depth map of golden `demo_b1`) -> the pickles demo.py
+    writes -> evaluate.main with the REFERENCE's joints (goldens) as ground truth: MPJPE and PA-MPJPE <= 1e-3 m."""
+    import os
+    import pickle
+    import shutil
+    import sys
+    from PIL import Image
+    from conftest import GOLD, ROOT
+    sys.path.insert(0, ROOT)
+    import demo as demo_mod
+    import evaluate as ev
+    m = next(c for c in golden_meta["cases"] if c["name"] == "demo_b1")
+    g_npy, g_exr = golden("demo_b1"), golden("demo_exr_b1")
+    small = np.load(os.path.join(GOLD, "demo", "img_001000_256_bgr_u8.npz"))["img"]
+    frame = np.zeros((1024, 1280, 3), dtype=np.uint8)
+    frame[:, 128:-128] = np.repeat(np.repeat(small, 4, axis=0), 4, axis=1)
+    img_dir, depth_dir, out_dir = tmp_path / "imgs", tmp_path / "depths", tmp_path / "out"
+    img_dir.mkdir(); depth_dir.mkdir(); out_dir.mkdir()
+    for name in ("img_001000.png", "img_001001.png"):
+        Image.fromarray(frame[:, :, ::-1]).save(img_dir / name)
+    shutil.copy(os.path.join(GOLD, "demo", "img_001000.jpg.exr"), depth_dir / "img_001000.png.exr")
+    _, depth = synth.make_inputs(m["input_seed"], 1, m["depth_kind"])
+    np.save(depth_dir / "img_001001.png.npy", depth[0].numpy().astype(np.float32))
+    res = demo_mod.Demo(load_config(), str(img_dir), str(depth_dir), weights="synthetic").run()
+    assert [os.path.basename(r["img_path"]) for r in res] == ["img_001000.png", "img_001001.png"]
+    for r in res:                                                   # what demo.main writes (reference demo.py:88-97)
+        with open(out_dir / (os.path.basename(r["img_path"]) + ".pkl"), "wb") as f:
+            pickle.dump(r["predicted_keypoints"], f)
+    with open(tmp_path / "gt.pkl", "wb") as f:
+        pickle.dump({"img_001000.png": g_exr["joints"][0], "img_001001.png": g_npy["joints"][0]}, f)
+    r = ev.main(["--pred_dir", str(out_dir), "--gt", str(tmp_path / "gt.pkl")])
+    print(f"demo -> evaluate on the GPU: MPJPE {r['mpjpe']:.3e} m, PA-MPJPE {r['pa_mpjpe']:.3e} m over {r['frames']} frames")
+    assert r["frames"] == 2 and r["mpjpe"] <= JOINT_TOL and r["pa_mpjpe"] <= JOINT_TOL, r
+    assert max(r["per_joint"]) <= JOINT_TOL
 
 
 def test_scene_volumes_from_dataset_side_voxeliser(net64, oracle_constants):

@@ -928,3 +928,76 @@ def test_conv3d_k3_128_vs_torch():
     err = float((_ncdhw(_unoct(out_oct).cpu()) - want).abs().max())
     print(f"k3 32->32 @128^3 octet-planar + skip: max error {err:.2e} of max|y| {float(want.abs().max()):.2f}")
     assert err < 2e-5 * max(1.0, float(want.abs().max())), err
+
+
+@pytest.mark.parametrize("B,dim,cin,cout", [(3, 64, 32, 32), (10, 32, 64, 64)])
+def test_conv3d_k3_wino44pp_unit_walk_vs_torch(B, dim, cin, cout):
+    """conv3d_k3_wino44pp_kernel against torch-CPU float32 where a persistent workgroup's unit range CROSSES a sample
+    boundary and a cout-block boundary (conv3d_wino44pp.hip `advance`: u.b += 1 / u.cb += 1).  Units are walked x, y, z, sample, cout
+    block; 256 workgroups take ceil(units / 256) consecutive units each:
+      32 -> 32 @64^3, B=3:  768 units, 3 per workgroup, 256 per sample -> workgroup 85 walks units 255, 256, 257 (two samples);
+      64 -> 64 @32^3, B=10: 640 units (2 cout blocks x 320 tiles), 3 per workgroup, 32 tiles per sample -> workgroup 10 crosses a sample
+                            boundary (units 30, 31, 32) and workgroup 106 the cout-block boundary (318, 319, 320).
+    Octet-planar in / out, with and without an octet-planar skip tensor (reference network/v2v.py:21-43); 2e-5 of max|y|."""
+    conv, bn = _conv_bn(cin, cout, 3, 4400 + dim)
+    x = torch.from_numpy(synth.normal(4400 + dim, "x", (B, cin, dim, dim, dim)))
+    with torch.no_grad():
+        lin = bn(conv(x))
+        want_plain, want_res = F.relu(lin), F.relu(lin + x)          # identity skip: the block input is the skip tensor
+    assert _lib.conv3d_variant(B, dim, cin, cout, 3, _lib.IN_OCTET) == 3
+    units = B * (dim // 16) * (dim // 8) ** 2 * (cout // 32)
+    per = -(-units // 256)
+    tiles_per_sample = (dim // 16) * (dim // 8) ** 2
+    assert per > 1 and tiles_per_sample % per != 0, "no workgroup would cross a sample boundary"
+    pc = _PackedConv(conv.to(DEV), bn.to(DEV))
+    x_oct = _oct(_ndhwc(x).to(DEV))
+    out_oct = torch.full((B, cout // 8, dim, dim, dim, 8), -77.0, device=DEV)
+    tol = lambda w: 2e-5 * max(1.0, float(w.abs().max()))
+    _lib.conv3d(x_oct, pc.w, pc.b, None, out_oct, B, dim, cin, cin, cout, 3, _lib.EPI_RELU | _lib.IN_OCTET | _lib.OUT_OCTET)
+    e1 = float((_ncdhw(_unoct(out_oct).cpu()) - want_plain).abs().max())
+    out_oct.fill_(-77.0)
+    _lib.conv3d(x_oct, pc.w, pc.b, x_oct, out_oct, B, dim, cin, cin, cout, 3,
+                _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | _lib.IN_OCTET | _lib.OUT_OCTET | _lib.RES_OCTET)
+    got = _ncdhw(_unoct(out_oct).cpu())
+    e2 = float((got - want_res).abs().max())
+    per_sample = (got - want_res).abs().amax(dim=(1, 2, 3, 4))
+    print(f"wino44pp {cin}->{cout} @{dim}^3 B={B} ({units} units, {per} per workgroup): plain {e1:.2e}, +skip {e2:.2e}; per sample "
+          + " ".join(f"{float(v):.1e}" for v in per_sample))
+    assert e1 < tol(want_plain) and e2 < tol(want_res), (e1, e2)
+
+
+def test_wino44pp_and_wino67_repeat_launches_bit_identical():
+    """the two kernels whose LDS-DMAs are inline assembly with hand-counted `s_waitcnt vmcnt` waits (conv3d_wino44pp.hip,
+    conv3d_wino67.hip) - a wait that is one too loose is a data race that shows as run-to-run differences.  40 launches per form on
+    the same input must give the same bits (short form of tools/diag/k44p_race_soak.py; the build itself refuses VGPR spills and
+    foreign M0 writes in these kernels: csrc/check_codeobj.py)."""
+    B, dim = 8, 64
+    conv, bn = _conv_bn(32, 32, 3, 91)
+    pc = _PackedConv(conv.to(DEV), bn.to(DEV))
+    x = torch.randn(B, 4, dim, dim, dim, 8, device=DEV)
+    res = torch.randn(B, 4, dim, dim, dim, 8, device=DEV)
+    out = torch.empty_like(x)
+    for flags, r in ((_lib.EPI_RELU | _lib.IN_OCTET | _lib.OUT_OCTET, None),
+                     (_lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | _lib.IN_OCTET | _lib.OUT_OCTET | _lib.RES_OCTET, res)):
+        first = None
+        for i in range(40):
+            out.fill_(float(i))
+            _lib.conv3d(x, pc.w, pc.b, r, out, B, dim, 32, 32, 32, 3, flags)
+            if first is None:
+                first = out.clone()
+            else:
+                assert torch.equal(out, first), f"wino44pp launch {i} differs (flags {flags})"
+    conv7, bn7 = _conv_bn(33, 16, 7, 92)
+    pc7 = _PackedConv(conv7.to(DEV), bn7.to(DEV), cin_pad=48)
+    x7 = torch.zeros(2, dim, dim, dim, 48, device=DEV)
+    x7[..., :33] = torch.randn(2, dim, dim, dim, 33, device=DEV)
+    x7p = _to_planar3(x7, 33)
+    out7 = torch.empty(2, dim, dim, dim, 16, device=DEV)
+    first = None
+    for i in range(40):
+        out7.fill_(float(i))
+        _lib.conv3d(x7p, pc7.w, pc7.b, None, out7, 2, dim, 33, 48, 16, 7, _lib.EPI_RELU | _lib.IN_PLANAR3)
+        if first is None:
+            first = out7.clone()
+        else:
+            assert torch.equal(out7, first), f"wino67 launch {i} differs"

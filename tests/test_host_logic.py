@@ -50,8 +50,18 @@ def test_fisheye_round_trip():
     pts = np.array([[640.0, 512.0], [300.0, 700.0], [900.0, 200.0], [615.0, 100.0]])
     ray = cam.camera2world_ray(pts)
     np.testing.assert_allclose(np.linalg.norm(ray, axis=1), 1.0, atol=1e-12)
-    back = cam.world2camera_pytorch(torch.from_numpy(ray * 1.7).float()).numpy()
+    back = cam.world2camera(ray * 1.7)
     np.testing.assert_allclose(back, pts, atol=0.35)   # the two calibration polynomials are only mutually approximate
+    back_t = cam.world2camera_pytorch(torch.from_numpy(ray * 1.7).float()).numpy()
+    np.testing.assert_allclose(back_t, back, atol=1e-3)     # numpy float64 and torch float32 projections agree
+    # camera2world = depth along the pixel's ray (reference utils/depth2pointcloud.py:32 feeds it the depth map)
+    pts3 = cam.camera2world(pts, np.full(4, 1.7))
+    np.testing.assert_allclose(pts3, ray * 1.7, atol=2e-6)
+    # normalize=True: pixels of the centred square crop mapped to [-1, 1] (reference :178-185)
+    nrm = cam.world2camera_pytorch(torch.from_numpy(ray * 1.7).float(), normalize=True).numpy()
+    w, h = cam.img_size
+    want = np.stack([(back_t[:, 0] - (w - h) // 2) / (h - 1) * 2 - 1, back_t[:, 1] / (h - 1) * 2 - 1], axis=1)
+    np.testing.assert_allclose(nrm, want, atol=1e-5)
 
 
 def test_odd_volume_raises_like_reference(config):
@@ -375,3 +385,21 @@ def test_evaluate_cli_mpjpe_and_pa_mpjpe(tmp_path):
     assert abs(r1["mpjpe"] - M.mpjpe(p32, gt)) < 1e-12 and abs(r1["pa_mpjpe"] - M.pa_mpjpe(p32, gt)) < 1e-12
     assert r1["pa_mpjpe"] < 0.03 < r1["mpjpe"]            # alignment removes the similarity transform, the noise stays
     assert M.pa_mpjpe(pred, gt) < 1e-9
+
+
+def test_real_depth_ray_table_cache_keys_on_content_not_identity():
+    """the dataset-side voxeliser's ray-table cache may not hand a table of ANOTHER calibration to an array that
+    happens to reuse a freed array's id(): same object -> cached, equal content -> cached, different content -> rebuilt."""
+    from sceneego_amd import real_depth_utils as R
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(6 * 4, 3))
+    t1 = R._ray_table(a, 4, 6, "cpu")
+    assert R._ray_table(a, 4, 6, "cpu") is t1
+    assert R._ray_table(a.copy(), 4, 6, "cpu") is t1           # another object, same calibration
+    b = a + 1.0
+    t2 = R._ray_table(b, 4, 6, "cpu")
+    assert t2 is not t1 and not torch.equal(t1, t2)
+    np.testing.assert_array_equal(t2.numpy(), b.reshape(6, 4, 3).transpose(1, 0, 2))
+    del b
+    c = a * 2.0                                                 # may or may not reuse b's id: must get its own table either way
+    np.testing.assert_array_equal(R._ray_table(c, 4, 6, "cpu").numpy(), c.reshape(6, 4, 3).transpose(1, 0, 2))

@@ -12,9 +12,19 @@ KEY=$( (hipcc --version 2>/dev/null; echo "$FLAGS ") | sha256sum | cut -c1-12)
 OBJ=_obj/$KEY
 [ -d "$OBJ" ] || { echo "development objects $OBJ missing: run build.sh --devtools" >&2; exit 1; }
 extra=""
-case $src in conv3d_wino2d|conv3d_wino44pp) extra="-fno-slp-vectorize";; voxelize) extra="-ffp-contract=off";; esac
+case $src in conv3d_wino2d) extra="-fno-slp-vectorize";; conv3d_wino44pp) extra="-fno-slp-vectorize -Wno-inline-asm";; conv3d_wino67) extra="-Wno-inline-asm";;
+  voxelize) extra="-ffp-contract=off";; esac
 mkdir -p _obj/variants
-hipcc $FLAGS $extra "$@" -c $src.hip -o _obj/variants/${src}_$name.o 2>&1 | grep -E "error" || true
+# never link a stale object: remove it first, stop when the compile fails (`| grep error || true` hid a failed compile and
+# the old object of the same name was linked and reported as "built")
+rm -f _obj/variants/${src}_$name.o
+log=_obj/variants/${src}_$name.log
+if ! hipcc $FLAGS $extra "$@" -c $src.hip -o _obj/variants/${src}_$name.o > "$log" 2>&1; then
+  grep -E "error" "$log" >&2 || tail -20 "$log" >&2
+  echo "build_variant.sh: compiling $src.hip ($name) FAILED - nothing linked" >&2
+  exit 1
+fi
+case $src in conv3d_wino44pp|conv3d_wino67) python3 check_codeobj.py _obj/variants/${src}_$name.o || echo "build_variant.sh: (attribution / stamp variant: continuing)" >&2;; esac
 objs=()
 for o in $OBJ/*.o; do
   b=$(basename $o .o)

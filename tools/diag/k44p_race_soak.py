@@ -23,7 +23,7 @@ for B, dim, cin, cout, skip, pool, skip16, in_oct in FORMS:
     torch.manual_seed(dim + cin + cout)
     conv = torch.nn.Conv3d(cin, cout, 3, padding=1).to(dev)
     pc = _PackedConv(conv, None, None, torch.float32)
-    assert _lib.conv3d_variant(B, dim, cin, cout, 3) == 3
+    assert _lib.conv3d_variant(B, dim, cin, cout, 3, _lib.IN_OCTET) == 3
     x = torch.randn(B, dim, dim, dim, cin, device=dev)
     res = torch.randn(B, dim, dim, dim, cout, device=dev) if skip else None
     flags = _lib.EPI_RELU | _lib.OUT_OCTET | (_lib.IN_OCTET if in_oct else 0) | ((_lib.EPI_RES_PRE_RELU | _lib.RES_OCTET) if skip else 0)
