@@ -213,7 +213,7 @@ def oracle_reference(sd, volume_size, img, depth, timed):
 
 
 K7_RATIO = {True: 12.0 / 42.0, False: 10.0 / 28.0}      # F(6,7) when dim % 16 == 0, else F(4,7): products per output and tap column
-LAYOUT_BITS = 32 | 64 | 128 | 256                            # SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET | SE_EPI_SKIPCONV16
+LAYOUT_BITS = 32 | 64 | 128 | 256 | 1024 | 2048 | 4096       # SE_IN_/OUT_/RES_OCTET | SE_EPI_SKIPCONV16 | SE_IN_/OUT_/RES_QUAD
 
 
 def launch_flops(lib, key, flags, batch):

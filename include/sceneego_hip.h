@@ -44,11 +44,11 @@ extern "C" {
 #define SE_OUT_OCTET         64  /* [B][C/8][D][D][D][8] (channel c at octet c/8, slot c%8) / `out` is written that way /          */
 #define SE_RES_OCTET         128 /* the skip tensor `residual` is read that way                                                 */
 #define SE_EPI_SKIPCONV16    256 /* set by se_conv3d_skip16_f32 only (not a caller flag of se_conv3d_f32)                       */
-#define SE_WS_COUNTERS       512 /* se_conv3d_f32 / se_conv3d_pool_f32: `workspace` was prepared by se_conv3d_workspace_init() and
-                                  * is used by launches of ONE stream at a time: the split-K levels then reduce in the last-arriving
-                                  * workgroup (arrival counters in the last SE_WS_COUNTER_ELEMS floats of the workspace, zero between
-                                  * launches) instead of a second launch.  Same sums in the same order as without the flag.       */
-#define SE_WS_COUNTER_ELEMS  1024
+#define SE_IN_QUAD           1024 /* se_conv3d_f32, k = 3 launches with se_conv3d_f32_variant(..., these flags) == 3 only: `in` is QUAD-planar   */
+#define SE_OUT_QUAD          2048 /* [B][C/4][D][D][D][4] (channel c at quad c/4, slot c%4) / `out` is written that way /                     */
+#define SE_RES_QUAD          4096 /* the skip tensor `residual` is read that way.  Quad- and octet-planar flags do not mix in one launch.    */
+#define SE_LAYOUT_OCTET_BITS (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET)
+#define SE_LAYOUT_QUAD_BITS  (SE_IN_QUAD | SE_OUT_QUAD | SE_RES_QUAD)
 
 /* ABI version; bumped on any signature change. */
 int se_abi_version(void);
@@ -140,11 +140,6 @@ int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const
                   float* out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
                   float* workspace, long long workspace_elems, void* stream);
 
-/* Zeroes the arrival counters in the tail of a split-K workspace (once, before the first launch that passes SE_WS_COUNTERS; every
- * such launch leaves them zero).  workspace_elems >= 2 * SE_WS_COUNTER_ELEMS.  The reference has no counterpart: it is part of what
- * lets a Conv3d + BatchNorm3d (+ReLU) (+skip) of the 4^3 / 2^3 levels (network/v2v.py:80-87,100-102) be ONE launch. */
-int se_conv3d_workspace_init(float* workspace, long long workspace_elems, void* stream);
-
 /* se_conv3d_f32 that also writes max_pool3d(out, kernel 2, stride 2) from the kernel's epilogue: `pool_out` is channels-last
  * [B][D/2][D/2][D/2][cout] float32.  Stands in for a Res3DBlock's last convolution followed by encoder_pool (reference
  * network/v2v.py:104-119) without re-reading the block output.  Only shapes with se_conv3d_f32_algo() == 2 (the 2-D Winograd
@@ -158,7 +153,8 @@ int se_conv3d_pool_f32(const float* in, const float* wpack, const float* bpack, 
  *     out = act( conv3(in; wpack) + skip_w . skip_in + bpack )
  * `skip_in` is the block input, 16 channels, channels-last [B][D][D][D][16]; `skip_w` its BN-folded weights [cout][16];
  * `bpack` must hold the SUM of both folded biases.  2-D Winograd shapes (se_conv3d_f32_algo() == 2) with octet-planar `in`
- * and `out` only (flags must carry SE_IN_OCTET | SE_OUT_OCTET; SE_EPI_RELU optional); SE_ERR_BAD_ARG otherwise.  Saves the
+ * and `out` only (flags must carry SE_IN_OCTET | SE_OUT_OCTET, or SE_IN_QUAD | SE_OUT_QUAD where se_conv3d_f32_variant(..., those
+ * flags) == 3; SE_EPI_RELU optional); SE_ERR_BAD_ARG otherwise.  Saves the
  * 1x1x1 launch, its output tensor and the skip-tensor read of the 3x3x3 convolution. */
 int se_conv3d_skip16_f32(const float* in, const float* wpack, const float* bpack, const float* skip_in, const float* skip_w,
                          float* out, int batch, int dim, int cin, int cout, int flags, void* stream);
@@ -180,7 +176,9 @@ int se_pointwise_chain3_softargmax_f32(const float* in, const float* wpack1, con
                                        const float* coord, float* scratch, int batch, int dim, int cout3, void* stream);
 
 /* ConvTranspose3d(k=2, s=2) + folded BN + ReLU (+ skip).  Replaces Upsample3DBlock and the decoder
- * adds (network/v2v.py:55-67,124-137).  in [B][D]^3[cin] -> out [B][2D]^3[cout]; residual like out. */
+ * adds (network/v2v.py:55-67,124-137).  in [B][D]^3[cin] -> out [B][2D]^3[cout]; residual [B][2D]^3[cout] (channels-last).
+ * flags: SE_EPI_RELU, SE_EPI_RES_PRE_RELU / SE_EPI_RES_POST_RELU, and SE_OUT_QUAD (cin -> cout = 64 -> 32 or 128 -> 64, D % 16 == 0
+ * only, else SE_ERR_BAD_ARG): `out` is written quad-planar [B][cout/4][2D][2D][2D][4], the input layout of the 3x3x3 kernel behind it. */
 int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
                          float* out, int batch, int dim, int cin, int cout, int flags, void* stream);
 
@@ -296,13 +294,14 @@ int se_bias_act_nchw_bf16(const se_bf16* x, const se_bf16* bias, const se_bf16* 
  * Pure function of the arguments; no device access. */
 int se_conv3d_f32_algo(int dim, int cin, int cout, int ksize);
 /* Which kernel a launch of `batch` samples with these flags really runs on: se_conv3d_f32_algo()'s value, except
- *   3 = the F(4,3) x F(4,3) ping-pong kernel (a member of the 2-D Winograd family: every layout / flag / fused form of algo 2 applies;
- *       it executes 1/4 of the direct convolution's MFMAs, algo 2 executes 1/3).  It takes an octet-planar input (SE_IN_OCTET) or a
- *       channels-last one with fewer than 32 channels; a channels-last input with >= 32 channels stays on algo 2;
- *   0 for a 2-D Winograd shape with <= 4096 voxels in the batch when `flags` asks for none of the octet-planar forms (such a call
+ *   3 = the F(4,3) x F(4,3) ping-pong kernel (a member of the 2-D Winograd family with the same fused forms; it executes 1/4 of the
+ *       direct convolution's MFMAs, algo 2 executes 1/3).  Its planar layout is QUAD-planar (SE_IN_QUAD / SE_OUT_QUAD / SE_RES_QUAD):
+ *       it takes a quad-planar input or a channels-last one with fewer than 32 channels; a channels-last input with >= 32 channels
+ *       and every launch with an octet-planar flag stay on algo 2 (whose planar layout is octet-planar);
+ *   0 for a 2-D Winograd shape with <= 4096 voxels in the batch when `flags` asks for none of the planar forms (such a call
  *       runs on the in-workgroup split-K kernel).
- * `flags`: the SE_IN_OCTET / SE_OUT_OCTET / SE_RES_OCTET bits of the launch (others ignored).  bench.py prices every launch of its
- * roofline with it. */
+ * `flags`: the SE_IN_* / SE_OUT_* / SE_RES_* layout bits of the launch (others ignored).  A caller that wants planar hand-overs asks
+ * with the quad bits first: 3 = use them; otherwise the octet bits (2 = use those).  bench.py prices every launch with it. */
 int se_conv3d_f32_variant(int batch, int dim, int cin, int cout, int ksize, int flags);
 
 #ifdef SE_DEVTOOLS

@@ -23,8 +23,9 @@ EPI_OUT_PLANAR = 8
 IN_OCTET = 32       # se_conv3d_f32, 2-D Winograd 3x3x3 shapes: octet-planar input [B][C/8][D][D][D][8]
 OUT_OCTET = 64      # ... octet-planar output
 RES_OCTET = 128     # ... octet-planar skip tensor
-WS_COUNTERS = 512   # se_conv3d_f32: the workspace carries zeroed arrival counters (conv3d_workspace_init): split-K levels in one launch
-WS_COUNTER_ELEMS = 1024
+IN_QUAD = 1024      # se_conv3d_f32, launches whose variant (with these flags) is 3: quad-planar input [B][C/4][D][D][D][4]
+OUT_QUAD = 2048     # ... quad-planar output
+RES_QUAD = 4096     # ... quad-planar skip tensor
 IN_PLANAR3 = 16     # se_conv3d_f32, k = 7: triplet-planar input [B][ceil(cin/3)][D][D][D][3]
 
 _vp, _i, _f, _d, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong
@@ -66,7 +67,6 @@ SIGNATURES = {
     "se_bias_act_nchw_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_conv3d_f32_algo": (_i, [_i, _i, _i, _i]),
     "se_conv3d_f32_variant": (_i, [_i, _i, _i, _i, _i, _i]),
-    "se_conv3d_workspace_init": (_i, [_vp, _ll, _vp]),
     "se_conv3d_split3_packed_elems": (_ll, [_i, _i]),
     "se_conv3d_split3_pack": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "se_conv3d_k3_split3_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -287,13 +287,6 @@ def conv3d_variant(batch, dim, cin, cout, ksize, flags=0) -> int:
     return int(load().se_conv3d_f32_variant(batch, dim, cin, cout, ksize, flags))
 
 
-def conv3d_workspace_init(workspace):
-    """Zero the arrival counters in the tail of a split-K workspace (once; launches with WS_COUNTERS leave them zero)."""
-    require_hip(workspace)
-    _chk_f32(workspace)
-    _check(load().se_conv3d_workspace_init(_ptr(workspace), workspace.numel(), _stream()), "se_conv3d_workspace_init")
-
-
 def conv3d_algo(dim, cin, cout, ksize) -> int:
     """Kernel family se_conv3d_f32 selects for this float32 shape (include/sceneego_hip.h: 0 direct, 1 / 2 Winograd 1-D / 2-D)."""
     return int(load().se_conv3d_f32_algo(dim, cin, cout, ksize))
@@ -469,6 +462,7 @@ def pointwise_chain3(inp, pc1, pc2, pc3, out, batch, dim, softargmax=None):
 
 
 def deconv3d_k2s2(inp, wpack, bpack, residual, out, batch, dim, cin, cout, flags):
+    """``flags`` may carry OUT_QUAD (float32, 64 -> 32 and 128 -> 64, dim % 16 == 0): ``out`` is then quad-planar [B][cout/4][2D][2D][2D][4]."""
     require_hip(inp, out)
     fn = load().se_deconv3d_k2s2_bf16 if inp.dtype == torch.bfloat16 else load().se_deconv3d_k2s2_f32
     assert out.dtype == inp.dtype and wpack.dtype == inp.dtype and (residual is None or residual.dtype == inp.dtype)

@@ -53,11 +53,11 @@ def main(argv):
     # ---- M0: only the asm statement's own s_mov_b32 in front of a global_load_lds ----
     lines = [l.split("//")[0].strip() for l in asm.splitlines()]
     lines = [l for l in lines if l and not l.endswith(":")]
-    n_dma = sum("global_load_lds_dwordx4" in l for l in lines)
+    n_dma = sum("global_load_lds_dword" in l for l in lines)
     for i, l in enumerate(lines):
         if re.search(r"\bm0\b", l):
             ok = re.match(r"s_mov_b32 m0, s\d+$", l) and i + 2 < len(lines) and lines[i + 1].startswith("s_nop") and \
-                "global_load_lds_dwordx4" in lines[i + 2]
+                "global_load_lds_dword" in lines[i + 2]
             if not ok:
                 bad.append(f"M0 touched outside the LDS-DMA asm statement: '{l}'")
     n_m0 = sum(bool(re.search(r"\bm0\b", l)) for l in lines)

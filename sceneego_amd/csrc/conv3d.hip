@@ -315,7 +315,12 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(ConvArgs a) {
 // back by the same wave, and the skip records of a sub-position are requested in front of its MFMAs.
 // A wave owns M_T tiles of 16 consecutive voxels; CGS = cin / 16, N_T = cout / 16 (all couts in one workgroup).
 // ------------------------------------------------------------------------------------------------
-template <int CGS, int N_T, int M_T>
+// OUTQ (round 5, SE_OUT_QUAD; dim % 16 == 0): the output is QUAD-planar [B][cout/4][2D][2D][2D][4] - what the 3x3x3 kernel of the
+// block behind it (back_layers.0, reference network/v2v.py:155) reads whole 16-byte records of.  A lane's D fragment is one record,
+// but the records of ONE x parity are 32 bytes apart (round 2 measured such half-line stores at 0.147 -> 0.229 ms for the octet-planar
+// form); here both parities of a (z, y) sub-position are computed first and exchanged across lanes (ds_bpermute: lane l takes voxel
+// l >> 1, parity l & 1) so that a store instruction writes 16 consecutive records = 256 contiguous bytes per cout quad.
+template <int CGS, int N_T, int M_T, bool OUTQ>
 __global__ __launch_bounds__(256) void deconv3d_k2s2_kernel(ConvArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -350,6 +355,7 @@ __global__ __launch_bounds__(256) void deconv3d_k2s2_kernel(ConvArgs a) {
     f32x4 bias[N_T];
 #pragma unroll
     for (int n = 0; n < N_T; ++n) bias[n] = *reinterpret_cast<const f32x4*>(a.bpack + n * 16 + 4 * h);
+    f32x4 val[OUTQ ? 2 : 1][M_T][N_T];      // OUTQ: finished records of the two x parities of a (z, y) sub-position
 #pragma unroll 1
     for (int sub = 0; sub < 8; ++sub) {
         // output records of this sub-position; the skip tensor is requested first so that its latency lies under the MFMAs
@@ -385,14 +391,45 @@ __global__ __launch_bounds__(256) void deconv3d_k2s2_kernel(ConvArgs a) {
         }
 #pragma unroll
         for (int m = 0; m < M_T; ++m) {
-            if (!vok[m]) continue;
+            if (!OUTQ && !vok[m]) continue;
 #pragma unroll
             for (int n = 0; n < N_T; ++n) {
                 f32x4 v = acc[m][n];
                 if (res_pre) v += rv[m][n];
                 if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (res_post) v += rv[m][n];
-                *reinterpret_cast<f32x4*>(a.out + ooff[m] + n * 16) = v;
+                if constexpr (OUTQ) {
+                    if (sub & 1) val[1][m][n] = v; else val[0][m][n] = v;
+                } else {
+                    *reinterpret_cast<f32x4*>(a.out + ooff[m] + n * 16) = v;
+                }
+            }
+        }
+        if constexpr (OUTQ) {
+            if (!(sub & 1)) continue;
+            // both x parities of (oz, oy) are finished: lane l of a 16-lane row takes (voxel l >> 1, parity l & 1) for the records
+            // x0 .. x0 + 15 and (voxel 8 + (l >> 1), parity l & 1) for x0 + 16 .. x0 + 31; the tile's 16 voxels are one x run
+            const int src_a = ((lane & 48) | (vl >> 1)) * 4, src_b = src_a + 32;
+            const bool odd = vl & 1;
+#pragma unroll
+            for (int m = 0; m < M_T; ++m) {
+                if (!vok[m]) continue;                 // uniform over the wave: the tile is 16 aligned voxels
+                const int oz = 2 * vz[m] + (sub >> 2), oy = 2 * vy[m] + ((sub >> 1) & 1), ox0 = 2 * (vx[m] - vl) + vl;
+#pragma unroll
+                for (int n = 0; n < N_T; ++n) {
+                    f32x4 ra, rb;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int e0 = __builtin_bit_cast(int, val[0][m][n][c]), e1 = __builtin_bit_cast(int, val[1][m][n][c]);
+                        const int a0 = __builtin_amdgcn_ds_bpermute(src_a, e0), a1 = __builtin_amdgcn_ds_bpermute(src_a, e1);
+                        const int b0 = __builtin_amdgcn_ds_bpermute(src_b, e0), b1 = __builtin_amdgcn_ds_bpermute(src_b, e1);
+                        ra[c] = __builtin_bit_cast(float, odd ? a1 : a0);
+                        rb[c] = __builtin_bit_cast(float, odd ? b1 : b0);
+                    }
+                    float* o = a.out + (((((long long)vb[m] * (a.cout >> 2) + n * 4 + h) * odim + oz) * odim + oy) * odim + ox0) * 4;
+                    *reinterpret_cast<f32x4*>(o) = ra;
+                    *reinterpret_cast<f32x4*>(o + 64) = rb;
+                }
             }
         }
     }
@@ -405,13 +442,12 @@ __global__ __launch_bounds__(256) void deconv3d_k2s2_kernel(ConvArgs a) {
 // (voxel tile, cout tile, tap slice) is its own workgroup writing a partial sum to the workspace, and a second
 // tiny kernel adds the slices in a FIXED order (bitwise deterministic, no atomics) and applies the epilogue.
 // ------------------------------------------------------------------------------------------------
-// FUSED (round 5; SE_WS_COUNTERS): no second launch - every (voxel tile, cout pair) has an arrival counter in the tail of the workspace
-// (zero before the first launch, se_conv3d_workspace_init; the last block leaves it zero again); the block that arrives LAST for its
-// tile adds the `splits` partials in the same fixed order 0, 1, ... as splitk_reduce_kernel (bit-identical, deterministic whichever
-// block is last) and applies the epilogue.  Partials cross XCDs: release fence (L2 write-back) in front of the arrival, acquire fence
-// (invalidate) behind it - the pattern of a kernel boundary, without the boundary.
-template <int N_T, bool FUSED>
-__global__ __launch_bounds__(256) void conv3d_k3_splitk_kernel(ConvArgs a, float* __restrict__ ws, int taps_per_split, unsigned* __restrict__ counters) {
+// Round 5 tried ONE launch (arrival counter per tile in the workspace, the last-arriving block reduces in the same fixed order):
+// with device-scope release / acquire fences it cost +50 us per launch (a cache-wide write-back / invalidate per wave, 864 blocks),
+// with device-scope (sc1) stores / loads of the partials it measured EQUAL to the two launches (the reduce launches are ~4.5 us each)
+// and was not bit-stable from launch to launch - not shipped (profiles/r05_fork_and_splitk_ab.txt).
+template <int N_T>
+__global__ __launch_bounds__(256) void conv3d_k3_splitk_kernel(ConvArgs a, float* __restrict__ ws, int taps_per_split) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int vl = lane & 15;
@@ -462,46 +498,10 @@ __global__ __launch_bounds__(256) void conv3d_k3_splitk_kernel(ConvArgs a, float
             }
         }
     }
-    if (vok) {
-        float* o = ws + ((size_t)split * a.total_vox + vid) * a.cout;
+    if (!vok) return;
+    float* o = ws + ((size_t)split * a.total_vox + vid) * a.cout;
 #pragma unroll
-        for (int n = 0; n < N_T; ++n) *reinterpret_cast<f32x4*>(o + (nt0 + n) * 16 + 4 * h) = acc[n];
-    }
-    if constexpr (FUSED) {
-        __shared__ int s_last;
-        const int splits = (int)gridDim.z;
-        __threadfence();                                   // release: this thread's partials are visible device-wide ...
-        __syncthreads();                                   // ... before the block's arrival is counted
-        unsigned* cnt = counters + blockIdx.y * gridDim.x + blockIdx.x;
-        if (threadIdx.x == 0) {
-            const unsigned old = atomicAdd(cnt, 1u);
-            s_last = old == (unsigned)(splits - 1);
-        }
-        __syncthreads();
-        if (!s_last) return;
-        __threadfence();                                   // acquire: the other blocks' partials
-        if (threadIdx.x == 0) *cnt = 0;                    // ready for the next launch (stream order)
-        // the tile: 64 voxels x N_T * 16 couts = 64 x N_T * 4 (voxel, cout quad) items for 256 threads
-        const long long per_b = (long long)dim * dim * dim;
-        const size_t sstride = (size_t)a.total_vox * a.cout;
-        constexpr int QUADS = N_T * 4;
-        for (int it = threadIdx.x; it < 64 * QUADS; it += 256) {
-            const long long v2 = (long long)blockIdx.x * 64 + it / QUADS;
-            if (v2 >= a.total_vox) continue;
-            const int co = nt0 * 16 + (it % QUADS) * 4;
-            const float* p0 = ws + v2 * a.cout + co;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            for (int s0 = 0; s0 < splits; s0 += 9) {       // all partials of a group requested before the first add; the order of the sum is fixed
-                f32x4 part[9];
-#pragma unroll
-                for (int u = 0; u < 9; ++u) part[u] = (s0 + u < splits) ? *reinterpret_cast<const f32x4*>(p0 + (size_t)(s0 + u) * sstride) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int u = 0; u < 9; ++u) v += part[u];
-            }
-            const int b = (int)(v2 / per_b);
-            conv_epilogue(a, v, b, v2 - (long long)b * per_b, per_b, co);
-        }
-    }
+    for (int n = 0; n < N_T; ++n) *reinterpret_cast<f32x4*>(o + (nt0 + n) * 16 + 4 * h) = acc[n];
 }
 
 // In-workgroup split-K for the small pyramid levels (8^3, 4^3, 2^3; 128 -> 128 channels): the WAVES waves of a workgroup share ONE
@@ -929,7 +929,7 @@ bool se_conv3d_wino44pp_shape(int batch, int dim, int cout);      // conv3d_wino
 bool se_conv3d_wino44pp_layout_ok(int cin, int flags);
 extern "C" int se_conv3d_f32_variant(int batch, int dim, int cin, int cout, int ksize, int flags) {
     const int algo = se_conv3d_f32_algo(dim, cin, cout, ksize);
-    const bool forms = flags & (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET | SE_EPI_SKIPCONV16);
+    const bool forms = flags & (SE_LAYOUT_OCTET_BITS | SE_LAYOUT_QUAD_BITS | SE_EPI_SKIPCONV16);
     if (algo == 2 && !forms && se_conv3d_small_volume(batch, dim)) return 0;       // a plain channels-last call runs the in-workgroup split-K form
     if (algo == 2 && g_variant != 64 && se_conv3d_wino44pp_shape(batch, dim, cout) && se_conv3d_wino44pp_layout_ok(cin, flags)) return 3;
     return algo;
@@ -1006,7 +1006,6 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
                            float* workspace, long long workspace_elems, void* stream) {
     if (batch <= 0 || dim <= 0 || cin <= 0 || cin_pad < cin || (cin_pad & 15) || cout <= 0) return SE_ERR_BAD_ARG;
     if (ksize != 1 && ksize != 3 && ksize != 7) return SE_ERR_BAD_ARG;
-    if ((flags & SE_WS_COUNTERS) && (!workspace || workspace_elems < 2 * SE_WS_COUNTER_ELEMS)) return SE_ERR_BAD_ARG;
     const bool planar = flags & SE_EPI_OUT_PLANAR;
     if (!planar && (cout & 15)) return SE_ERR_BAD_ARG;
     if (planar && (flags & (SE_EPI_RES_PRE_RELU | SE_EPI_RES_POST_RELU))) return SE_ERR_BAD_ARG;
@@ -1015,7 +1014,7 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
     ConvArgs a;
     a.in = in; a.wpack = wpack; a.bpack = bpack; a.res = residual; a.out = out;
     a.total_vox = (long long)batch * dim * dim * dim;
-    a.dim = dim; a.cin = cin; a.cin_pad = cin_pad; a.cout = cout; a.nts = round_up16(cout) / 16; a.flags = flags & ~SE_WS_COUNTERS;
+    a.dim = dim; a.cin = cin; a.cin_pad = cin_pad; a.cout = cout; a.nts = round_up16(cout) / 16; a.flags = flags;
     a.wpack_b = wpack + packed_elems_a(cout, cin_pad, ksize, 0);
     a.wpack_d = nullptr;
     if (ksize == 7 && cout <= 16)
@@ -1038,10 +1037,15 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
     if (ksize == 3 && (cout % 32)) a.wpack_b = nullptr;
     if (ksize == 1) a.wpack_b = nullptr;
     if ((flags & SE_IN_PLANAR3) && ksize != 7) return SE_ERR_BAD_ARG;
-    if ((flags & (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET)) && se_conv3d_f32_algo(dim, cin, cout, ksize) != 2) return SE_ERR_BAD_ARG;
+    if ((flags & (SE_LAYOUT_OCTET_BITS | SE_LAYOUT_QUAD_BITS)) && se_conv3d_f32_algo(dim, cin, cout, ksize) != 2) return SE_ERR_BAD_ARG;
+    if ((flags & SE_LAYOUT_OCTET_BITS) && (flags & SE_LAYOUT_QUAD_BITS)) return SE_ERR_BAD_ARG;
+    // quad-planar tensors exist in the F(4,3) x F(4,3) kernel only - and as the OUTPUT of a channels-last launch of the F(4,3) x F(2,3) one
+    if ((flags & SE_LAYOUT_QUAD_BITS) && se_conv3d_f32_variant(batch, dim, cin, cout, ksize, flags) != 3 &&
+        (flags & SE_LAYOUT_QUAD_BITS) != SE_OUT_QUAD)
+        return SE_ERR_BAD_ARG;
     const int took = se_conv3d_tiled_try(a, batch, ksize, s);
     if (took != SE_TILED_NOT_TAKEN) return took;
-    if (flags & (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET)) return SE_ERR_BAD_ARG;   // only the 2-D Winograd kernel knows the octet-planar forms
+    if (flags & (SE_LAYOUT_OCTET_BITS | SE_LAYOUT_QUAD_BITS)) return SE_ERR_BAD_ARG;   // only the 2-D Winograd kernels know the planar forms
     if (flags & SE_IN_PLANAR3) return SE_ERR_BAD_ARG;
     // small volumes with wide channels: split the taps over grid.z when the plain launch would not fill the chip
     if (ksize == 3 && !planar && a.nts % 2 == 0 && a.total_vox <= 8192 && (a.total_vox * cin_pad * 4LL) < (1LL << 31) && g_variant_direct != 1 &&
@@ -1062,20 +1066,11 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
         const long long wgs = m_blocks * (a.nts / 2);
         if (wgs < 1024) {
             int splits = 27;                                  // taps per split: 1, 3, 9 (or no split)
-            const long long ws_partials = (flags & SE_WS_COUNTERS) ? workspace_elems - SE_WS_COUNTER_ELEMS : workspace_elems;
-            while (splits > 1 && (wgs * (splits / 3) >= 2048 || (long long)splits * a.total_vox * cout > ws_partials))
+            while (splits > 1 && (wgs * (splits / 3) >= 2048 || (long long)splits * a.total_vox * cout > workspace_elems))
                 splits /= 3;
-            if (splits > 1 && (flags & SE_WS_COUNTERS)) {
-                // one launch: the last-arriving block of a tile reduces (counters in the workspace tail, zero between launches)
-                unsigned* counters = reinterpret_cast<unsigned*>(workspace + workspace_elems - SE_WS_COUNTER_ELEMS);
-                hipLaunchKernelGGL((conv3d_k3_splitk_kernel<2, true>), dim3((unsigned)m_blocks, a.nts / 2, splits), dim3(256), 0, s,
-                                   a, workspace, 27 / splits, counters);
-                SE_CHECK_LAUNCH();
-                return 0;
-            }
             if (splits > 1) {
-                hipLaunchKernelGGL((conv3d_k3_splitk_kernel<2, false>), dim3((unsigned)m_blocks, a.nts / 2, splits), dim3(256), 0, s,
-                                   a, workspace, 27 / splits, nullptr);
+                hipLaunchKernelGGL((conv3d_k3_splitk_kernel<2>), dim3((unsigned)m_blocks, a.nts / 2, splits), dim3(256), 0, s,
+                                   a, workspace, 27 / splits);
                 SE_CHECK_LAUNCH();
                 const long long threads = a.total_vox * (cout / 4);
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a,
@@ -1090,12 +1085,6 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
         case 3: return launch_direct<3>(a, s);
         default: return launch_direct<7>(a, s);
     }
-}
-
-extern "C" int se_conv3d_workspace_init(float* workspace, long long workspace_elems, void* stream) {
-    if (!workspace || workspace_elems < 2 * SE_WS_COUNTER_ELEMS) return SE_ERR_BAD_ARG;
-    const hipError_t e = hipMemsetAsync(workspace + workspace_elems - SE_WS_COUNTER_ELEMS, 0, SE_WS_COUNTER_ELEMS * sizeof(float), se_stream(stream));
-    return e == hipSuccess ? 0 : (int)e;
 }
 
 extern "C" int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
@@ -1119,8 +1108,8 @@ extern "C" int se_conv3d_skip16_f32(const float* in, const float* wpack, const f
                                     const float* skip_w, float* out, int batch, int dim, int cin, int cout, int flags,
                                     void* stream) {
     if (!skip_in || !skip_w) return SE_ERR_BAD_ARG;
-    if ((flags & (SE_IN_OCTET | SE_OUT_OCTET)) != (SE_IN_OCTET | SE_OUT_OCTET)) return SE_ERR_BAD_ARG;
-    if (flags & ~(SE_IN_OCTET | SE_OUT_OCTET | SE_EPI_RELU)) return SE_ERR_BAD_ARG;
+    const int lay = flags & ~SE_EPI_RELU;
+    if (lay != (SE_IN_OCTET | SE_OUT_OCTET) && lay != (SE_IN_QUAD | SE_OUT_QUAD)) return SE_ERR_BAD_ARG;
     return conv3d_f32_impl(in, wpack, bpack, skip_in, out, nullptr, skip_w, batch, dim, cin, cin, cout, 3,
                            flags | SE_EPI_SKIPCONV16, nullptr, 0, stream);
 }
@@ -1130,10 +1119,12 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
     if (batch <= 0 || dim <= 0 || cin <= 0 || (cin & 15) || cout <= 0 || (cout & 15)) return SE_ERR_BAD_ARG;
     if (flags & SE_EPI_OUT_PLANAR) return SE_ERR_BAD_ARG;
     if ((flags & SE_EPI_RES_PRE_RELU) && (flags & SE_EPI_RES_POST_RELU)) return SE_ERR_BAD_ARG;
+    if (flags & (SE_LAYOUT_OCTET_BITS | SE_IN_QUAD | SE_RES_QUAD)) return SE_ERR_BAD_ARG;
+    const bool outq = flags & SE_OUT_QUAD;
     ConvArgs a;
     a.in = in; a.wpack = wpack; a.bpack = bpack; a.res = residual; a.out = out;
     a.total_vox = (long long)batch * dim * dim * dim;
-    a.dim = dim; a.cin = cin; a.cin_pad = cin; a.cout = cout; a.nts = cout / 16; a.flags = flags;
+    a.dim = dim; a.cin = cin; a.cin_pad = cin; a.cout = cout; a.nts = cout / 16; a.flags = flags & ~SE_OUT_QUAD;
     a.wpack_b = nullptr;
     a.wpack_d = nullptr;
     a.wpack_e = nullptr;
@@ -1149,9 +1140,20 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
     const unsigned g2 = (unsigned)((a.total_vox + 127) / 128), g1 = (unsigned)((a.total_vox + 63) / 64);
 #define SE_DECONV_CASE(CI, CO, MT, G)                                                                                          \
     if (cin == CI && cout == CO) {                                                                                             \
-        hipLaunchKernelGGL((deconv3d_k2s2_kernel<CI / 16, CO / 16, MT>), dim3(G), dim3(256), 0, se_stream(stream), a);        \
+        hipLaunchKernelGGL((deconv3d_k2s2_kernel<CI / 16, CO / 16, MT, false>), dim3(G), dim3(256), 0, se_stream(stream), a); \
         SE_CHECK_LAUNCH();                                                                                                     \
         return 0;                                                                                                              \
+    }
+    if (outq) {
+        // quad-planar output (SE_OUT_QUAD): the 64 -> 32 layer in front of back_layers.0, volumes whose x rows hold whole 16-voxel tiles
+        if ((dim & 15) || !((cin == 64 && cout == 32) || (cin == 128 && cout == 64))) return SE_ERR_BAD_ARG;
+        const bool two = g2 >= 4u * (unsigned)se_num_cus();
+        if (cin == 64 && two) hipLaunchKernelGGL((deconv3d_k2s2_kernel<4, 2, 2, true>), dim3(g2), dim3(256), 0, se_stream(stream), a);
+        else if (cin == 64) hipLaunchKernelGGL((deconv3d_k2s2_kernel<4, 2, 1, true>), dim3(g1), dim3(256), 0, se_stream(stream), a);
+        else if (two) hipLaunchKernelGGL((deconv3d_k2s2_kernel<8, 4, 2, true>), dim3(g2), dim3(256), 0, se_stream(stream), a);
+        else hipLaunchKernelGGL((deconv3d_k2s2_kernel<8, 4, 1, true>), dim3(g1), dim3(256), 0, se_stream(stream), a);
+        SE_CHECK_LAUNCH();
+        return 0;
     }
     if (g2 >= 4u * (unsigned)se_num_cus()) {
         SE_DECONV_CASE(64, 32, 2, g2)

@@ -227,7 +227,7 @@ static int tiled_try_one(const ConvArgs& a, int batch, int launch_batch, int ksi
     // in-workgroup split-K kernel of the 8^3 level (conv_common.h: se_conv3d_small_volume; 47 against 92 us per 128 -> 128 launch);
     // a caller that asks for an octet-planar / pooled / fused-skip form gets the 2-D kernel as before
     if (ksize == 3 && g_variant == 0 && se_conv3d_small_volume(launch_batch, dim) && a.cin_pad == a.cin && se_wino2d_shape_ok(dim, a.cin, a.cout) &&
-        !(a.flags & (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET | SE_EPI_SKIPCONV16 | SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR)) && !a.pool_out &&
+        !(a.flags & (SE_LAYOUT_OCTET_BITS | SE_LAYOUT_QUAD_BITS | SE_EPI_SKIPCONV16 | SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR)) && !a.pool_out &&
         !a.skip_w && (a.nts % 2) == 0)
         return SE_TILED_NOT_TAKEN;
     if (ksize == 3 && (g_variant == 0 || (g_variant >= 40 && g_variant < 70))) {   // production: 2-D Winograd F(4,3) x F(2,3), register accumulators
@@ -237,7 +237,7 @@ static int tiled_try_one(const ConvArgs& a, int batch, int launch_batch, int ksi
     // octet-planar tensors, the pooled second output and the fused 16-channel skip convolution exist in the 2-D Winograd kernel only:
     // a launch that asks for one of them and was declined (cin_pad != cin, SE_EPI_RES_POST_RELU / SE_EPI_OUT_PLANAR, ...) is an error -
     // none of the kernels below would read or write those tensors the way the caller laid them out
-    if ((a.flags & (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET | SE_EPI_SKIPCONV16)) || a.pool_out || a.skip_w) return SE_ERR_BAD_ARG;
+    if ((a.flags & (SE_LAYOUT_OCTET_BITS | SE_LAYOUT_QUAD_BITS | SE_EPI_SKIPCONV16)) || a.pool_out || a.skip_w) return SE_ERR_BAD_ARG;
     if (ksize == 3 && (g_variant == 0 || g_variant == 4 || g_variant == 30 || (g_variant >= 10 && g_variant < 20))) {   // 1-D Winograd F(4,3) (se_debug_set_variant(30): instead of the 2-D kernel)
         const int rc = se_conv3d_wino_try(a, batch, s);
         if (rc != SE_TILED_NOT_TAKEN) return rc;

@@ -376,7 +376,7 @@ unsigned long long* g_wino_dbg43 = nullptr;
 int se_conv3d_wino_try(const ConvArgs& a, int batch, hipStream_t s) {
     const int dim = a.dim;
     if (!a.wpack_b || !a.wpack_e || dim < 16 || (dim & 7) || (a.cout & 31) || (a.cin & 15) || a.cin_pad != a.cin) return SE_TILED_NOT_TAKEN;
-    if (a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR | SE_IN_OCTET | SE_OUT_OCTET)) return SE_TILED_NOT_TAKEN;
+    if (a.flags & (SE_EPI_RES_POST_RELU | SE_EPI_OUT_PLANAR | SE_LAYOUT_OCTET_BITS | SE_LAYOUT_QUAD_BITS)) return SE_TILED_NOT_TAKEN;
     constexpr int LDS43 = 160 * 1024;
     constexpr int MAXPP = (LDS43 - (W43_FLOATS + 2 * PP_VH_FLOATS) * 4) / 16;
     const int num_cus = se_num_cus();

@@ -113,14 +113,16 @@ constexpr int rider_raw_count(int gg, int g) {
 // LAYOUT: bit 0 = input is octet-planar [B][cin/8][D][D][D][8] (SE_IN_OCTET), bit 1 = output is octet-planar (SE_OUT_OCTET),
 // bit 2 = the skip tensor is octet-planar (SE_RES_OCTET), bit 3 = also write the 2x2x2 max-pool of the output (se_conv3d_pool_f32;
 // instantiated for the layouts the V2V program pools: 3 and 7), bit 4 = the skip path is a 1x1x1 convolution over a 16-channel
-// channels-last tensor computed in the epilogue (se_conv3d_skip16_f32; instantiated for layout 3).
+// channels-last tensor computed in the epilogue (se_conv3d_skip16_f32; instantiated for layout 3), bit 5 = the output is QUAD-planar
+// [B][cout/4][D][D][D][4] (SE_OUT_QUAD alone, instantiated for layout 32: channels-last input, no skip tensor - the first convolution
+// of a block whose second one runs on the F(4,3) x F(4,3) kernel and whose input comes channels-last from a max-pool; round 5).
 // In the octet-planar form an 8-channel chunk of a halo row is ONE contiguous run (18 positions x 32 B) instead of 18 pieces of
 // 32 B at a 4*cin-byte stride: 4x fewer cache lines per load instruction.
 template <int EXP, int LAYOUT>
 __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const float* __restrict__ wg, int tiles_x, int tiles_y,
                                                                int tiles_z, int total_tiles, int n_units, int units_per_wg, unsigned long long* dbg) {
     constexpr int exp = EXP;
-    constexpr bool in_oct = LAYOUT & 1, out_oct = LAYOUT & 2, res_oct = LAYOUT & 4, pool = LAYOUT & 8, skc = LAYOUT & 16;
+    constexpr bool in_oct = LAYOUT & 1, out_oct = LAYOUT & 2, res_oct = LAYOUT & 4, pool = LAYOUT & 8, skc = LAYOUT & 16, out_quad = LAYOUT & 32;
     unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, t8 = 0, st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5; (void)t6; (void)t7; (void)t8; (void)st; (void)dbg;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -388,9 +390,11 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
         const int ystride_cl = dim * a.cout, zstride_cl = dim * dim * a.cout;
         // octet-planar output: octet (cb*4 + ct*2 + h/2), 16 bytes at (h & 1) * 4 inside the 8-channel record of voxel (z, y, x)
         const long long s00o = (((((long long)u.b * (a.cout >> 3) + u.cb * 4 + ct * 2) * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * 8;
-        const int voff = out_oct ? (h >> 1) * dim * dim * dim * 8 + px * 8 + (h & 1) * 4 : voff_cl;   // (a.cout == channels of out and of the skip tensor)
-        const int ystride = out_oct ? dim * 8 : ystride_cl, zstride = out_oct ? dim * dim * 8 : zstride_cl;
-        float* ob = a.out + (out_oct ? s00o : s00);
+        // quad-planar output: plane (cb*8 + ct*4 + h), the lane's 4 couts are the 16-byte record of voxel (z, y, x)
+        const long long s00q = (((((long long)u.b * (a.cout >> 2) + u.cb * 8 + ct * 4) * dim + u.z0) * dim + u.y0 + G * 4 + jt * 2) * dim + u.x0) * 4;
+        const int voff = out_quad ? h * dim * dim * dim * 4 + px * 4 : out_oct ? (h >> 1) * dim * dim * dim * 8 + px * 8 + (h & 1) * 4 : voff_cl;   // (a.cout == channels of out and of the skip tensor)
+        const int ystride = out_quad ? dim * 4 : out_oct ? dim * 8 : ystride_cl, zstride = out_quad ? dim * dim * 4 : out_oct ? dim * dim * 8 : zstride_cl;
+        float* ob = a.out + (out_quad ? s00q : out_oct ? s00o : s00);
         // all eight output vectors first, then the skip tensor (prefetched behind the V-tile transform; its latency also
         // overlaps this arithmetic), ReLU and the stores
         f32x4 out[2][4];
@@ -765,6 +769,10 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, int launch_batch, hipStre
     // round 4: the 64^3 / 32^3 levels run on the F(4,3) x F(4,3) ping-pong kernel (1/4 of the direct MFMAs; this kernel: 1/3);
     // development builds: se_debug_set_variant(64) keeps them here (A/B)
     if (g_variant != 64 && g_variant < 41 && se_conv3d_wino44pp_takes(a, launch_batch)) return se_conv3d_wino44pp_launch(a, batch, s);
+    // this kernel's planar layout is octet-planar; the one quad-planar form it has: channels-last in, quad-planar out, no skip tensor
+    const bool quad_out_only = (a.flags & SE_LAYOUT_QUAD_BITS) == SE_OUT_QUAD && !(a.flags & SE_LAYOUT_OCTET_BITS) && !a.res && !a.pool_out &&
+                               !(a.flags & SE_EPI_SKIPCONV16);
+    if ((a.flags & SE_LAYOUT_QUAD_BITS) && !quad_out_only) return SE_ERR_BAD_ARG;
     const int tx = dim / 16, ty = dim / 8, tz = dim / 4;
     const long long total_tiles = (long long)batch * tx * ty * tz;
     const long long n_units = total_tiles * (a.cout / 32);
@@ -823,6 +831,11 @@ int se_conv3d_wino2d_try(const ConvArgs& a, int batch, int launch_batch, hipStre
         if (layout == 3) W2_LAUNCH(0, 11);
         else if (layout == 7) W2_LAUNCH(0, 15);
         else return SE_ERR_BAD_ARG;       // pooled output: octet-planar in / out only (what the V2V program uses)
+        SE_CHECK_LAUNCH();
+        return 0;
+    }
+    if (quad_out_only) {
+        W2_LAUNCH(0, 32);
         SE_CHECK_LAUNCH();
         return 0;
     }

@@ -165,9 +165,13 @@ __device__ __forceinline__ void at43p(const f32x4& m0, const f32x4& m1, const f3
     }
 }
 
-// LAYOUT: bit 0 = input octet-planar [B][cin/8][D][D][D][8] (SE_IN_OCTET), bit 1 = output octet-planar (SE_OUT_OCTET), bit 2 = skip
-// tensor octet-planar (SE_RES_OCTET), bit 3 = also write the 2x2x2 max-pool of the output (se_conv3d_pool_f32), bit 4 = the skip path
-// is a 1x1x1 convolution over a 16-channel channels-last tensor computed in the epilogue (se_conv3d_skip16_f32)
+// LAYOUT: bit 0 = input QUAD-planar [B][cin/4][D][D][D][4] (SE_IN_QUAD), bit 1 = output quad-planar (SE_OUT_QUAD), bit 2 = skip
+// tensor quad-planar (SE_RES_QUAD), bit 3 = also write the 2x2x2 max-pool of the output (se_conv3d_pool_f32), bit 4 = the skip path
+// is a 1x1x1 convolution over a 16-channel channels-last tensor computed in the epilogue (se_conv3d_skip16_f32).
+// Quad-planar (round 5; rounds 2-4 handed octet-planar tensors [B][C/8][D^3][8] between these launches): a 4-channel step reads WHOLE
+// 16-byte records, 18 of them contiguous per halo row (288 B), instead of half of every 32-byte octet record - that half was the
+// 1.57 x of the counter traffic over the algorithmic bytes; an MFMA D fragment (4 couts of a voxel per lane) is
+// exactly one record, 16 lanes write 256 contiguous bytes.  The octet-planar flags are served by the F(4,3) x F(2,3) kernel only.
 template <int LAYOUT>
 __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, const float* __restrict__ wg, int tiles_x, int tiles_y, int tiles_z,
                                                                  int total_tiles, int n_units, int units_per_wg, unsigned long long* dbg) {
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
     unsigned st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = 0;
 #endif
-    constexpr bool in_oct = LAYOUT & 1, out_oct = LAYOUT & 2, res_oct = LAYOUT & 4, pool = LAYOUT & 8, skc = LAYOUT & 16;
+    constexpr bool in_pl = LAYOUT & 1, out_pl = LAYOUT & 2, res_pl = LAYOUT & 4, pool = LAYOUT & 8, skc = LAYOUT & 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;
     float* vt = lds + 3 * P_SLOT;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
     // volume (reads zero).  No vector instruction but the load itself rides in the MFMA stream.
     constexpr unsigned OOB = 0x80000000u;
     const unsigned in_bytes = (unsigned)dim * dim * dim * cin * 4u;
-    const int vfl = in_oct ? 8 : cin;                                                 // floats between x neighbours
+    const int vfl = in_pl ? 4 : cin;                                                  // floats between x neighbours
     f32x4 raw[6];
     unsigned f_voff = OOB;
     auto fetch_setup = [&](const UnitP& u) {
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
         f_voff = ok ? (unsigned)((gz * dim * dim + gx) * vfl * 4) : OOB;
     };
     auto row_base = [&](const UnitP& u, int c4) {        // element (z 0, y 0, x 0) of the step's sample / channel quad
-        return a.in + (long long)u.b * dim * dim * dim * cin + (in_oct ? (long long)(c4 >> 1) * dim * dim * dim * 8 + (c4 & 1) * 4 : c4 * 4);
+        return a.in + (long long)u.b * dim * dim * dim * cin + (in_pl ? (long long)c4 * dim * dim * dim * 4 : c4 * 4);
     };
     auto fetch_one = [&](const UnitP& u, int c4, auto r_tag) {
         constexpr int r = decltype(r_tag)::value;
@@ -354,19 +358,19 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return reinterpret_cast<gfloat*>(((unsigned long long)hi << 32) | lo);
     };
-    auto lane_off = [&](bool oct) {          // per-lane element offset of this lane's 4 couts of x position px (recomputed per tile)
+    auto lane_off = [&](bool pl) {           // per-lane element offset of this lane's 4 couts of x position px (recomputed per tile)
         int l = lane;
         asm volatile("" : "+v"(l));
         const int pxx = l & 15, hh = l >> 4;
-        return oct ? (hh >> 1) * dim * dim * dim * 8 + pxx * 8 + (hh & 1) * 4 : pxx * a.cout + 4 * hh;
+        return pl ? hh * dim * dim * dim * 4 + pxx * 4 : pxx * a.cout + 4 * hh;      // quad-planar: the lane's 4 couts are ONE record of plane hh
     };
-    const int o_ys = out_oct ? dim * 8 : dim * a.cout, o_zs = o_ys * dim;
-    const int r_ys = res_oct ? dim * 8 : dim * a.cout, r_zs = r_ys * dim;
-    auto tile_base = [&](const float* t, const UnitP& u, bool oct) {
+    const int o_ys = out_pl ? dim * 4 : dim * a.cout, o_zs = o_ys * dim;
+    const int r_ys = res_pl ? dim * 4 : dim * a.cout, r_zs = r_ys * dim;
+    auto tile_base = [&](const float* t, const UnitP& u, bool pl) {
         const int gz0 = u.z0 + 4 * zt, gy0 = u.y0 + 4 * G;
         const long long cl = ((((long long)u.b * dim + gz0) * dim + gy0) * dim + u.x0) * a.cout + u.cb * 32 + ct * 16;
-        const long long oc = (((((long long)u.b * (a.cout >> 3) + u.cb * 4 + ct * 2) * dim + gz0) * dim + gy0) * dim + u.x0) * 8;
-        return uniform_ptr(t + (oct ? oc : cl));
+        const long long qp = (((((long long)u.b * (a.cout >> 2) + u.cb * 8 + ct * 4) * dim + gz0) * dim + gy0) * dim + u.x0) * 4;
+        return uniform_ptr(t + (pl ? qp : cl));
     };
     // skip tensor rv[y][z]; the fused 1x1x1 skip convolution reads its 16-channel channels-last input the same way (4 channels per k lane)
     f32x4 wsk = {0.f, 0.f, 0.f, 0.f};
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
             const int gz0 = u.z0 + 4 * zt, gy0 = u.y0 + 4 * G;
             return uniform_ptr(a.res + ((((long long)u.b * dim + gz0) * dim + gy0) * dim + u.x0) * 16);
         } else {
-            return tile_base(a.res, u, res_oct);
+            return tile_base(a.res, u, res_pl);
         }
     };
     // Raw buffer loads, issued for EVERY tile: without a skip tensor the descriptor has zero records and the loads return zeros
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
     auto load_rv = [&](f32x4 (&rv)[4][4], const gfloat* rb) {
         int l = lane;
         asm volatile("" : "+v"(l));
-        const int r_lane = skc ? (l & 15) * 16 + 4 * (l >> 4) : lane_off(res_oct);
+        const int r_lane = skc ? (l & 15) * 16 + 4 * (l >> 4) : lane_off(res_pl);
         const bool on = (skc || use_res) && !(SE_K44P_EXP & 16);
         const auto rs = __builtin_amdgcn_make_buffer_rsrc((float*)rb, 0, on ? 0x7fffffff : 0, 0x00020000);
 #pragma unroll
@@ -420,9 +424,9 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
     // either: the first MFMA of every accumulator in a tile's first step takes an inline-constant zero as its C operand.
     // y runs 3..0: y = 3 reads acc[18..23] before y = 0 parks into acc[20..23].
     gfloat* p_ob = nullptr;             // output rows of the tile whose outputs are parked
-    const int o_lane = lane_off(out_oct);
+    const int o_lane = lane_off(out_pl);
     auto epilogue_z = [&](const UnitP& u, f32x4 (&rv)[4][4]) {
-        p_ob = tile_base(a.out, u, out_oct);
+        p_ob = tile_base(a.out, u, out_pl);
         const f32x4 bias = *reinterpret_cast<const gf32x4*>(uniform_ptr(a.bpack + u.cb * 32 + ct * 16) + 4 * h);
         if constexpr (skc) wsk = *reinterpret_cast<const gf32x4*>(uniform_ptr(a.skip_w + (u.cb * 32 + ct * 16) * 16) + px * 16 + 4 * h);
 #pragma unroll
@@ -735,8 +739,13 @@ bool se_conv3d_wino44pp_shape(int batch, int dim, int cout) {
     return units >= se_num_cus() || dim >= 64;
 }
 // A channels-last input with >= 32 channels stays on the F(4,3) x F(2,3) kernel: a 4-channel chunk is 16 bytes of every 128-byte
-// record there (measured 0.578 against 0.506 ms at 32->32 @64^3; one launch per step has such an input, back_layers.0).
-bool se_conv3d_wino44pp_layout_ok(int cin, int flags) { return (flags & SE_IN_OCTET) || cin < 32; }
+// record there (measured 0.578 against 0.506 ms at 32->32 @64^3).
+// input layouts: quad-planar, or channels-last with fewer than 32 channels (a 4-channel chunk is 16 bytes of every cin * 4-byte
+// record); any octet-planar tensor belongs to the F(4,3) x F(2,3) kernel
+bool se_conv3d_wino44pp_layout_ok(int cin, int flags) {
+    if (flags & (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET)) return false;
+    return (flags & SE_IN_QUAD) || cin < 32;
+}
 bool se_conv3d_wino44pp_takes(const ConvArgs& a, int batch) {
     if (!se_conv3d_wino44pp_layout_ok(a.cin, a.flags)) return false;
     return a.wpack_i && se_conv3d_wino44pp_shape(batch, a.dim, a.cout);
@@ -767,7 +776,7 @@ int se_conv3d_wino44pp_launch(const ConvArgs& a, int batch, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3((unsigned)((n_units + per - 1) / per)), dim3(512), P_LDS_BYTES, s, a, a.wpack_i, tx, ty,  \
                            tz, (int)total_tiles, (int)n_units, per, dbg);                                                       \
     } while (0)
-    const int layout = ((a.flags & SE_IN_OCTET) ? 1 : 0) | ((a.flags & SE_OUT_OCTET) ? 2 : 0) | ((a.flags & SE_RES_OCTET) && a.res ? 4 : 0);
+    const int layout = ((a.flags & SE_IN_QUAD) ? 1 : 0) | ((a.flags & SE_OUT_QUAD) ? 2 : 0) | ((a.flags & SE_RES_QUAD) && a.res ? 4 : 0);
     if (a.flags & SE_EPI_SKIPCONV16) {
         if (layout != 3 || a.pool_out || !a.skip_w || !a.res) return SE_ERR_BAD_ARG;
         P_LAUNCH(19);
@@ -777,7 +786,7 @@ int se_conv3d_wino44pp_launch(const ConvArgs& a, int batch, hipStream_t s) {
     if (a.pool_out) {
         if (layout == 3) P_LAUNCH(11);
         else if (layout == 7) P_LAUNCH(15);
-        else return SE_ERR_BAD_ARG;       // pooled output: octet-planar in / out only (what the V2V program uses)
+        else return SE_ERR_BAD_ARG;       // pooled output: quad-planar in / out only (what the V2V program uses)
         SE_CHECK_LAUNCH();
         return 0;
     }

@@ -24,8 +24,11 @@ import torch.nn as nn
 from . import _lib
 
 
-# a level's skip block is forked onto the side stream when batch x voxels of the level is at most this (64^3 at batch 1)
-FORK_MAX_VOXELS = 64 ** 3
+# A level's skip block is forked onto the side stream when batch x voxels of the level is at most this.  0 = never: measured in
+# round 5 (tools/diag/fork_sweep.py, tools/diag/splitk_ab.py; profiles/r05_fork_and_splitk_ab.txt) every fork set is SLOWER than the
+# single-stream order on this platform - batch 1: 2.83 -> 3.0-3.2 ms eager, 2.82 -> 3.02 ms as a replayed hipGraph; batch 8: +0.1-0.2 ms -
+# a cross-queue dependency costs more than the overlap of the under-filled launches returns.  The capability stays (fork_levels).
+FORK_MAX_VOXELS = 0
 
 
 def _round16(c):
@@ -232,22 +235,15 @@ class V2VProgram:
         self.back2 = basic(bl[2])
         self.out = _PackedConv(model.output_layer, None, None, dtype)
         self.out_scaled = self.out if self.output_scale == 1.0 else _PackedConv(model.output_layer, None, None, dtype, scale=self.output_scale)
-        # scratch for the split-K path of the small pyramid levels (se_conv3d_f32 workspace): 32 Mi floats, arrival counters in its tail
-        # (se_conv3d_workspace_init + SE_WS_COUNTERS: the 4^3 / 2^3 levels reduce in the last-arriving workgroup, one launch per layer).
-        # A workspace serves ONE stream at a time: the forked skip branches (run()) have their own.
-        self.workspace = self._new_workspace() if dtype == torch.float32 else None
-        self.workspace_side = self._new_workspace() if dtype == torch.float32 else None     # (created here, never inside a graph capture)
-        self._side_stream = torch.cuda.Stream(device=self.device) if dtype == torch.float32 else None
+        # scratch for the split-K path of the small pyramid levels (se_conv3d_f32 workspace): 32 Mi floats.  A workspace serves ONE
+        # stream at a time: the forked skip branches (run(), off by default) have their own.
+        self.workspace = torch.empty(32 << 20, device=self.device, dtype=torch.float32) if dtype == torch.float32 else None
+        self.workspace_side = None
+        self._side_stream = None
         self._ws = self.workspace              # the workspace of the stream run() is issuing on
         # skip_res{k+1} of the levels in fork_levels run on a side stream beside the encoder chain (reference network/v2v.py:104-119:
         # skip_x_k = skip_res_k(x) is not read before decoder_upsample_k).  None = decide per batch in run().
         self.fork_levels = None
-
-    def _new_workspace(self):
-        ws = torch.empty(32 << 20, device=self.device, dtype=torch.float32)
-        _lib.conv3d_workspace_init(ws)
-        torch.cuda.current_stream(self.device).synchronize()      # set-up time only: the counters are zero before any stream uses them
-        return ws
 
     def _pack_res(self, m):
         c1 = _PackedConv(m.res_branch[0], m.res_branch[1], None, self.dtype, split3=self.split3)
@@ -271,51 +267,58 @@ class V2VProgram:
         if self.split3 and pc.w_split is not None and dim % 16 == 0 and pool_out is None:
             _lib.conv3d_k3_split3(x, pc.w_split, pc.b, residual, out, B, dim, pc.cin_pad, pc.cout, flags)
             return out
-        ws = self._ws
-        _lib.conv3d(x, pc.w, pc.b, residual, out, B, dim, pc.cin, pc.cin_pad, pc.cout, pc.k, flags | (_lib.WS_COUNTERS if ws is not None else 0),
-                    ws, pool_out=pool_out)
+        _lib.conv3d(x, pc.w, pc.b, residual, out, B, dim, pc.cin, pc.cin_pad, pc.cout, pc.k, flags, self._ws, pool_out=pool_out)
         return out
 
-    def _res(self, x, blk, B, dim, x_oct=False, out_oct=False, pool_out=None):
+    _LAY = {"quad": (_lib.IN_QUAD, _lib.OUT_QUAD, _lib.RES_QUAD), "oct": (_lib.IN_OCTET, _lib.OUT_OCTET, _lib.RES_OCTET)}
+
+    def _res(self, x, blk, B, dim, x_lay=None, out_planar=False, pool_out=None):
         """Res3DBlock (v2v.py:40-43): relu(bn(conv(relu(bn(conv(x))))) + skip(x)).
 
-        Layouts (float32 program, blocks whose two 3x3x3 convolutions run on the 2-D Winograd kernel): the tensor between the two
-        convolutions is always octet-planar [B][C/8][D][D][D][8]; ``x_oct`` says the block input is, ``out_oct`` asks for an
-        octet-planar block output (4x fewer cache lines per halo load of the reader; see run() for who reads what)."""
+        Layouts (float32 program, blocks whose two 3x3x3 convolutions run on a 2-D Winograd kernel): the tensor between the two
+        convolutions is always in the block's planar layout (``_planar``: quad-planar [B][C/4][D][D][D][4] on the F(4,3) x F(4,3) kernel,
+        octet-planar [B][C/8][D][D][D][8] on the F(4,3) x F(2,3) one); ``x_lay`` names the layout of the block input (None =
+        channels-last), ``out_planar`` asks for the block output in the block's planar layout (see run() for who reads what)."""
         c1, c2, sk = blk
-        w2d = self._oct_ok(blk, dim, B)    # both convolutions take the octet-planar flags (2-D Winograd, or the split-bf16 kernel)
-        assert w2d or not (x_oct or out_oct)
-        assert sk is None or not x_oct           # the 1x1x1 skip convolution reads channels-last
-        mid = _lib.OUT_OCTET if w2d else 0
-        a = self._conv(x, c1, B, dim, _lib.EPI_RELU | mid | (_lib.IN_OCTET if x_oct else 0))
+        kind = self._planar(blk, dim, B)    # both convolutions take the planar / pooled / fused-skip forms of this kernel family
+        assert kind or not (x_lay or out_planar)
+        assert x_lay in (None, kind)
+        assert sk is None or not x_lay           # the 1x1x1 skip convolution reads channels-last
+        IN, OUT, RES = self._LAY[kind] if kind else (0, 0, 0)
+        a = self._conv(x, c1, B, dim, _lib.EPI_RELU | OUT | (IN if x_lay else 0))
         fused = sk.fused if sk is not None else None
-        if fused is not None and w2d and not self.split3 and out_oct and pool_out is None and not x_oct:
+        if fused is not None and kind and not self.split3 and out_planar and pool_out is None and not x_lay:
             out = torch.empty((B, dim, dim, dim, c2.cout), device=self.device, dtype=self.dtype)
-            _lib.conv3d_skip16(a, c2.w, fused[1], x, fused[0], out, B, dim, c2.cin, c2.cout, _lib.EPI_RELU | _lib.IN_OCTET | _lib.OUT_OCTET)
+            _lib.conv3d_skip16(a, c2.w, fused[1], x, fused[0], out, B, dim, c2.cin, c2.cout, _lib.EPI_RELU | IN | OUT)
             return out
         s = x if sk is None else self._conv(x, sk, B, dim, 0)
-        f2 = _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | (_lib.IN_OCTET if w2d else 0)
-        if x_oct and sk is None:
-            f2 |= _lib.RES_OCTET
-        if out_oct:
-            f2 |= _lib.OUT_OCTET
+        f2 = _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | IN
+        if x_lay and sk is None:
+            f2 |= RES
+        if out_planar:
+            f2 |= OUT
         return self._conv(a, c2, B, dim, f2, residual=s, pool_out=pool_out)      # pool_out: the block's 2x max-pool, written by the same launch
 
-    def _oct_ok(self, blk, dim, B):
-        """Do both convolutions of the block take the octet-planar / pooled / fused-skip forms at this (batch, level)?  (2-D Winograd
-        family: variants 2 and 3; a level with so few voxels that the plain split-K kernel is faster - 16^3 at batch 1 - says no and
-        stays channels-last.)"""
+    def _planar(self, blk, dim, B):
+        """Planar hand-over layout of a block at this (batch, level): "quad" when both 3x3x3 convolutions run on the F(4,3) x F(4,3)
+        kernel (variant 3 with quad flags: the 64^3 / 32^3 levels), "oct" when they run on the F(4,3) x F(2,3) kernel (the 16^3
+        level) or on the split-bf16 kernel, None for a level with so few voxels that the plain split-K kernel is faster (16^3 at batch
+        1: it stays channels-last) and for the levels below."""
         c1, c2, _ = blk
         if self.dtype != torch.float32:
-            return False
+            return None
         if self.split3:
-            return c1.w_split is not None and c2.w_split is not None and dim % 16 == 0
-        return _lib.conv3d_variant(B, dim, c1.cin_pad, c1.cout, 3) in (2, 3) and _lib.conv3d_variant(B, dim, c2.cin_pad, c2.cout, 3) in (2, 3)
+            return "oct" if c1.w_split is not None and c2.w_split is not None and dim % 16 == 0 else None
+        var = lambda c, fl: _lib.conv3d_variant(B, dim, c.cin_pad, c.cout, 3, fl)
+        if var(c1, _lib.IN_QUAD) == 3 and var(c2, _lib.IN_QUAD) == 3:
+            return "quad"
+        if var(c1, 0) in (2, 3) and var(c2, 0) in (2, 3):
+            return "oct"
+        return None
 
     def _fork_set(self, B, G):
-        """Levels (0 = G^3 ... 4 = (G/16)^3) whose skip block runs on the side stream.  Default: every level whose launches leave
-        CUs idle - all five at batch 1 (the demo.py case), the levels at or below 16^3-at-batch-8 size otherwise; the full-chip
-        persistent launches of the big levels gain nothing from a second stream (measured)."""
+        """Levels (0 = G^3 ... 4 = (G/16)^3) whose skip block runs on the side stream: ``fork_levels`` if set, else the levels
+        with at most FORK_MAX_VOXELS voxels in the batch (default 0 = none: measured slower, see the constant)."""
         if self.dtype != torch.float32 or self.split3:
             return frozenset()
         if self.fork_levels is not None:
@@ -326,6 +329,9 @@ class V2VProgram:
         return frozenset(k for k in range(5) if B * (G >> k) ** 3 <= FORK_MAX_VOXELS)
 
     def _side(self, main):
+        if self._side_stream is None:      # first use of the (off by default) fork: outside any graph capture thanks to the warm-up forwards
+            self._side_stream = torch.cuda.Stream(device=self.device)
+            self.workspace_side = torch.empty_like(self.workspace)
         return self._side_stream
 
     def _pool(self, x, B, dim, c, x_oct=False):
@@ -333,11 +339,18 @@ class V2VProgram:
         _lib.maxpool3d_2(x, out, B, dim, c, in_octet=x_oct)
         return out
 
-    def _up(self, x, pc, skip, B, dim):
-        """Upsample3DBlock + decoder add (v2v.py:64-67,124-137): relu(bn(convT(x))) + skip."""
+    def _up(self, x, pc, skip, B, dim, out_quad=False):
+        """Upsample3DBlock + decoder add (v2v.py:64-67,124-137): relu(bn(convT(x))) + skip.  ``out_quad``: the output is written
+        quad-planar [B][C/4][2D][2D][2D][4] for a block behind it whose convolutions run on the F(4,3) x F(4,3) kernel."""
         out = self._new(B, dim * 2, pc.cout)
-        _lib.deconv3d_k2s2(x, pc.w, pc.b, skip, out, B, dim, pc.cin_pad, pc.cout, _lib.EPI_RELU | _lib.EPI_RES_POST_RELU)
+        _lib.deconv3d_k2s2(x, pc.w, pc.b, skip, out, B, dim, pc.cin_pad, pc.cout,
+                           _lib.EPI_RELU | _lib.EPI_RES_POST_RELU | (_lib.OUT_QUAD if out_quad else 0))
         return out
+
+    @staticmethod
+    def _up_quad_ok(pc, dim):
+        """Shapes whose transposed convolution has the quad-planar output form (se_deconv3d_k2s2_f32 with SE_OUT_QUAD)."""
+        return dim % 16 == 0 and (pc.cin_pad, pc.cout) in ((64, 32), (128, 64))
 
     # -- the network -------------------------------------------------------------------------
     def run(self, x, B, G, out=None, softargmax=None, scaled=False):
@@ -354,19 +367,20 @@ class V2VProgram:
         if G % 32:
             raise ValueError("volume_size must be a multiple of 32 (five 2x max-pools), got %d" % G)
         x = self._conv(x, self.front0, B, G, _lib.EPI_RELU | (_lib.IN_PLANAR3 if planar3 else 0))
-        # Tensor layouts of the float32 program: a Res3DBlock output that is read only by 2-D Winograd convolutions (as input or as
-        # skip tensor) and by a max-pool is kept octet-planar; what the deconvolutions, the 1x1x1 convolutions and the fused tail
-        # read stays channels-last.  x_oct tracks the layout of the running tensor.
+        # Tensor layouts of the float32 program: a Res3DBlock output that is read only by 2-D Winograd convolutions of the same kernel
+        # family (as input or as skip tensor) and by a max-pool is kept in that family's planar layout (_planar: quad-planar at 64^3 /
+        # 32^3, octet-planar at 16^3); what the deconvolutions, the 1x1x1 convolutions and the fused tail read stays channels-last.
+        # x_lay tracks the layout of the running tensor.
         # A block whose output goes to an encoder max-pool writes the pooled tensor from its last convolution's epilogue when
-        # that convolution runs on the 2-D Winograd kernel (`pooled`); the pool kernel is then not launched.
-        x_oct = False
+        # that convolution runs on a 2-D Winograd kernel (`pooled`); the pool kernel is then not launched.
+        x_lay = None
         pooled = None
         for i, blk in enumerate(self.front_res):
-            ok = self._oct_ok(blk, G, B)
-            if ok and not self.split3 and i == len(self.front_res) - 1:      # (the split-bf16 kernel has no pooled form)
+            kind = self._planar(blk, G, B)
+            if kind and not self.split3 and i == len(self.front_res) - 1:      # (the split-bf16 kernel has no pooled form)
                 pooled = self._new(B, G // 2, blk[1].cout)
-            x = self._res(x, blk, B, G, x_oct=x_oct, out_oct=ok, pool_out=pooled)
-            x_oct = ok
+            x = self._res(x, blk, B, G, x_lay=x_lay, out_planar=bool(kind), pool_out=pooled)
+            x_lay = kind
         # encoder (v2v.py:104-119).  skip_res_k(x) is not read before decoder_upsample_k: the skip blocks of the levels in `fork` are
         # issued on a side stream (event fork behind the producer of x, event join in front of the deconvolution that reads the
         # result) and run beside the encoder / middle / decoder chain, which at small batches leaves most of the chip idle
@@ -386,7 +400,7 @@ class V2VProgram:
                 with torch.cuda.stream(side):
                     self._ws = self.workspace_side
                     try:
-                        sk = self._res(x, self.skip[k], B, dim, x_oct=x_oct, out_oct=False)
+                        sk = self._res(x, self.skip[k], B, dim, x_lay=x_lay)
                     finally:
                         self._ws = self.workspace
                     joins[k] = torch.cuda.Event()
@@ -394,28 +408,37 @@ class V2VProgram:
                 sk.record_stream(main)
                 skips.append(sk)
             else:
-                skips.append(self._res(x, self.skip[k], B, dim, x_oct=x_oct, out_oct=False))    # read by the decoder's deconvolution
-            x = pooled if pooled is not None else self._pool(x, B, dim, x.numel() // (B * dim ** 3), x_oct=x_oct)
+                skips.append(self._res(x, self.skip[k], B, dim, x_lay=x_lay))    # read by the decoder's deconvolution: channels-last
+            if pooled is None and x_lay == "quad":
+                raise RuntimeError("a quad-planar block output is always pooled by its producer")
+            x = pooled if pooled is not None else self._pool(x, B, dim, x.numel() // (B * dim ** 3), x_oct=x_lay == "oct")
             pooled = None
             dim //= 2
-            ok = self._oct_ok(self.enc[k], dim, B)
-            if ok and not self.split3 and k < 4:
+            kind = self._planar(self.enc[k], dim, B)
+            if kind and not self.split3 and k < 4:
                 pooled = self._new(B, dim // 2, self.enc[k][1].cout)
-            x = self._res(x, self.enc[k], B, dim, x_oct=False, out_oct=ok, pool_out=pooled)
-            x_oct = ok
-        if x_oct:    # cannot happen: the deepest levels are too small for the 2-D kernel
-            raise RuntimeError("octet-planar tensor reached the middle block")
+            x = self._res(x, self.enc[k], B, dim, x_lay=None, out_planar=bool(kind), pool_out=pooled)
+            x_lay = kind
+        if x_lay:    # cannot happen: the deepest levels are too small for the 2-D kernels
+            raise RuntimeError("planar tensor reached the middle block")
         x = self._res(x, self.mid, B, dim)
         # decoder (v2v.py:121-137)
+        # A decoder / back block whose convolutions run on the F(4,3) x F(4,3) kernel gets its input quad-planar straight from the
+        # transposed convolution in front of it (round 5; rounds 2-4: channels-last, which kept the block's first convolution on the
+        # F(4,3) x F(2,3) kernel - 0.41 ms against 0.32 for back_layers.0's).
+        x_lay = None
         for k in range(4, -1, -1):
-            x = self._res(x, self.dec[k], B, dim)
+            x = self._res(x, self.dec[k], B, dim, x_lay=x_lay)
             if joins[k] is not None:
                 main.wait_event(joins[k])
-            x = self._up(x, self.up[k], skips[k], B, dim)
+            nxt = self.dec[k - 1] if k > 0 else self.back_res
+            quad = self._planar(nxt, dim * 2, B) == "quad" and self._up_quad_ok(self.up[k], dim) and not self.split3
+            x = self._up(x, self.up[k], skips[k], B, dim, out_quad=quad)
+            x_lay = "quad" if quad else None
             skips[k] = None
             dim *= 2
         # back layers + output (v2v.py:155-161)
-        x = self._res(x, self.back_res, B, G)
+        x = self._res(x, self.back_res, B, G, x_lay=x_lay)
         if out is None:
             out = torch.empty((B, self.cout, G * G * G), device=self.device, dtype=torch.float32)
         if self.cout <= 16:

@@ -48,16 +48,17 @@ def test_pure_host_entry_points():
     assert lib.se_conv3d_f32_algo(128, 32, 32, 3) == 2 and lib.se_conv3d_f32_algo(256, 32, 32, 3) != 2
     assert lib.se_conv3d_f32_algo(256, 8, 32, 3) != 2 and lib.se_conv3d_f32_algo(64, 36, 32, 3) != 2
     # which kernel a launch runs on: 3 = F(4,3) x F(4,3) ping-pong at the 64^3 / 32^3 levels, 2 = F(4,3) x F(2,3) at 16^3; the last
-    # argument carries the launch's layout flags: the ping-pong kernel takes an octet-planar input or < 32 channels-last channels
-    IN_OCT = _lib.IN_OCTET
-    assert lib.se_conv3d_f32_variant(8, 64, 32, 32, 3, IN_OCT) == 3 and lib.se_conv3d_f32_variant(8, 16, 128, 128, 3, IN_OCT) == 2
+    # argument carries the launch's layout flags: the ping-pong kernel takes a QUAD-planar input or < 32 channels-last channels, every
+    # octet-planar launch belongs to the F(4,3) x F(2,3) kernel
+    IN_Q, IN_OCT = _lib.IN_QUAD, _lib.IN_OCTET
+    assert lib.se_conv3d_f32_variant(8, 64, 32, 32, 3, IN_Q) == 3 and lib.se_conv3d_f32_variant(8, 16, 128, 128, 3, IN_OCT) == 2
+    assert lib.se_conv3d_f32_variant(8, 64, 32, 32, 3, IN_OCT) == 2 and lib.se_conv3d_f32_variant(8, 16, 128, 128, 3, IN_Q) == 2
     assert lib.se_conv3d_f32_variant(8, 64, 32, 32, 3, 0) == 2 and lib.se_conv3d_f32_variant(8, 64, 16, 32, 3, 0) == 3
-    assert lib.se_conv3d_f32_variant(8, 64, 33, 16, 7, 0) == 7 and lib.se_conv3d_f32_variant(1, 64, 32, 32, 3, IN_OCT | _lib.OUT_OCTET) == 3
+    assert lib.se_conv3d_f32_variant(8, 64, 33, 16, 7, 0) == 7 and lib.se_conv3d_f32_variant(1, 64, 32, 32, 3, IN_Q | _lib.OUT_QUAD) == 3
+    assert lib.se_conv3d_f32_variant(4, 32, 64, 64, 3, IN_Q) == 3 and lib.se_conv3d_f32_variant(2, 32, 64, 64, 3, IN_Q) == 2
     # <= 4096 voxels in the batch (16^3 at batch 1): the plain call of a 2-D Winograd shape is served by the in-workgroup split-K kernel
     assert lib.se_conv3d_f32_variant(1, 16, 128, 128, 3, 0) == 0 and lib.se_conv3d_f32_variant(2, 16, 128, 128, 3, 0) == 2
     assert lib.se_conv3d_f32_variant(1, 16, 128, 128, 3, IN_OCT) == 2        # ... a call with octet-planar forms keeps the 2-D kernel
-    # split-K workspace contract: the counters flag needs a workspace that can hold them
-    assert lib.se_conv3d_workspace_init(None, 1 << 20, None) == -1 and _lib.WS_COUNTER_ELEMS == 1024
     # soft-argmax partial records: 8 floats per (row, chunk); 256 chunks per row at batch 1 (15 rows), 32 from batch 8 (120 rows) on
     lib.se_softargmax3d_scratch_elems.restype = ctypes.c_longlong
     assert lib.se_softargmax3d_scratch_elems(15) == 15 * 256 * 8 and lib.se_softargmax3d_scratch_elems(30) == 30 * 128 * 8

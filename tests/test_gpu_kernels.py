@@ -315,7 +315,7 @@ def test_conv3d_linearity_full_size():
 # (the 64^3-level shape at B=8, and a ragged voxel count), 1 tile per wave at >= 2 per CU; the others on the grid.z form
 @pytest.mark.parametrize("B,dim,cin,cout,skip", [(2, 4, 128, 128, True), (1, 8, 128, 64, True), (1, 16, 64, 32, False),
                                                   (3, 2, 32, 16, True), (8, 32, 64, 32, True), (4, 34, 64, 32, False),
-                                                  (8, 16, 128, 64, True)])
+                                                  (8, 16, 128, 64, True), (1, 32, 64, 32, True), (32, 16, 128, 64, False)])
 def test_deconv_vs_torch(B, dim, cin, cout, skip):
     seed = cin + cout + dim
     up = nn.ConvTranspose3d(cin, cout, 2, stride=2)
@@ -334,6 +334,16 @@ def test_deconv_vs_torch(B, dim, cin, cout, skip):
     _lib.deconv3d_k2s2(_ndhwc(x).to(DEV), pc.w, pc.b, _ndhwc(sk).to(DEV) if skip else None, out, B, dim, cin, cout,
                        _lib.EPI_RELU | (_lib.EPI_RES_POST_RELU if skip else 0))
     assert float((_ncdhw(out.cpu()) - want).abs().max()) < 2e-5
+    # quad-planar output (SE_OUT_QUAD, round 5: the decoder hands the block behind it whole 16-byte records): the same arithmetic,
+    # the records exchanged across lanes before the store - bit-identical to the channels-last launch
+    if (cin, cout) in ((64, 32), (128, 64)) and dim % 16 == 0:
+        outq = torch.full((B, cout // 4, 2 * dim, 2 * dim, 2 * dim, 4), -7.0, device=DEV)
+        _lib.deconv3d_k2s2(_ndhwc(x).to(DEV), pc.w, pc.b, _ndhwc(sk).to(DEV) if skip else None, outq, B, dim, cin, cout,
+                           _lib.EPI_RELU | (_lib.EPI_RES_POST_RELU if skip else 0) | _lib.OUT_QUAD)
+        assert torch.equal(_unquad(outq), out)
+    else:
+        with pytest.raises(_lib.HipExtensionError):
+            _lib.deconv3d_k2s2(_ndhwc(x).to(DEV), pc.w, pc.b, None, out, B, dim, cin, cout, _lib.EPI_RELU | _lib.OUT_QUAD)
 
 
 def test_maxpool_exact():
@@ -779,6 +789,23 @@ def _unoct(t):      # [B,C/8,D,D,D,8] -> [B,D,D,D,C]
     return t.permute(0, 2, 3, 4, 1, 5).reshape(B, D, D, D, O * 8)
 
 
+def _quad(t):       # [B,D,D,D,C] -> [B,C/4,D,D,D,4]
+    B, D, C = t.shape[0], t.shape[1], t.shape[-1]
+    return t.view(B, D, D, D, C // 4, 4).permute(0, 4, 1, 2, 3, 5).contiguous()
+
+
+def _unquad(t):     # [B,C/4,D,D,D,4] -> [B,D,D,D,C]
+    B, Q, D = t.shape[0], t.shape[1], t.shape[2]
+    return t.permute(0, 2, 3, 4, 1, 5).reshape(B, D, D, D, Q * 4)
+
+
+# planar hand-over layouts of the two 2-D Winograd kernels: (to planar, from planar, record width, IN / OUT / RES flags)
+def _lay(kind):
+    if kind == "quad":      # conv3d_k3_wino44pp_kernel (64^3 / 32^3 levels)
+        return _quad, _unquad, 4, _lib.IN_QUAD, _lib.OUT_QUAD, _lib.RES_QUAD
+    return _oct, _unoct, 8, _lib.IN_OCTET, _lib.OUT_OCTET, _lib.RES_OCTET      # conv3d_k3_wino2d_kernel
+
+
 def test_conv7_front_layer_64_planar3_vs_torch():
     """front_layers.0 at its production size: Conv3d(33, 16, 7) + BN + ReLU (reference network/v2v.py:8-19,147) on 64^3, B=2, the
     triplet-planar input (SE_IN_PLANAR3) -> conv3d_k7_wino67_kernel<true>.  64 = 10 x 6 + 4: the 11th z tile of F(6,7) is ragged,
@@ -853,13 +880,16 @@ def test_conv7_channels_last_16_channels_with_nan_behind_the_tensor():
     assert not bool(outside.any())
 
 
+@pytest.mark.parametrize("kind", ["quad", "oct"])
 @pytest.mark.parametrize("cin", [32, 16])
-def test_conv3d_k3_64_octet_pool_skip_forms_vs_torch(cin):
-    """The dominant kernel at its production size and in its production forms (reference network/v2v.py:21-43, 46-52): Res3DBlock
-    convolutions cin -> 32 on 64^3, B=1, octet-planar in / out / skip tensor (SE_IN_OCTET | SE_OUT_OCTET | SE_RES_OCTET), the pooled
-    epilogue (se_conv3d_pool_f32) and - for the 16 -> 32 block - the fused 1x1x1 skip convolution (se_conv3d_skip16_f32), each
-    against torch-CPU float32 Conv3d + BatchNorm3d (+ skip) + ReLU (+ max_pool3d), 2e-5 of max|y|."""
+def test_conv3d_k3_64_planar_pool_skip_forms_vs_torch(cin, kind):
+    """The dominant kernels at their production size and in their production forms (reference network/v2v.py:21-43, 46-52): Res3DBlock
+    convolutions cin -> 32 on 64^3, B=1, planar in / out / skip tensor, the pooled epilogue (se_conv3d_pool_f32) and - for the 16 -> 32
+    block - the fused 1x1x1 skip convolution (se_conv3d_skip16_f32), each against torch-CPU float32 Conv3d + BatchNorm3d (+ skip) +
+    ReLU (+ max_pool3d), 2e-5 of max|y|.  kind "quad": quad-planar tensors, conv3d_k3_wino44pp_kernel (what the program runs at this
+    level since round 5); "oct": octet-planar tensors, conv3d_k3_wino2d_kernel (the 16^3 level's kernel and the A/B reference)."""
     B, dim, cout = 1, 64, 32
+    to_pl, from_pl, _, IN, OUT, RES = _lay(kind)
     conv, bn = _conv_bn(cin, cout, 3, 640 + cin)
     x = torch.from_numpy(synth.normal(640 + cin, "x", (B, cin, dim, dim, dim)))
     res = torch.from_numpy(synth.normal(640 + cin, "r", (B, cout, dim, dim, dim)))
@@ -868,33 +898,44 @@ def test_conv3d_k3_64_octet_pool_skip_forms_vs_torch(cin):
         want_plain = F.relu(lin)
         want_res = F.relu(lin + res)
     assert _lib.conv3d_algo(dim, cin, cout, 3) == 2
+    assert _lib.conv3d_variant(B, dim, cin, cout, 3, IN | OUT) == (3 if kind == "quad" else 2)
     pc = _PackedConv(conv.to(DEV), bn.to(DEV))
-    x_oct, res_cl = _oct(_ndhwc(x).to(DEV)), _ndhwc(res).to(DEV)
-    res_oct = _oct(res_cl)
-    out_oct = torch.full((B, cout // 8, dim, dim, dim, 8), -77.0, device=DEV)
+    x_pl, res_cl = to_pl(_ndhwc(x).to(DEV)), _ndhwc(res).to(DEV)
+    res_pl = to_pl(res_cl)
+    out_pl = torch.full_like(res_pl, -77.0)
     tol = lambda w: 2e-5 * max(1.0, float(w.abs().max()))
-    # conv1 of a block: octet-planar in / out, ReLU, no skip tensor
-    _lib.conv3d(x_oct, pc.w, pc.b, None, out_oct, B, dim, cin, cin, cout, 3, _lib.EPI_RELU | _lib.IN_OCTET | _lib.OUT_OCTET)
-    e1 = float((_ncdhw(_unoct(out_oct).cpu()) - want_plain).abs().max())
+    # conv1 of a block: planar in / out, ReLU, no skip tensor
+    _lib.conv3d(x_pl, pc.w, pc.b, None, out_pl, B, dim, cin, cin, cout, 3, _lib.EPI_RELU | IN | OUT)
+    e1 = float((_ncdhw(from_pl(out_pl).cpu()) - want_plain).abs().max())
     assert e1 < tol(want_plain), e1
-    # conv2 of a block: + octet-planar skip tensor, ReLU; then the same with the pooled epilogue
-    fl = _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | _lib.IN_OCTET | _lib.OUT_OCTET | _lib.RES_OCTET
-    out_oct.fill_(-77.0)
-    _lib.conv3d(x_oct, pc.w, pc.b, res_oct, out_oct, B, dim, cin, cin, cout, 3, fl)
-    e2 = float((_ncdhw(_unoct(out_oct).cpu()) - want_res).abs().max())
+    # conv2 of a block: + planar skip tensor, ReLU; then the same with the pooled epilogue
+    fl = _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | IN | OUT | RES
+    out_pl.fill_(-77.0)
+    _lib.conv3d(x_pl, pc.w, pc.b, res_pl, out_pl, B, dim, cin, cin, cout, 3, fl)
+    e2 = float((_ncdhw(from_pl(out_pl).cpu()) - want_res).abs().max())
     assert e2 < tol(want_res), e2
+    keep = out_pl.clone()
     pooled = torch.full((B, dim // 2, dim // 2, dim // 2, cout), float("nan"), device=DEV)
-    out_oct.fill_(-77.0)
-    _lib.conv3d(x_oct, pc.w, pc.b, res_oct, out_oct, B, dim, cin, cin, cout, 3, fl, pool_out=pooled)
-    e3 = float((_ncdhw(_unoct(out_oct).cpu()) - want_res).abs().max())
+    out_pl.fill_(-77.0)
+    _lib.conv3d(x_pl, pc.w, pc.b, res_pl, out_pl, B, dim, cin, cin, cout, 3, fl, pool_out=pooled)
+    e3 = float((_ncdhw(from_pl(out_pl).cpu()) - want_res).abs().max())
     e4 = float((_ncdhw(pooled.cpu()) - F.max_pool3d(want_res, 2)).abs().max())
     assert e3 < tol(want_res) and e4 < tol(want_res), (e3, e4)
-    # channels-last input (back_layers.0 takes the deconvolution's channels-last output), channels-last skip tensor and output
+    assert torch.equal(out_pl, keep)                                     # the pooled form leaves the full-resolution output as it was
+    # channels-last skip tensor and output with a planar input (a block's second convolution in front of a deconvolution / the tail)
     out_cl = torch.full((B, dim, dim, dim, cout), -77.0, device=DEV)
+    _lib.conv3d(x_pl, pc.w, pc.b, res_cl, out_cl, B, dim, cin, cin, cout, 3, _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | IN)
+    assert torch.equal(out_cl, from_pl(keep))                            # same arithmetic in every layout
+    # channels-last input (a block's first convolution behind a max-pool or the 7^3 layer), planar output
+    out_pl.fill_(-77.0)
+    _lib.conv3d(_ndhwc(x).to(DEV), pc.w, pc.b, None, out_pl, B, dim, cin, cin, cout, 3, _lib.EPI_RELU | OUT)
+    e5 = float((_ncdhw(from_pl(out_pl).cpu()) - want_plain).abs().max())
+    assert e5 < tol(want_plain), e5
+    # plain channels-last call
     _lib.conv3d(_ndhwc(x).to(DEV), pc.w, pc.b, res_cl, out_cl, B, dim, cin, cin, cout, 3, _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU)
-    e5 = float((_ncdhw(out_cl.cpu()) - want_res).abs().max())
-    assert e5 < tol(want_res), e5
-    msg = f"k3 {cin}->32 @64^3: plain {e1:.2e}, +skip {e2:.2e}, pooled {e3:.2e}/{e4:.2e}, channels-last {e5:.2e}"
+    e6 = float((_ncdhw(out_cl.cpu()) - want_res).abs().max())
+    assert e6 < tol(want_res), e6
+    msg = f"k3 {cin}->32 @64^3 {kind}: plain {e1:.2e}, +skip {e2:.2e}, pooled {e3:.2e}/{e4:.2e}, cl-in planar-out {e5:.2e}, channels-last {e6:.2e}"
     if cin == 32:
         # front_layers.1 (Res3DBlock(16, 32)): second convolution 32 -> 32 with the block's 1x1x1 skip convolution 16 -> 32 fused
         skip, bns = _conv_bn(16, cout, 1, 77)
@@ -904,29 +945,34 @@ def test_conv3d_k3_64_octet_pool_skip_forms_vs_torch(cin):
         ps = _PackedConv(skip.to(DEV), bns.to(DEV))
         scale = (bns.weight / torch.sqrt(bns.running_var + bns.eps)).detach()
         w_skip = (skip.weight.detach().reshape(cout, 16) * scale[:, None]).contiguous().to(DEV)
-        out_oct.fill_(-77.0)
-        _lib.conv3d_skip16(x_oct, pc.w, (pc.b + ps.b).contiguous(), _ndhwc(xs).to(DEV), w_skip, out_oct, B, dim, cin, cout,
-                           _lib.EPI_RELU | _lib.IN_OCTET | _lib.OUT_OCTET)
-        e6 = float((_ncdhw(_unoct(out_oct).cpu()) - want_s).abs().max())
-        assert e6 < tol(want_s), e6
-        msg += f", fused skip16 {e6:.2e}"
+        out_pl.fill_(-77.0)
+        _lib.conv3d_skip16(x_pl, pc.w, (pc.b + ps.b).contiguous(), _ndhwc(xs).to(DEV), w_skip, out_pl, B, dim, cin, cout,
+                           _lib.EPI_RELU | IN | OUT)
+        e7 = float((_ncdhw(from_pl(out_pl).cpu()) - want_s).abs().max())
+        assert e7 < tol(want_s), e7
+        msg += f", fused skip16 {e7:.2e}"
     print(msg)
+    # the two planar layouts do not mix in one launch
+    with pytest.raises(_lib.HipExtensionError):
+        _lib.conv3d(x_pl, pc.w, pc.b, None, out_pl, B, dim, cin, cin, cout, 3, _lib.EPI_RELU | _lib.IN_QUAD | _lib.OUT_OCTET)
 
 
 def test_conv3d_k3_128_vs_torch():
-    """BASELINE configs[4] (128^3 grid): the 3x3x3 32 -> 32 layer at 128^3, B=1, octet-planar forms, against torch-CPU float32."""
+    """BASELINE configs[4] (128^3 grid): the 3x3x3 32 -> 32 layer at 128^3, B=1, quad-planar forms (conv3d_k3_wino44pp_kernel), against
+    torch-CPU float32."""
     B, dim, cin, cout = 1, 128, 32, 32
     conv, bn = _conv_bn(cin, cout, 3, 128)
     x = torch.from_numpy(synth.normal(128, "x", (B, cin, dim, dim, dim)))
     with torch.no_grad():
         want = F.relu(bn(conv(x)) + x)              # Res3DBlock with an identity skip: the block input is the skip tensor
     pc = _PackedConv(conv.to(DEV), bn.to(DEV))
-    x_oct = _oct(_ndhwc(x).to(DEV))
-    out_oct = torch.full((B, cout // 8, dim, dim, dim, 8), -77.0, device=DEV)
-    _lib.conv3d(x_oct, pc.w, pc.b, x_oct, out_oct, B, dim, cin, cin, cout, 3,
-                _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | _lib.IN_OCTET | _lib.OUT_OCTET | _lib.RES_OCTET)
-    err = float((_ncdhw(_unoct(out_oct).cpu()) - want).abs().max())
-    print(f"k3 32->32 @128^3 octet-planar + skip: max error {err:.2e} of max|y| {float(want.abs().max()):.2f}")
+    x_q = _quad(_ndhwc(x).to(DEV))
+    out_q = torch.full((B, cout // 4, dim, dim, dim, 4), -77.0, device=DEV)
+    assert _lib.conv3d_variant(B, dim, cin, cout, 3, _lib.IN_QUAD) == 3
+    _lib.conv3d(x_q, pc.w, pc.b, x_q, out_q, B, dim, cin, cin, cout, 3,
+                _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | _lib.IN_QUAD | _lib.OUT_QUAD | _lib.RES_QUAD)
+    err = float((_ncdhw(_unquad(out_q).cpu()) - want).abs().max())
+    print(f"k3 32->32 @128^3 quad-planar + skip: max error {err:.2e} of max|y| {float(want.abs().max()):.2f}")
     assert err < 2e-5 * max(1.0, float(want.abs().max())), err
 
 
@@ -938,27 +984,27 @@ def test_conv3d_k3_wino44pp_unit_walk_vs_torch(B, dim, cin, cout):
       32 -> 32 @64^3, B=3:  768 units, 3 per workgroup, 256 per sample -> workgroup 85 walks units 255, 256, 257 (two samples);
       64 -> 64 @32^3, B=10: 640 units (2 cout blocks x 320 tiles), 3 per workgroup, 32 tiles per sample -> workgroup 10 crosses a sample
                             boundary (units 30, 31, 32) and workgroup 106 the cout-block boundary (318, 319, 320).
-    Octet-planar in / out, with and without an octet-planar skip tensor (reference network/v2v.py:21-43); 2e-5 of max|y|."""
+    Quad-planar in / out, with and without a quad-planar skip tensor (reference network/v2v.py:21-43); 2e-5 of max|y|."""
     conv, bn = _conv_bn(cin, cout, 3, 4400 + dim)
     x = torch.from_numpy(synth.normal(4400 + dim, "x", (B, cin, dim, dim, dim)))
     with torch.no_grad():
         lin = bn(conv(x))
         want_plain, want_res = F.relu(lin), F.relu(lin + x)          # identity skip: the block input is the skip tensor
-    assert _lib.conv3d_variant(B, dim, cin, cout, 3, _lib.IN_OCTET) == 3
+    assert _lib.conv3d_variant(B, dim, cin, cout, 3, _lib.IN_QUAD) == 3
     units = B * (dim // 16) * (dim // 8) ** 2 * (cout // 32)
     per = -(-units // 256)
     tiles_per_sample = (dim // 16) * (dim // 8) ** 2
     assert per > 1 and tiles_per_sample % per != 0, "no workgroup would cross a sample boundary"
     pc = _PackedConv(conv.to(DEV), bn.to(DEV))
-    x_oct = _oct(_ndhwc(x).to(DEV))
-    out_oct = torch.full((B, cout // 8, dim, dim, dim, 8), -77.0, device=DEV)
+    x_q = _quad(_ndhwc(x).to(DEV))
+    out_q = torch.full((B, cout // 4, dim, dim, dim, 4), -77.0, device=DEV)
     tol = lambda w: 2e-5 * max(1.0, float(w.abs().max()))
-    _lib.conv3d(x_oct, pc.w, pc.b, None, out_oct, B, dim, cin, cin, cout, 3, _lib.EPI_RELU | _lib.IN_OCTET | _lib.OUT_OCTET)
-    e1 = float((_ncdhw(_unoct(out_oct).cpu()) - want_plain).abs().max())
-    out_oct.fill_(-77.0)
-    _lib.conv3d(x_oct, pc.w, pc.b, x_oct, out_oct, B, dim, cin, cin, cout, 3,
-                _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | _lib.IN_OCTET | _lib.OUT_OCTET | _lib.RES_OCTET)
-    got = _ncdhw(_unoct(out_oct).cpu())
+    _lib.conv3d(x_q, pc.w, pc.b, None, out_q, B, dim, cin, cin, cout, 3, _lib.EPI_RELU | _lib.IN_QUAD | _lib.OUT_QUAD)
+    e1 = float((_ncdhw(_unquad(out_q).cpu()) - want_plain).abs().max())
+    out_q.fill_(-77.0)
+    _lib.conv3d(x_q, pc.w, pc.b, x_q, out_q, B, dim, cin, cin, cout, 3,
+                _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | _lib.IN_QUAD | _lib.OUT_QUAD | _lib.RES_QUAD)
+    got = _ncdhw(_unquad(out_q).cpu())
     e2 = float((got - want_res).abs().max())
     per_sample = (got - want_res).abs().amax(dim=(1, 2, 3, 4))
     print(f"wino44pp {cin}->{cout} @{dim}^3 B={B} ({units} units, {per} per workgroup): plain {e1:.2e}, +skip {e2:.2e}; per sample "
@@ -974,11 +1020,12 @@ def test_wino44pp_and_wino67_repeat_launches_bit_identical():
     B, dim = 8, 64
     conv, bn = _conv_bn(32, 32, 3, 91)
     pc = _PackedConv(conv.to(DEV), bn.to(DEV))
-    x = torch.randn(B, 4, dim, dim, dim, 8, device=DEV)
-    res = torch.randn(B, 4, dim, dim, dim, 8, device=DEV)
+    x = torch.randn(B, 8, dim, dim, dim, 4, device=DEV)
+    res = torch.randn(B, 8, dim, dim, dim, 4, device=DEV)
     out = torch.empty_like(x)
-    for flags, r in ((_lib.EPI_RELU | _lib.IN_OCTET | _lib.OUT_OCTET, None),
-                     (_lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | _lib.IN_OCTET | _lib.OUT_OCTET | _lib.RES_OCTET, res)):
+    assert _lib.conv3d_variant(B, dim, 32, 32, 3, _lib.IN_QUAD) == 3
+    for flags, r in ((_lib.EPI_RELU | _lib.IN_QUAD | _lib.OUT_QUAD, None),
+                     (_lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | _lib.IN_QUAD | _lib.OUT_QUAD | _lib.RES_QUAD, res)):
         first = None
         for i in range(40):
             out.fill_(float(i))
