@@ -417,15 +417,17 @@ __global__ __launch_bounds__(256) void deconv3d_k2s2_kernel(ConvArgs a) {
                 const int oz = 2 * vz[m] + (sub >> 2), oy = 2 * vy[m] + ((sub >> 1) & 1), ox0 = 2 * (vx[m] - vl) + vl;
 #pragma unroll
                 for (int n = 0; n < N_T; ++n) {
-                    f32x4 ra, rb;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int e0 = __builtin_bit_cast(int, val[0][m][n][c]), e1 = __builtin_bit_cast(int, val[1][m][n][c]);
-                        const int a0 = __builtin_amdgcn_ds_bpermute(src_a, e0), a1 = __builtin_amdgcn_ds_bpermute(src_a, e1);
-                        const int b0 = __builtin_amdgcn_ds_bpermute(src_b, e0), b1 = __builtin_amdgcn_ds_bpermute(src_b, e1);
-                        ra[c] = __builtin_bit_cast(float, odd ? a1 : a0);
-                        rb[c] = __builtin_bit_cast(float, odd ? b1 : b0);
-                    }
+                    // (component by component, written out: with a `for (c)` loop over the vector elements hipcc 7.2 permuted only
+                    // element 0 and splatted it over the record - disassembly, round 5)
+                    auto pull = [&](int src, float e) {
+                        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, e)));
+                    };
+                    const f32x4 v0 = val[0][m][n], v1 = val[1][m][n];
+                    const f32x4 a0 = {pull(src_a, v0.x), pull(src_a, v0.y), pull(src_a, v0.z), pull(src_a, v0.w)};
+                    const f32x4 a1 = {pull(src_a, v1.x), pull(src_a, v1.y), pull(src_a, v1.z), pull(src_a, v1.w)};
+                    const f32x4 b0 = {pull(src_b, v0.x), pull(src_b, v0.y), pull(src_b, v0.z), pull(src_b, v0.w)};
+                    const f32x4 b1 = {pull(src_b, v1.x), pull(src_b, v1.y), pull(src_b, v1.z), pull(src_b, v1.w)};
+                    const f32x4 ra = odd ? a1 : a0, rb = odd ? b1 : b0;
                     float* o = a.out + (((((long long)vb[m] * (a.cout >> 2) + n * 4 + h) * odim + oz) * odim + oy) * odim + ox0) * 4;
                     *reinterpret_cast<f32x4*>(o) = ra;
                     *reinterpret_cast<f32x4*>(o + 64) = rb;

@@ -340,7 +340,11 @@ def test_deconv_vs_torch(B, dim, cin, cout, skip):
         outq = torch.full((B, cout // 4, 2 * dim, 2 * dim, 2 * dim, 4), -7.0, device=DEV)
         _lib.deconv3d_k2s2(_ndhwc(x).to(DEV), pc.w, pc.b, _ndhwc(sk).to(DEV) if skip else None, outq, B, dim, cin, cout,
                            _lib.EPI_RELU | (_lib.EPI_RES_POST_RELU if skip else 0) | _lib.OUT_QUAD)
-        assert torch.equal(_unquad(outq), out)
+        # (bit-identical where the channels-last launch runs the same kernel; the small volumes' channels-last form is the grid.z kernel,
+        # whose channel groups are summed in another order)
+        same_kernel = (B * dim ** 3 + 63) // 64 >= 512
+        assert torch.equal(_unquad(outq), out) if same_kernel else float((_unquad(outq) - out).abs().max()) < 1e-5
+        assert float((_ncdhw(_unquad(outq).cpu()) - want).abs().max()) < 2e-5
     else:
         with pytest.raises(_lib.HipExtensionError):
             _lib.deconv3d_k2s2(_ndhwc(x).to(DEV), pc.w, pc.b, None, out, B, dim, cin, cout, _lib.EPI_RELU | _lib.OUT_QUAD)

@@ -71,6 +71,7 @@ def run(form_z, form_y, chunk, per_item, n_tiles, seed=0, cin=33):
             V = np.einsum("qy,cxpy->cxpq", BTy.astype(f32), V).astype(f32)
         out = np.zeros((mz, my), dtype=f32)
         acc = None
+        hyb = None
         for c0 in range(0, cin, chunk):
             for c in range(c0, min(c0 + chunk, cin)):
                 for x in range(7):
@@ -81,13 +82,19 @@ def run(form_z, form_y, chunk, per_item, n_tiles, seed=0, cin=33):
                         for ky in range(7):                            # direct along y: dy joins the accumulation chain
                             term = U[c, x, :, ky] * V[c, x, :, ky]
                             acc = term if acc is None else (acc + term).astype(f32)
-            if per_item:
+            if per_item == "z":           # hybrid: A^T along z per item (in-wave), the xi_y domain sums persist, A^T along y once per tile
+                o = (ATz.astype(f32) @ acc.reshape(nz, -1)).astype(f32)
+                hyb = o if hyb is None else (hyb + o).astype(f32)
+                acc = None
+            elif per_item:
                 o = (ATz.astype(f32) @ acc.reshape(nz, -1)).astype(f32)
                 if form_y:
                     o = (o @ ATy.astype(f32).T).astype(f32)
                 out = (out + o.reshape(mz, my)).astype(f32)
                 acc = None
-        if not per_item:
+        if per_item == "z":
+            out = (hyb @ ATy.astype(f32).T).astype(f32)
+        elif not per_item:
             o = (ATz.astype(f32) @ acc.reshape(nz, -1)).astype(f32)
             if form_y:
                 o = (o @ ATy.astype(f32).T).astype(f32)
@@ -106,6 +113,7 @@ def main():
             ("F(6,7) z, direct y, A^T per tile", "F(6,7)", None, 3, False),
             ("F(6,7) z x F(2,7) y, A^T per item", "F(6,7)", "F(2,7)", 2, True),
             ("F(6,7) z x F(2,7) y, A^T per tile", "F(6,7)", "F(2,7)", 2, False),
+            ("F(6,7) z x F(2,7) y, A^T_z per item, A^T_y per tile", "F(6,7)", "F(2,7)", 2, "z"),
             ("F(4,7) z x F(4,7) y, A^T per item", "F(4,7)", "F(4,7)", 2, True),
             ("F(4,7) z x F(4,7) y, A^T per tile", "F(4,7)", "F(4,7)", 2, False),
             ("F(6,7) z x F(4,7) y, A^T per item", "F(6,7)", "F(4,7)", 1, True),
@@ -114,7 +122,7 @@ def main():
     print(f"float32 error / max|y| over {a.tiles} random tiles (33 channels x 7 dx x 7 x 7 taps; kernel-test bound: 2e-5)")
     for name, fz, fy, ch, per in rows:
         mx, mn = run(fz, fy, ch, per, a.tiles)
-        print(f"  {name:38s} chunk {ch}: max {mx:.2e}  mean {mn:.2e}")
+        print(f"  {name:52s} chunk {ch}: max {mx:.2e}  mean {mn:.2e}")
 
 
 if __name__ == "__main__":
