@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0
 # algorithmic work of V2V + soft-argmax per frame at 64^3 / 128^3, fp32
 V2V_GFLOP_PER_FRAME = {64: 299.1, 128: 2393.0}
 V2V_GB_PER_FRAME = {64: 1.372, 128: 10.98}
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
 JOINT_TOL = 1e-3               # BASELINE.json north_star: joints within 1e-3 m of the reference's CPU forward
 # se_conv3d_f32_algo() -> (kernel name, executed MFMA FLOP / direct-convolution FLOP)
 K3_ALGOS = {

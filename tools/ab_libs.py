@@ -39,7 +39,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--octet", type=int, default=3, help="2-D Winograd shapes: 1 IN_OCTET, 2 OUT_OCTET, 3 both, 0 channels-last")
     ap.add_argument("--no-res", action="store_true")
-    ap.add_argument("--res-octet", action="store_true", help="2-D Winograd shapes: the skip tensor is read octet-planar (SE_RES_OCTET)")
+    ap.add_argument("--res-octet", action="store_true", help="2-D Winograd shapes: the skip tensor is read in the planar layout too (SE_RES_OCTET / SE_RES_QUAD)")
+    ap.add_argument("--layout", default="quad", choices=["quad", "oct"],
+                    help="planar layout --octet's bits select: quad-planar (F(4,3) x F(4,3) kernel, the default since round 5) or octet-planar (F(4,3) x F(2,3))")
     ap.add_argument("--planar3", action="store_true", help="7^3 shapes: triplet-planar input (SE_IN_PLANAR3)")
     args = ap.parse_args()
     dev = "cuda:0"
@@ -76,9 +78,12 @@ def main():
         if k == 7 and args.planar3:
             flags |= _lib.IN_PLANAR3
         if k == 3 and libs[0].se_conv3d_f32_algo(dim, cin_pad, cout, 3) == 2:
-            flags |= (_lib.IN_OCTET if args.octet & 1 else 0) | (_lib.OUT_OCTET if args.octet & 2 else 0)
+            IN, OUT, RES = (_lib.IN_QUAD, _lib.OUT_QUAD, _lib.RES_QUAD) if args.layout == "quad" else (_lib.IN_OCTET, _lib.OUT_OCTET, _lib.RES_OCTET)
+            if args.layout == "quad" and libs[0].se_conv3d_f32_variant(B, dim, cin_pad, cout, 3, IN) != 3:
+                IN, OUT, RES = _lib.IN_OCTET, _lib.OUT_OCTET, _lib.RES_OCTET          # (levels the F(4,3) x F(4,3) kernel does not take)
+            flags |= (IN if args.octet & 1 else 0) | (OUT if args.octet & 2 else 0)
             if args.res_octet and not no_res:
-                flags |= _lib.RES_OCTET
+                flags |= RES
         outs = [torch.empty(B, dim, dim, dim, cout, device=dev) for _ in libs]
         times = [[] for _ in libs]
         for r in range(args.rounds + 2):

@@ -27,7 +27,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-TAG = "r04"
+TAG = "r05"
 PASSES = [
     ["FETCH_SIZE"],
     ["WRITE_SIZE"],
