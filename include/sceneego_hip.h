@@ -170,15 +170,17 @@ int se_pointwise_chain3_f32(const float* in, const float* wpack1, const float* b
  * before and, while still in registers, reduced to the per-chunk partial records in `scratch`
  * (se_softargmax3d_scratch_elems(batch * cout3) floats).  `coord` = [dim^3][3] voxel-centre coordinates.  Finish with
  * se_softargmax3d_finish_f32(out, scratch, ...).  Replaces the back_layers / output_layer chain of network/v2v.py:155-161
- * together with the first half of utils/op.py:83-96. */
+ * together with the first half of utils/op.py:83-96.  flags: 0, or SE_IN_QUAD: `in` is quad-planar [B][8][dim^3][4] (what
+ * back_layers.0's last convolution writes with SE_OUT_QUAD). */
 int se_pointwise_chain3_softargmax_f32(const float* in, const float* wpack1, const float* bpack1, const float* wpack2,
                                        const float* bpack2, const float* wpack3, const float* bpack3, float* out,
-                                       const float* coord, float* scratch, int batch, int dim, int cout3, void* stream);
+                                       const float* coord, float* scratch, int batch, int dim, int cout3, int flags, void* stream);
 
 /* ConvTranspose3d(k=2, s=2) + folded BN + ReLU (+ skip).  Replaces Upsample3DBlock and the decoder
  * adds (network/v2v.py:55-67,124-137).  in [B][D]^3[cin] -> out [B][2D]^3[cout]; residual [B][2D]^3[cout] (channels-last).
  * flags: SE_EPI_RELU, SE_EPI_RES_PRE_RELU / SE_EPI_RES_POST_RELU, and SE_OUT_QUAD (cin -> cout = 64 -> 32 or 128 -> 64, D % 16 == 0
- * only, else SE_ERR_BAD_ARG): `out` is written quad-planar [B][cout/4][2D][2D][2D][4], the input layout of the 3x3x3 kernel behind it. */
+ * only, else SE_ERR_BAD_ARG): `out` is written quad-planar [B][cout/4][2D][2D][2D][4], the input layout of the 3x3x3 kernel behind it;
+ * SE_RES_QUAD (with SE_OUT_QUAD and SE_EPI_RES_POST_RELU only): `residual` is quad-planar [B][cout/4][2D][2D][2D][4] too. */
 int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
                          float* out, int batch, int dim, int cin, int cout, int flags, void* stream);
 

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -54,7 +54,7 @@ SIGNATURES = {
     "se_softargmax3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "se_softargmax3d_scratch_elems": (_ll, [_i]),
     "se_softargmax3d_finish_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "se_pointwise_chain3_softargmax_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "se_pointwise_chain3_softargmax_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_conv3d_pack_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_packed_elems_bf16": (_ll, [_i, _i, _i, _i]),
     "se_conv3d_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -439,12 +439,13 @@ def conv3d_skip16(inp, wpack, bpack_sum, skip_in, skip_w, out, batch, dim, cin, 
                                            dim, cin, cout, flags, _stream()), "se_conv3d_skip16_f32")
 
 
-def pointwise_chain3(inp, pc1, pc2, pc3, out, batch, dim, softargmax=None):
+def pointwise_chain3(inp, pc1, pc2, pc3, out, batch, dim, softargmax=None, in_quad=False):
     """back_layers.1 -> back_layers.2 -> output_layer in one launch; pc* are packed 1x1x1 convs (32->32, 32->32, 32->J).
     ``softargmax`` = (coord [dim^3, 3], scratch): float32 only - the launch also writes pass 1 of the soft-argmax (softmax mode) into
-    ``scratch``; finish with softargmax3d_finish."""
+    ``scratch``; finish with softargmax3d_finish.  ``in_quad`` (that form only): ``inp`` is quad-planar [B][8][dim^3][4]."""
     require_hip(inp, out)
     assert out.dtype == torch.float32
+    assert not in_quad or softargmax is not None
     if softargmax is not None:
         coord, scratch = softargmax
         require_hip(coord, scratch)
@@ -453,7 +454,7 @@ def pointwise_chain3(inp, pc1, pc2, pc3, out, batch, dim, softargmax=None):
         with _timed(("tail", 1, 32, pc3.cout, dim)):
             _check(load().se_pointwise_chain3_softargmax_f32(_ptr(inp), _ptr(pc1.w), _ptr(pc1.b), _ptr(pc2.w), _ptr(pc2.b), _ptr(pc3.w),
                                                              _ptr(pc3.b), _ptr(out), _ptr(coord), _ptr(scratch), batch, dim, pc3.cout,
-                                                             _stream()), "se_pointwise_chain3_softargmax_f32")
+                                                             IN_QUAD if in_quad else 0, _stream()), "se_pointwise_chain3_softargmax_f32")
         return
     fn = load().se_pointwise_chain3_bf16 if inp.dtype == torch.bfloat16 else load().se_pointwise_chain3_f32
     with _timed(("tail" + _tag(inp), 1, 32, pc3.cout, dim)):

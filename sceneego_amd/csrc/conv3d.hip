@@ -320,7 +320,10 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(ConvArgs a) {
 // but the records of ONE x parity are 32 bytes apart (round 2 measured such half-line stores at 0.147 -> 0.229 ms for the octet-planar
 // form); here both parities of a (z, y) sub-position are computed first and exchanged across lanes (ds_bpermute: lane l takes voxel
 // l >> 1, parity l & 1) so that a store instruction writes 16 consecutive records = 256 contiguous bytes per cout quad.
-template <int CGS, int N_T, int M_T, bool OUTQ>
+// RESQ (with OUTQ, SE_RES_QUAD; SE_EPI_RES_POST_RELU only): the skip tensor is quad-planar as well and is added BEHIND the exchange, where
+// a lane holds the record it stores - the skip read is then the same 256 contiguous bytes per 16 lanes as the store (the channels-last
+// skip read of a sub-position is 64-byte pieces at a 256-byte stride), and the block that produced the skip tensor writes whole records.
+template <int CGS, int N_T, int M_T, bool OUTQ, bool RESQ = false>
 __global__ __launch_bounds__(256) void deconv3d_k2s2_kernel(ConvArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256) void deconv3d_k2s2_kernel(ConvArgs a) {
     const long long ovox_per_b = (long long)odim * odim * odim;
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack) + lane;
     const bool relu = a.flags & SE_EPI_RELU;
-    const bool res_pre = (a.flags & SE_EPI_RES_PRE_RELU) && a.res, res_post = (a.flags & SE_EPI_RES_POST_RELU) && a.res;
+    const bool res_pre = !RESQ && (a.flags & SE_EPI_RES_PRE_RELU) && a.res, res_post = !RESQ && (a.flags & SE_EPI_RES_POST_RELU) && a.res;
     f32x4 bias[N_T];
 #pragma unroll
     for (int n = 0; n < N_T; ++n) bias[n] = *reinterpret_cast<const f32x4*>(a.bpack + n * 16 + 4 * h);
@@ -427,8 +430,13 @@ __global__ __launch_bounds__(256) void deconv3d_k2s2_kernel(ConvArgs a) {
                     const f32x4 a1 = {pull(src_a, v1.x), pull(src_a, v1.y), pull(src_a, v1.z), pull(src_a, v1.w)};
                     const f32x4 b0 = {pull(src_b, v0.x), pull(src_b, v0.y), pull(src_b, v0.z), pull(src_b, v0.w)};
                     const f32x4 b1 = {pull(src_b, v1.x), pull(src_b, v1.y), pull(src_b, v1.z), pull(src_b, v1.w)};
-                    const f32x4 ra = odd ? a1 : a0, rb = odd ? b1 : b0;
-                    float* o = a.out + (((((long long)vb[m] * (a.cout >> 2) + n * 4 + h) * odim + oz) * odim + oy) * odim + ox0) * 4;
+                    f32x4 ra = odd ? a1 : a0, rb = odd ? b1 : b0;
+                    const long long qo = (((((long long)vb[m] * (a.cout >> 2) + n * 4 + h) * odim + oz) * odim + oy) * odim + ox0) * 4;
+                    if constexpr (RESQ) {       // quad-planar skip tensor: the records this lane stores
+                        ra += *reinterpret_cast<const f32x4*>(a.res + qo);
+                        rb += *reinterpret_cast<const f32x4*>(a.res + qo + 64);
+                    }
+                    float* o = a.out + qo;
                     *reinterpret_cast<f32x4*>(o) = ra;
                     *reinterpret_cast<f32x4*>(o + 64) = rb;
                 }
@@ -739,7 +747,7 @@ __global__ __launch_bounds__(PW_SA_WAVES * 64) void pointwise_chain3_sa_kernel(c
                                                                   const float* __restrict__ b2, const float* __restrict__ w3,
                                                                   const float* __restrict__ b3, float* __restrict__ out,
                                                                   const float* __restrict__ coord, float* __restrict__ scratch,
-                                                                  int vox_per_b, int chunk, int cout3, int splits) {
+                                                                  int vox_per_b, int chunk, int cout3, int splits, int in_quad) {
     extern __shared__ __attribute__((aligned(16))) float pw_sa_lds[];
     float (*red)[64][20] = reinterpret_cast<float (*)[64][20]>(pw_sa_lds);        // [PW_SA_WAVES][64][20]
     const int lane = threadIdx.x & 63;
@@ -751,6 +759,10 @@ __global__ __launch_bounds__(PW_SA_WAVES * 64) void pointwise_chain3_sa_kernel(c
     const f32x4* W2 = reinterpret_cast<const f32x4*>(w2) + lane;
     const f32x4* W3 = reinterpret_cast<const f32x4*>(w3) + lane;
     const float* inb = in + (long long)b * vox_per_b * 32;
+    // B fragment of channel group cg: this lane's 4 channels cg * 16 + 4 h ..: channels-last record n, or (round 5, SE_IN_QUAD) record n
+    // of quad plane cg * 4 + h - 16 lanes read 256 contiguous bytes either way
+    const long long x_str = in_quad ? 4 : 32, x_cg = in_quad ? 4LL * vox_per_b * 4 : 16;
+    const float* inl = inb + (in_quad ? (long long)h * vox_per_b * 4 : 4 * h);
     float m[4], l[4], sx[4], sy[4], sz[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = sx[r] = sy[r] = sz[r] = 0.f; }
@@ -759,7 +771,7 @@ __global__ __launch_bounds__(PW_SA_WAVES * 64) void pointwise_chain3_sa_kernel(c
         const int n0 = v0 + wave * 16 + vl;
 #pragma unroll
         for (int cg = 0; cg < 2; ++cg)
-            xn[cg] = n0 < v1 ? *reinterpret_cast<const f32x4*>(inb + (long long)n0 * 32 + cg * 16 + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            xn[cg] = n0 < v1 ? *reinterpret_cast<const f32x4*>(inl + n0 * x_str + cg * x_cg) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     for (int t0 = v0 + wave * 16; t0 < v1; t0 += PW_SA_WAVES * 16) {
         const int n = t0 + vl;
@@ -770,7 +782,7 @@ __global__ __launch_bounds__(PW_SA_WAVES * 64) void pointwise_chain3_sa_kernel(c
             const int nn = n + PW_SA_WAVES * 16;
 #pragma unroll
             for (int cg = 0; cg < 2; ++cg)
-                xn[cg] = nn < v1 ? *reinterpret_cast<const f32x4*>(inb + (long long)nn * 32 + cg * 16 + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                xn[cg] = nn < v1 ? *reinterpret_cast<const f32x4*>(inl + nn * x_str + cg * x_cg) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         float cx = 0.f, cy = 0.f, cz = 0.f;
         if (ok) { cx = coord[(size_t)n * 3]; cy = coord[(size_t)n * 3 + 1]; cz = coord[(size_t)n * 3 + 2]; }
@@ -911,7 +923,7 @@ int launch_direct(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int se_abi_version(void) { return 12; }
+extern "C" int se_abi_version(void) { return 13; }
 
 // Mirrors the dispatch of se_conv3d_f32 -> se_conv3d_tiled_try -> se_conv3d_wino_try / se_conv3d_k7_wino_try for the
 // default channels-last call (no SE_EPI_OUT_PLANAR / SE_EPI_RES_POST_RELU flags).
@@ -1121,12 +1133,14 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
     if (batch <= 0 || dim <= 0 || cin <= 0 || (cin & 15) || cout <= 0 || (cout & 15)) return SE_ERR_BAD_ARG;
     if (flags & SE_EPI_OUT_PLANAR) return SE_ERR_BAD_ARG;
     if ((flags & SE_EPI_RES_PRE_RELU) && (flags & SE_EPI_RES_POST_RELU)) return SE_ERR_BAD_ARG;
-    if (flags & (SE_LAYOUT_OCTET_BITS | SE_IN_QUAD | SE_RES_QUAD)) return SE_ERR_BAD_ARG;
-    const bool outq = flags & SE_OUT_QUAD;
+    if (flags & (SE_LAYOUT_OCTET_BITS | SE_IN_QUAD)) return SE_ERR_BAD_ARG;
+    const bool outq = flags & SE_OUT_QUAD, resq = flags & SE_RES_QUAD;
+    // a quad-planar skip tensor: only with the quad-planar output, added behind the ReLU (what the decoder does)
+    if (resq && (!outq || !residual || !(flags & SE_EPI_RES_POST_RELU))) return SE_ERR_BAD_ARG;
     ConvArgs a;
     a.in = in; a.wpack = wpack; a.bpack = bpack; a.res = residual; a.out = out;
     a.total_vox = (long long)batch * dim * dim * dim;
-    a.dim = dim; a.cin = cin; a.cin_pad = cin; a.cout = cout; a.nts = cout / 16; a.flags = flags & ~SE_OUT_QUAD;
+    a.dim = dim; a.cin = cin; a.cin_pad = cin; a.cout = cout; a.nts = cout / 16; a.flags = flags & ~(SE_OUT_QUAD | SE_RES_QUAD);
     a.wpack_b = nullptr;
     a.wpack_d = nullptr;
     a.wpack_e = nullptr;
@@ -1150,10 +1164,16 @@ extern "C" int se_deconv3d_k2s2_f32(const float* in, const float* wpack, const f
         // quad-planar output (SE_OUT_QUAD): the 64 -> 32 layer in front of back_layers.0, volumes whose x rows hold whole 16-voxel tiles
         if ((dim & 15) || !((cin == 64 && cout == 32) || (cin == 128 && cout == 64))) return SE_ERR_BAD_ARG;
         const bool two = g2 >= 4u * (unsigned)se_num_cus();
-        if (cin == 64 && two) hipLaunchKernelGGL((deconv3d_k2s2_kernel<4, 2, 2, true>), dim3(g2), dim3(256), 0, se_stream(stream), a);
-        else if (cin == 64) hipLaunchKernelGGL((deconv3d_k2s2_kernel<4, 2, 1, true>), dim3(g1), dim3(256), 0, se_stream(stream), a);
-        else if (two) hipLaunchKernelGGL((deconv3d_k2s2_kernel<8, 4, 2, true>), dim3(g2), dim3(256), 0, se_stream(stream), a);
-        else hipLaunchKernelGGL((deconv3d_k2s2_kernel<8, 4, 1, true>), dim3(g1), dim3(256), 0, se_stream(stream), a);
+#define SE_DECONVQ(CG, NT, MT, G)                                                                                                      \
+        do {                                                                                                                           \
+            if (resq) hipLaunchKernelGGL((deconv3d_k2s2_kernel<CG, NT, MT, true, true>), dim3(G), dim3(256), 0, se_stream(stream), a); \
+            else hipLaunchKernelGGL((deconv3d_k2s2_kernel<CG, NT, MT, true, false>), dim3(G), dim3(256), 0, se_stream(stream), a);     \
+        } while (0)
+        if (cin == 64 && two) SE_DECONVQ(4, 2, 2, g2);
+        else if (cin == 64) SE_DECONVQ(4, 2, 1, g1);
+        else if (two) SE_DECONVQ(8, 4, 2, g2);
+        else SE_DECONVQ(8, 4, 1, g1);
+#undef SE_DECONVQ
         SE_CHECK_LAUNCH();
         return 0;
     }
@@ -1196,8 +1216,8 @@ extern "C" int se_pointwise_chain3_f32(const float* in, const float* wpack1, con
 extern "C" int se_pointwise_chain3_softargmax_f32(const float* in, const float* wpack1, const float* bpack1, const float* wpack2,
                                                   const float* bpack2, const float* wpack3, const float* bpack3, float* out,
                                                   const float* coord, float* scratch, int batch, int dim, int cout3,
-                                                  void* stream) {
-    if (batch <= 0 || dim <= 0 || cout3 <= 0 || cout3 > 16 || !coord || !scratch) return SE_ERR_BAD_ARG;
+                                                  int flags, void* stream) {
+    if (batch <= 0 || dim <= 0 || cout3 <= 0 || cout3 > 16 || !coord || !scratch || (flags & ~SE_IN_QUAD)) return SE_ERR_BAD_ARG;
     const long long vox_per_b = (long long)dim * dim * dim;
     if (vox_per_b >= (1LL << 31) || (vox_per_b & 3)) return SE_ERR_BAD_ARG;
     const int splits = se_sa_splits(batch * cout3);                                               // as softargmax.hip
@@ -1206,7 +1226,7 @@ extern "C" int se_pointwise_chain3_softargmax_f32(const float* in, const float* 
     constexpr int LDS = PW_SA_WAVES * 64 * 20 * 4;
     SE_ENSURE_LDS(pointwise_chain3_sa_kernel, LDS);
     hipLaunchKernelGGL(pointwise_chain3_sa_kernel, dim3(splits, batch), dim3(PW_SA_WAVES * 64), LDS, se_stream(stream), in, wpack1, bpack1,
-                       wpack2, bpack2, wpack3, bpack3, out, coord, scratch, (int)vox_per_b, chunk, cout3, splits);
+                       wpack2, bpack2, wpack3, bpack3, out, coord, scratch, (int)vox_per_b, chunk, cout3, splits, (flags & SE_IN_QUAD) ? 1 : 0);
     SE_CHECK_LAUNCH();
     return 0;
 }

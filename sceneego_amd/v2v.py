@@ -339,12 +339,13 @@ class V2VProgram:
         _lib.maxpool3d_2(x, out, B, dim, c, in_octet=x_oct)
         return out
 
-    def _up(self, x, pc, skip, B, dim, out_quad=False):
+    def _up(self, x, pc, skip, B, dim, out_quad=False, res_quad=False):
         """Upsample3DBlock + decoder add (v2v.py:64-67,124-137): relu(bn(convT(x))) + skip.  ``out_quad``: the output is written
-        quad-planar [B][C/4][2D][2D][2D][4] for a block behind it whose convolutions run on the F(4,3) x F(4,3) kernel."""
+        quad-planar [B][C/4][2D][2D][2D][4] for a block behind it whose convolutions run on the F(4,3) x F(4,3) kernel;
+        ``res_quad`` (with it): ``skip`` is quad-planar too (the skip block wrote whole records)."""
         out = self._new(B, dim * 2, pc.cout)
         _lib.deconv3d_k2s2(x, pc.w, pc.b, skip, out, B, dim, pc.cin_pad, pc.cout,
-                           _lib.EPI_RELU | _lib.EPI_RES_POST_RELU | (_lib.OUT_QUAD if out_quad else 0))
+                           _lib.EPI_RELU | _lib.EPI_RES_POST_RELU | (_lib.OUT_QUAD if out_quad else 0) | (_lib.RES_QUAD if res_quad else 0))
         return out
 
     @staticmethod
@@ -385,6 +386,14 @@ class V2VProgram:
         # issued on a side stream (event fork behind the producer of x, event join in front of the deconvolution that reads the
         # result) and run beside the encoder / middle / decoder chain, which at small batches leaves most of the chip idle
         # (16^3 at batch 1: 32 work units on 256 CUs).  Inside a hipGraph capture the fork and the joins become graph edges.
+        # Which transposed convolutions write (and read their skip tensor) quad-planar: those in front of a block whose convolutions
+        # run on the F(4,3) x F(4,3) kernel (decoder_res1 at 32^3, back_layers.0 at 64^3); the skip block of that level then writes its
+        # output quad-planar as well - whole 16-byte records instead of 64 of every 128 bytes of a channels-last record.
+        up_quad = [False] * 5
+        for k in range(5):
+            nxt = self.dec[k - 1] if k > 0 else self.back_res
+            up_quad[k] = (not self.split3 and self._planar(nxt, G >> k, B) == "quad" and self._up_quad_ok(self.up[k], G >> (k + 1))
+                          and self._planar(self.skip[k], G >> k, B) == "quad")
         skips = []
         joins = [None] * 5
         fork = self._fork_set(B, G)
@@ -400,7 +409,7 @@ class V2VProgram:
                 with torch.cuda.stream(side):
                     self._ws = self.workspace_side
                     try:
-                        sk = self._res(x, self.skip[k], B, dim, x_lay=x_lay)
+                        sk = self._res(x, self.skip[k], B, dim, x_lay=x_lay, out_planar=up_quad[k])
                     finally:
                         self._ws = self.workspace
                     joins[k] = torch.cuda.Event()
@@ -408,7 +417,7 @@ class V2VProgram:
                 sk.record_stream(main)
                 skips.append(sk)
             else:
-                skips.append(self._res(x, self.skip[k], B, dim, x_lay=x_lay))    # read by the decoder's deconvolution: channels-last
+                skips.append(self._res(x, self.skip[k], B, dim, x_lay=x_lay, out_planar=up_quad[k]))    # read by the decoder's deconvolution
             if pooled is None and x_lay == "quad":
                 raise RuntimeError("a quad-planar block output is always pooled by its producer")
             x = pooled if pooled is not None else self._pool(x, B, dim, x.numel() // (B * dim ** 3), x_oct=x_lay == "oct")
@@ -431,20 +440,22 @@ class V2VProgram:
             x = self._res(x, self.dec[k], B, dim, x_lay=x_lay)
             if joins[k] is not None:
                 main.wait_event(joins[k])
-            nxt = self.dec[k - 1] if k > 0 else self.back_res
-            quad = self._planar(nxt, dim * 2, B) == "quad" and self._up_quad_ok(self.up[k], dim) and not self.split3
-            x = self._up(x, self.up[k], skips[k], B, dim, out_quad=quad)
+            quad = up_quad[k]
+            x = self._up(x, self.up[k], skips[k], B, dim, out_quad=quad, res_quad=quad)
             x_lay = "quad" if quad else None
             skips[k] = None
             dim *= 2
         # back layers + output (v2v.py:155-161)
-        x = self._res(x, self.back_res, B, G, x_lay=x_lay)
+        # the fused tail with the soft-argmax pass reads a quad-planar tensor as well: back_layers.0 then writes whole records
+        sa = softargmax if self.dtype == torch.float32 else None
+        tail_quad = self.cout <= 16 and sa is not None and not self.split3 and self._planar(self.back_res, G, B) == "quad"
+        x = self._res(x, self.back_res, B, G, x_lay=x_lay, out_planar=tail_quad)
         if out is None:
             out = torch.empty((B, self.cout, G * G * G), device=self.device, dtype=torch.float32)
         if self.cout <= 16:
             # back_layers.1 / .2 / output_layer fused: one read of x, one planar write of the logits
             # ``softargmax`` = (coord, scratch): float32 program only - pass 1 of the soft-argmax rides in the same launch
-            _lib.pointwise_chain3(x, self.back1, self.back2, outc, out, B, G, softargmax=softargmax if self.dtype == torch.float32 else None)
+            _lib.pointwise_chain3(x, self.back1, self.back2, outc, out, B, G, softargmax=sa, in_quad=tail_quad)
             return out
         x = self._conv(x, self.back1, B, G, _lib.EPI_RELU)
         x = self._conv(x, self.back2, B, G, _lib.EPI_RELU)

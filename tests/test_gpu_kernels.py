@@ -345,6 +345,14 @@ def test_deconv_vs_torch(B, dim, cin, cout, skip):
         same_kernel = (B * dim ** 3 + 63) // 64 >= 512
         assert torch.equal(_unquad(outq), out) if same_kernel else float((_unquad(outq) - out).abs().max()) < 1e-5
         assert float((_ncdhw(_unquad(outq).cpu()) - want).abs().max()) < 2e-5
+        if skip:    # ... and with the skip tensor quad-planar too (SE_RES_QUAD: added behind the exchange - the same single addition)
+            outq2 = torch.full_like(outq, -7.0)
+            _lib.deconv3d_k2s2(_ndhwc(x).to(DEV), pc.w, pc.b, _quad(_ndhwc(sk).to(DEV)), outq2, B, dim, cin, cout,
+                               _lib.EPI_RELU | _lib.EPI_RES_POST_RELU | _lib.OUT_QUAD | _lib.RES_QUAD)
+            assert torch.equal(outq2, outq)
+            with pytest.raises(_lib.HipExtensionError):          # a quad-planar skip tensor needs the quad-planar output
+                _lib.deconv3d_k2s2(_ndhwc(x).to(DEV), pc.w, pc.b, _quad(_ndhwc(sk).to(DEV)), out, B, dim, cin, cout,
+                                   _lib.EPI_RELU | _lib.EPI_RES_POST_RELU | _lib.RES_QUAD)
     else:
         with pytest.raises(_lib.HipExtensionError):
             _lib.deconv3d_k2s2(_ndhwc(x).to(DEV), pc.w, pc.b, None, out, B, dim, cin, cout, _lib.EPI_RELU | _lib.OUT_QUAD)
@@ -494,6 +502,12 @@ def test_pointwise_chain_with_softargmax_pass1(B, G):
     assert float((j - j_ref).abs().max()) < 2e-6
     assert float((vol - vol_ref).abs().max()) <= 1e-5 * float(vol_ref.max())
     assert abs(float(vol.sum()) - B * 15) < 1e-3
+    # quad-planar input (SE_IN_QUAD, round 5: back_layers.0 hands the tail whole 16-byte records): the same fragments, the same bits
+    out_q = torch.full_like(ref, float("nan"))
+    scratch_q = torch.full_like(scratch, float("nan"))
+    _lib.pointwise_chain3(_quad(x), p1, p2, p3, out_q, B, G, softargmax=(coord, scratch_q), in_quad=True)
+    assert torch.equal(out_q, ref)
+    assert torch.equal(torch.nan_to_num(scratch_q, nan=-1.0), torch.nan_to_num(scratch, nan=-1.0))      # (the pad slots of a record keep their NaN fill)
 
 
 def test_voxelize_strided_into_v2v_buffer(voxel_setup):
