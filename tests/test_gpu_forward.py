@@ -236,6 +236,27 @@ def test_forward_17_joints_unfused_tail_vs_oracle(oracle_constants):
     assert float((vols.cpu() - ovols).abs().max()) <= 2e-3 * float(ovols.max())
 
 
+def test_v2v_fork_levels_bit_identical(net64):
+    """The optional fork of the skip blocks onto a side stream (V2VProgram.fork_levels; off by default: measured slower, DESIGN.md
+    section 4 round 5) changes the ISSUE order only: reference network/v2v.py:104-137 reads skip_x_k first in decoder_upsample_k.  Same
+    V2V input -> bit-identical logits with no fork, with every level forked and with a mixed set, eagerly and replayed 3 times."""
+    x = torch.randn(2, 33, 64, 64, 64, generator=torch.Generator().manual_seed(5)).to(DEV)
+    prog = net64.volume_net.program
+    try:
+        prog.fork_levels = ()
+        with torch.no_grad():
+            ref = net64.volume_net(x).clone()
+        for levels in ((0, 1, 2, 3, 4), (1, 3)):
+            prog.fork_levels = levels
+            for _ in range(3):
+                with torch.no_grad():
+                    got = net64.volume_net(x)
+                torch.cuda.synchronize()
+                assert torch.equal(got, ref), levels
+    finally:
+        prog.fork_levels = None
+
+
 def test_scene_volumes_branch_and_none(net64, oracle_constants):
     """Pre-voxelised input (voxel_net_depth.py:246-249) gives the same joints as the depth branch; no scene -> None."""
     const = oracle_constants(64)
