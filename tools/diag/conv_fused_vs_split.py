@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from sceneego_amd import _lib  # noqa: E402
 
 dev = "cuda:0"
-B = 8
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 shapes = [  # (cin, H, cout, k, stride)   conv1 / conv2 of the bottlenecks + stem
     (3, 256, 64, 7, 2), (64, 64, 64, 1, 1), (64, 64, 64, 3, 1), (256, 64, 64, 1, 1), (256, 64, 128, 1, 1), (128, 64, 128, 3, 2),
     (512, 32, 128, 1, 1), (128, 32, 128, 3, 1), (512, 32, 256, 1, 1), (256, 32, 256, 3, 2), (1024, 16, 256, 1, 1),

@@ -15,9 +15,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "split_bf16":
     net.set_v2v_dtype("split_bf16")
 const = O.Constants(os.path.join(ROOT, "sceneego_amd", "calibration", "fisheye.calibration_05_08.json"))
 worst = 0.0
-for seed in (3, 19, 101, 2027, 5150, 90210):
+# batch sizes 2, 3, 5: odd batches put a persistent workgroup's unit range across a sample boundary (conv3d_wino44pp.hip `advance`)
+for seed, nb in ((3, 2), (19, 3), (101, 5), (2027, 2), (5150, 3), (90210, 5)):
     for kind in ("uniform", "floor"):
-        img, depth = synth.make_inputs(seed, 2, kind)
+        img, depth = synth.make_inputs(seed, nb, kind)
         with torch.no_grad():
             kp = net(img.to("cuda:0"), net.grid_coord_proj_batch, net.coord_volumes, depth_map_batch=depth.to("cuda:0"))[0].cpu()
         taps = {}
