@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
     const int tg = tid & 255;                   // thread inside the group
     const int dim = a.dim, cin = a.cin;
     const int chunks = cin >> 2;
-    const int u_begin = (int)blockIdx.x * units_per_wg;
+    const int u_begin = se_xcd_walk_index((int)blockIdx.x, (int)gridDim.x) * units_per_wg;      // XCD-aware: conv_common.h
     const int u_end = min(u_begin + units_per_wg, n_units);
     if (u_begin >= u_end) return;
     const int n_steps = (u_end - u_begin) * chunks;

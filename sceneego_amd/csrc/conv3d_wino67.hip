@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
     const int h = lane >> 4;
     const int dim = a.dim;
     const int chunks = (a.cin + 2) / 3;
-    const int u_begin = (int)blockIdx.x * units_per_wg;
+    const int u_begin = se_xcd_walk_index((int)blockIdx.x, (int)gridDim.x) * units_per_wg;      // XCD-aware: conv_common.h
     const int u_end = min(u_begin + units_per_wg, total_tiles);
     if (u_begin >= u_end) return;
     const int n = u_end - u_begin;

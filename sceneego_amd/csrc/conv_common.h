@@ -42,6 +42,18 @@ __host__ __device__ inline float se_wino27_G(int xi, int kz) {
     }
 }
 
+// XCD-aware walk of the persistent kernels (round 5).  Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8,
+// each XCD has its own L2), so with unit ranges in blockIdx order the NEIGHBOURING ranges - which share their halo rows - sit in eight
+// different L2s and every shared row is fetched from the fabric once per L2.  Virtual index: the workgroups of one XCD walk
+// consecutive ranges, the halo between them is an L2 hit.  (Round 4 measured the same map at -2 ... +1 % of time - the kernels are not
+// bound by where their rows come from; what it buys is fabric traffic: SE_XCD_WALK=0 in an A/B build restores blockIdx order.)
+#ifndef SE_XCD_WALK
+#define SE_XCD_WALK 1
+#endif
+__device__ __forceinline__ int se_xcd_walk_index(int wg, int n_wg) {
+    return (SE_XCD_WALK && (n_wg & 7) == 0) ? (wg & 7) * (n_wg >> 3) + (wg >> 3) : wg;
+}
+
 __host__ __device__ inline int round_up16(int v) { return (v + 15) & ~15; }
 
 // Shapes the 2-D Winograd 3x3x3 kernel (conv3d_wino2d.hip) covers - ONE predicate for se_conv3d_f32_algo() (what callers use to
