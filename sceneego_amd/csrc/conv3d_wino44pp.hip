@@ -92,6 +92,7 @@ unsigned long long* g_w44p_dbg = nullptr;
 
 struct UnitP {
     int cb, b, z0, y0, x0;
+    int i;          // linear unit index (x fastest, then y, z, sample, cout block)
 };
 
 // F(4,3) B^T (points 0, +-1, +-2, inf) on six values, per component (scalar float arithmetic: packed VALU beside the partner
@@ -199,10 +200,26 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
     const int tg = tid & 255;                   // thread inside the group
     const int dim = a.dim, cin = a.cin;
     const int chunks = cin >> 2;
-    const int u_begin = se_xcd_walk_index((int)blockIdx.x, (int)gridDim.x) * units_per_wg;      // XCD-aware: conv_common.h
-    const int u_end = min(u_begin + units_per_wg, n_units);
-    if (u_begin >= u_end) return;
-    const int n_steps = (u_end - u_begin) * chunks;
+    // This workgroup's units: u_first, u_first + u_stride, ... (n_mine of them).  SE_XCD_WALK (conv_common.h) 1: a contiguous range of the
+    // XCD's share; 2 (round 5): the workgroups of an XCD INTERLEAVE - workgroup w of the XCD's S takes units w, w + S, w + 2 S ... of the
+    // XCD's range - so that the S tiles in flight on an XCD at any time are S consecutive units (at 64^3: a whole z slab of a sample)
+    // and the halo rows they share are hits in the XCD's L2 while both readers are at work.
+    int u_first, u_stride, n_mine;
+#ifndef SE_K44P_XCD_WALK
+#define SE_K44P_XCD_WALK 2       // measured (profiles/r05_wino44pp_experiments.txt section 5): reads of a launch 602 -> 358 MB, time -0.7 % inside the forward
+#endif
+    if (SE_K44P_XCD_WALK == 2 && (gridDim.x & 7) == 0) {
+        const int S = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, w = (int)blockIdx.x >> 3;
+        const int r0 = xcd * S * units_per_wg, r1 = min(r0 + S * units_per_wg, n_units);
+        u_first = r0 + w; u_stride = S;
+        n_mine = u_first < r1 ? (r1 - u_first + S - 1) / S : 0;
+    } else {
+        u_first = se_xcd_walk_index((int)blockIdx.x, (int)gridDim.x) * units_per_wg;
+        u_stride = 1;
+        n_mine = min(u_first + units_per_wg, n_units) - u_first;
+    }
+    if (n_mine <= 0) return;
+    const int n_steps = n_mine * chunks;
 
     auto decode = [&](int u) {
         UnitP r;
@@ -213,10 +230,32 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
         const int zz = t % tiles_z;
         r.b = t / tiles_z;
         r.z0 = zz * 8; r.y0 = yy * 8; r.x0 = xt * 16;
+        r.i = u;
         return r;
     };
     // the unit after u in the walk (x fastest, then y, z, sample, cout block): carries instead of divisions
+    // interleaved walk: the stride in mixed radix (tiles_x, tiles_y, tiles_z, samples) - a jump is four adds with carries, no division
+    const int batch_n = total_tiles / (tiles_x * tiles_y * tiles_z);
+    int sj_x = 0, sj_y = 0, sj_z = 0, sj_b = 0, sj_cb = 0;
+    if (u_stride != 1) {
+        int t = u_stride;
+        sj_x = t % tiles_x; t /= tiles_x;
+        sj_y = t % tiles_y; t /= tiles_y;
+        sj_z = t % tiles_z; t /= tiles_z;
+        sj_b = t % batch_n; sj_cb = t / batch_n;
+    }
     auto advance = [&](UnitP u) {
+        if (u_stride != 1) {
+            u.i += u_stride;
+            int x = (u.x0 >> 4) + sj_x, y = (u.y0 >> 3) + sj_y, z = (u.z0 >> 3) + sj_z, b = u.b + sj_b, cb = u.cb + sj_cb;
+            if (x >= tiles_x) { x -= tiles_x; y += 1; }
+            if (y >= tiles_y) { y -= tiles_y; z += 1; }
+            if (z >= tiles_z) { z -= tiles_z; b += 1; }
+            if (b >= batch_n) { b -= batch_n; cb += 1; }
+            u.x0 = x << 4; u.y0 = y << 3; u.z0 = z << 3; u.b = b; u.cb = cb;
+            return u;
+        }
+        u.i += 1;
         u.x0 += 16;
         if (u.x0 == dim) {
             u.x0 = 0; u.y0 += 8;
@@ -489,7 +528,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
     };
 
     // State of the walk: (ucur, ccur) = the step this group computes next, (unx, cnx) = the step after it.
-    UnitP ucur = decode(u_begin);
+    UnitP ucur = decode(u_first);
     UnitP unx = ucur;
     int cnx = 0, inx = 0;
     int slot = 0;                   // slot of half A of step (ucur, ccur) = (2 step) mod 3; half B: slot + 1 (mod 3)
@@ -659,7 +698,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
             barrier();
             barrier();
         }
-        const int n_tiles = u_end - u_begin;
+        const int n_tiles = n_mine;
         for (int t = 0; t < n_tiles; ++t) {
             if (t == 0) step(std::integral_constant<int, 0>{});
             else step(std::integral_constant<int, 1>{});

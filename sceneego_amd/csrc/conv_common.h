@@ -53,6 +53,8 @@ __host__ __device__ inline float se_wino27_G(int xi, int kz) {
 __device__ __forceinline__ int se_xcd_walk_index(int wg, int n_wg) {
     return (SE_XCD_WALK && (n_wg & 7) == 0) ? (wg & 7) * (n_wg >> 3) + (wg >> 3) : wg;
 }
+// The interleaved form of the same idea (workgroup w of an XCD's S takes units w, w + S, ...: the S tiles in flight on an XCD are S
+// consecutive units) lives in the kernels that have it: SE_K44P_XCD_WALK (on), SE_K67_XCD_WALK (off).
 
 __host__ __device__ inline int round_up16(int v) { return (v + 15) & ~15; }
 
