@@ -11,8 +11,8 @@ from sceneego_amd import _lib
 from sceneego_amd.v2v import _PackedConv
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 dev = "cuda:0"
-oct_ = lambda t: t.view(t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.shape[4] // 8, 8).permute(0, 4, 1, 2, 3, 5).contiguous()
-unoct = lambda t: t.permute(0, 2, 3, 4, 1, 5).reshape(t.shape[0], t.shape[2], t.shape[3], t.shape[4], t.shape[1] * 8)
+oct_ = lambda t: t.view(t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.shape[4] // 4, 4).permute(0, 4, 1, 2, 3, 5).contiguous()      # (quad-planar)
+unoct = lambda t: t.permute(0, 2, 3, 4, 1, 5).reshape(t.shape[0], t.shape[2], t.shape[3], t.shape[4], t.shape[1] * t.shape[5])
 bad = 0
 #          B  dim cin cout  skip   pool   skip16 in_oct
 FORMS = [(8, 64, 32, 32, True, False, False, True), (8, 64, 32, 32, False, False, False, True), (8, 64, 32, 32, True, True, False, True),
@@ -23,10 +23,10 @@ for B, dim, cin, cout, skip, pool, skip16, in_oct in FORMS:
     torch.manual_seed(dim + cin + cout)
     conv = torch.nn.Conv3d(cin, cout, 3, padding=1).to(dev)
     pc = _PackedConv(conv, None, None, torch.float32)
-    assert _lib.conv3d_variant(B, dim, cin, cout, 3, _lib.IN_OCTET) == 3
+    assert _lib.conv3d_variant(B, dim, cin, cout, 3, _lib.IN_QUAD) == 3
     x = torch.randn(B, dim, dim, dim, cin, device=dev)
     res = torch.randn(B, dim, dim, dim, cout, device=dev) if skip else None
-    flags = _lib.EPI_RELU | _lib.OUT_OCTET | (_lib.IN_OCTET if in_oct else 0) | ((_lib.EPI_RES_PRE_RELU | _lib.RES_OCTET) if skip else 0)
+    flags = _lib.EPI_RELU | _lib.OUT_QUAD | (_lib.IN_QUAD if in_oct else 0) | ((_lib.EPI_RES_PRE_RELU | _lib.RES_QUAD) if skip else 0)
     xin = oct_(x) if in_oct else x
     rin = oct_(res) if skip else None
     pooled = torch.empty(B, dim // 2, dim // 2, dim // 2, cout, device=dev) if pool else None
@@ -35,11 +35,11 @@ for B, dim, cin, cout, skip, pool, skip16, in_oct in FORMS:
 
     def launch(o):
         if skip16:
-            _lib.conv3d_skip16(xin, pc.w, pc.b, xs, wsk, o, B, dim, cin, cout, _lib.EPI_RELU | _lib.IN_OCTET | _lib.OUT_OCTET)
+            _lib.conv3d_skip16(xin, pc.w, pc.b, xs, wsk, o, B, dim, cin, cout, _lib.EPI_RELU | _lib.IN_QUAD | _lib.OUT_QUAD)
         else:
             _lib.conv3d(xin, pc.w, pc.b, rin, o, B, dim, cin, cin, cout, 3, flags, None, pool_out=pooled)
 
-    ref = torch.empty(B, cout // 8, dim, dim, dim, 8, device=dev)
+    ref = torch.empty(B, cout // 4, dim, dim, dim, 4, device=dev)       # quad-planar (round 5: the kernel's planar layout)
     launch(ref)
     pref = pooled.clone() if pool else None
     if dim <= 64 and B <= 3 or (B, dim, cin, skip, pool, skip16) == (8, 64, 32, True, False, False):
@@ -68,7 +68,7 @@ for B, dim, cin, cout, skip, pool, skip16, in_oct in FORMS:
         if not torch.equal(out, ref) or (pool and not torch.equal(pooled, pref)):
             n_bad += 1
     torch.cuda.synchronize()
-    print(f"3^3 {cin}->{cout} @{dim}^3 B={B} skip={skip} pool={pool} skip16={skip16} input {'octet-planar' if in_oct else 'channels-last'}: "
+    print(f"3^3 {cin}->{cout} @{dim}^3 B={B} skip={skip} pool={pool} skip16={skip16} input {'quad-planar' if in_oct else 'channels-last'}: "
           f"{n_bad} of {n} launches differed from the first", flush=True)
     bad += n_bad
 assert bad == 0
