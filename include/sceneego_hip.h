@@ -135,7 +135,10 @@ long long se_conv3d_packed_elems(int cout, int cin_pad, int ksize, int transpose
  *   else the direct kernel; results are identical in both up to float32 summation order.
  *   workspace (optional, may be NULL): `workspace_elems` floats of scratch; when given, small volumes
  *   (too few voxels to fill 256 CUs) split the 27 taps over extra workgroups and reduce the partial sums
- *   from the workspace in a fixed order (deterministic).  32 Mi floats cover every V2V level up to B = 64. */
+ *   from the workspace in a fixed order (deterministic), and the 7^3 front layer of a launch with fewer than two
+ *   tiles per CU (batch 1 at 64^3) splits every tile's 3-channel chunks between two workgroups - the second halves'
+ *   sums pass through the first B * D^3 * 16 floats of the workspace and are added by a second kernel of the same
+ *   call.  32 Mi floats cover every V2V level up to B = 64.  A workspace serves one stream at a time. */
 int se_conv3d_f32(const float* in, const float* wpack, const float* bpack, const float* residual,
                   float* out, int batch, int dim, int cin, int cin_pad, int cout, int ksize, int flags,
                   float* workspace, long long workspace_elems, void* stream);

@@ -636,6 +636,162 @@ __global__ __launch_bounds__(WAVES * 64) void conv3d_k3_wavesplit_kernel(ConvArg
     }
 }
 
+// 4096-voxel levels with wide channels (8^3 at batch 8, 16^3 at batch 1; 128 -> 128): the in-workgroup split-K form above reads
+// every operand of every k step straight from the vector cache - each voxel record 27 times, the weights once per 32 voxels:
+// 442 MB of cache traffic per launch, 30 of its 45 us with the MFMAs knocked out (round 5, profiles/r05_small_levels.txt).
+// This form stages the activations through LDS and shares a weight fragment between four voxel tiles:
+//   workgroup = 64 consecutive voxels (whole rows: one z slab at dim 8, four rows at dim 16) x 32 couts, 8 waves;
+//   per 32-channel stage the 3 x (R+2) x (DIM+2) halo of the tile is staged once (raw buffer loads, a voxel outside the volume
+//   reads zeros through an out-of-range offset; global -> registers under the previous stage's MFMAs -> LDS, two buffers, one
+//   barrier per stage); a halo voxel takes 144 bytes of LDS (128 + 16 pad: every 8 lanes of a ds_read_b128 cover the 32 banks);
+//   the 54 (tap, 16-channel group) k steps of a stage are dealt to the waves (step = wave + 8 j: 7, 7, 7, 7, 7, 7, 6, 6); a k step
+//   = 2 weight fragments (global; the whole next stage's seven steps in flight in a register ring) + 4 ds_read_b128 + 32 MFMAs;
+//   the waves' partial sums meet in LDS in wave order (deterministic) and the epilogue runs in the same launch, its bias and
+//   skip-tensor loads issued ahead of the last stage's MFMAs.
+template <int DIM>
+struct Halo64 {
+    static constexpr int R = 64 / DIM;                // rows of a tile
+    static constexpr int HX = DIM + 2, HY = R + 2;
+    static constexpr int HV = 3 * HY * HX;            // halo voxels: 300 (dim 8) / 324 (dim 16)
+    static constexpr int PITCH = 144;
+    static constexpr int HB = HV * PITCH;
+    static constexpr int PIECES = HV * 8;             // 16-byte pieces of a stage
+    static constexpr int HP = (PIECES + 511) / 512;
+    static constexpr int MT_OFF = (16 / DIM) * HX * PITCH;   // LDS bytes between consecutive voxel tiles (16 voxels = 16 / DIM rows)
+    static constexpr int LDS_BYTES = 2 * HB > 65536 ? 2 * HB : 65536;
+};
+
+template <int DIM>
+__global__ __launch_bounds__(512) void conv3d_k3_halo64_kernel(ConvArgs a) {
+    using G = Halo64<DIM>;
+    constexpr int HX = G::HX, HY = G::HY, PITCH = G::PITCH, HP = G::HP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int vl = lane & 15, h = lane >> 4;
+    const int stages = a.cin >> 5;
+    const int nt0 = blockIdx.y * 2;
+    constexpr unsigned OOB = 0x80000000u;
+    int t = blockIdx.x;
+    const int ty = t % (DIM / G::R); t /= (DIM / G::R);
+    const int z = t % DIM;
+    const int b = t / DIM;
+    const int y0 = ty * G::R;
+    const long long vid0 = (((long long)b * DIM + z) * DIM + y0) * DIM;       // the tile's 64 voxels are consecutive in memory
+
+    // this thread's halo pieces: byte offset in the input tensor (out of range for a voxel outside the volume) - fixed over the stages
+    unsigned goff[HP];
+#pragma unroll
+    for (int j = 0; j < HP; ++j) {
+        const int p = tid + 512 * j;
+        const int hv = p >> 3, q = p & 7;
+        const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+        const int gz = z + hz - 1, gy = y0 + hy - 1, gx = hx - 1;
+        const bool ok = p < G::PIECES && (unsigned)gz < (unsigned)DIM && (unsigned)gy < (unsigned)DIM && (unsigned)gx < (unsigned)DIM;
+        goff[j] = ok ? (unsigned)(((((long long)b * DIM + gz) * DIM + gy) * DIM + gx) * a.cin_pad * 4 + q * 16) : OOB;
+    }
+    const int lpiece = (tid >> 3) * PITCH + (tid & 7) * 16;                   // piece j: + j * 64 * PITCH
+    const unsigned in_bytes = (unsigned)(a.total_vox * a.cin_pad * 4);        // launcher: fits 31 bits
+    const unsigned w_bytes = (unsigned)(27 * (a.cin >> 4) * a.nts * 1024);
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)in_bytes, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, (int)w_bytes, 0x00020000);
+    const int woff = lane * 16;
+    // operand reads: lane (vl, h) = voxel vl of the tile's first 16, channels 4 h .. 4 h + 3, at the tap (-1, -1, -1) corner
+    const int lrow = DIM == 8 ? (vl >> 3) : 0, lx = DIM == 8 ? (vl & 7) : vl;
+    const int lbase = (lrow * HX + lx) * PITCH + h * 16;
+
+    f32x4 st[HP];
+    auto load_stage = [&](int sg) {
+#pragma unroll
+        for (int j = 0; j < HP; ++j) st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)goff[j], sg * 128, 0));
+    };
+    auto commit_stage = [&](unsigned char* buf) {
+#pragma unroll
+        for (int j = 0; j < HP; ++j)
+            if (tid + 512 * j < G::PIECES) *reinterpret_cast<f32x4*>(buf + lpiece + j * 64 * PITCH) = st[j];
+    };
+    f32x4 wr[7][2];
+    auto load_w = [&](int j, int sg) {                 // slot j of stage sg: step wave + 8 j = (tap, group); slot 6 of waves 6, 7: dead, never used
+        const int step = wave + 8 * j;
+        const int tap = step >> 1, cg = sg * 2 + (step & 1);
+        const int wso = step < 54 ? ((cg * 27 + tap) * a.nts + nt0) * 1024 : 0;
+        wr[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff, wso, 0));
+        wr[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff, wso + 1024, 0));
+    };
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // the epilogue's operands (wave w finishes fragment w = (cout tile w >> 2, voxel tile w & 3))
+    const long long per_b = (long long)DIM * DIM * DIM;
+    const int co0 = (nt0 + (wave >> 2)) * 16 + 4 * h;
+    const long long ooff = (vid0 + (wave & 3) * 16 + vl) * a.cout + co0;
+    f32x4 ebias = (f32x4){0.f, 0.f, 0.f, 0.f}, eres = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    load_stage(0);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) load_w(j, 0);
+    for (int sg = 0; sg < stages; ++sg) {
+        unsigned char* buf = lds + (sg & 1) * G::HB;
+        commit_stage(buf);
+        __syncthreads();          // the stage is in LDS; every wave has left the stage before the previous one (the buffer written next)
+        const bool more = sg + 1 < stages;
+        if (more) {
+            load_stage(sg + 1);
+        } else {
+            ebias = *reinterpret_cast<const f32x4*>(a.bpack + co0);
+            if (a.res) eres = *reinterpret_cast<const f32x4*>(a.res + ooff);
+        }
+        f32x4 xf[2][4];
+        auto read_x = [&](f32x4 (&x)[4], int j) {
+            int step = wave + 8 * j;
+            step = step < 54 ? step : 53;
+            const int tap = step >> 1;
+            const int toff = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * PITCH + (step & 1) * 64;     // wave-uniform
+            const unsigned char* p = buf + lbase + toff;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) x[n] = *reinterpret_cast<const f32x4*>(p + n * G::MT_OFF);
+        };
+        read_x(xf[0], 0);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            if (j + 1 < 7) read_x(xf[(j + 1) & 1], j + 1);
+            if (wave + 8 * j < 54) {                   // uniform
+                const f32x4(&x)[4] = xf[j & 1];
+                const float wv[2][4] = {{wr[j][0].x, wr[j][0].y, wr[j][0].z, wr[j][0].w}, {wr[j][1].x, wr[j][1].y, wr[j][1].z, wr[j][1].w}};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)            // component outer: consecutive MFMAs go to different accumulators
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const float xv[4] = {x[n].x, x[n].y, x[n].z, x[n].w};
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[m][c], xv[c], acc[m][n], 0, 0, 0);
+                    }
+            }
+            if (more) load_w(j, sg + 1);               // the slot's registers are free: next stage's weights, seven steps ahead
+        }
+    }
+    __syncthreads();              // every wave is done with the halo buffers: the partial sums go on top of them
+    f32x4(*red)[8][64] = reinterpret_cast<f32x4(*)[8][64]>(lds);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) red[wave][m * 4 + n][lane] = acc[m][n];
+    __syncthreads();
+    f32x4 v = red[0][wave][lane];                      // partials added in wave order
+#pragma unroll
+    for (int w2 = 1; w2 < 8; ++w2) v += red[w2][wave][lane];
+    v += ebias;
+    if ((a.flags & SE_EPI_RES_PRE_RELU) && a.res) v += eres;
+    if (a.flags & SE_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if ((a.flags & SE_EPI_RES_POST_RELU) && a.res) v += eres;
+    *reinterpret_cast<f32x4*>(a.out + ooff) = v;
+    (void)per_b;
+}
+
 // thread = (voxel, cout quad): sum the split partials in order, then the usual epilogue
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a, const float* __restrict__ ws, int splits) {
     const int cq = a.cout >> 2;
@@ -1045,6 +1201,8 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
     if (ksize == 3 && cout % 32 == 0) a.wpack_i = a.wpack_g + (long long)(cin_pad / 8) * (cout / 32) * SE_WINO2D_CHUNK_FLOATS;
     a.pool_out = pool_out;
     a.skip_w = skip_w;
+    a.ws = workspace;
+    a.ws_elems = workspace ? workspace_elems : 0;
     if (!skip_w && (flags & SE_EPI_SKIPCONV16)) return SE_ERR_BAD_ARG;
     if (skip_w && (!residual || se_conv3d_f32_algo(dim, cin, cout, ksize) != 2 || cin_pad != cin)) return SE_ERR_BAD_ARG;
     if (pool_out && ((dim & 1) || se_conv3d_f32_algo(dim, cin, cout, ksize) != 2 || cin_pad != cin)) return SE_ERR_BAD_ARG;   // only the 2-D Winograd kernel pools
@@ -1066,7 +1224,19 @@ static int conv3d_f32_impl(const float* in, const float* wpack, const float* bpa
         (a.total_vox >= 2048 || g_variant_direct == 2)) {
         // 8^3-sized levels: in-workgroup split-K, single launch (round 2: 0.063 vs 0.077 ms for grid split-K + reduce at B = 8)
         const long long tiles = (a.total_vox + 15) / 16;
-        if (a.total_vox >= 2048)
+#ifndef SE_HALO64
+#define SE_HALO64 1
+#endif
+        if (SE_HALO64 && a.total_vox >= 2048 && (dim == 8 || dim == 16) && (a.cin & 31) == 0 && !(flags & SE_EPI_OUT_PLANAR)) {   // 64-voxel tiles, activations through LDS
+            const dim3 grid((unsigned)(a.total_vox / 64), a.nts / 2);
+            if (dim == 8) {
+                SE_ENSURE_LDS(conv3d_k3_halo64_kernel<8>, Halo64<8>::LDS_BYTES);
+                hipLaunchKernelGGL((conv3d_k3_halo64_kernel<8>), grid, dim3(512), Halo64<8>::LDS_BYTES, s, a);
+            } else {
+                SE_ENSURE_LDS(conv3d_k3_halo64_kernel<16>, Halo64<16>::LDS_BYTES);
+                hipLaunchKernelGGL((conv3d_k3_halo64_kernel<16>), grid, dim3(512), Halo64<16>::LDS_BYTES, s, a);
+            }
+        } else if (a.total_vox >= 2048)
             hipLaunchKernelGGL((conv3d_k3_wavesplit_kernel<2, 4>), dim3((unsigned)((tiles + 1) / 2), a.nts / 2), dim3(256), 0, s, a);
         else if (a.total_vox >= 256)
             hipLaunchKernelGGL((conv3d_k3_wavesplit_kernel<1, 8>), dim3((unsigned)tiles, a.nts / 2), dim3(512), 0, s, a);

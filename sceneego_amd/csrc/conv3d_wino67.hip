@@ -61,7 +61,7 @@ struct K7SOps { f32x4 a0, a1, a2, b0, b1, b2; };    // 12 xi of weights (A) and 
 
 template <bool PLANAR>
 __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int tiles_x, int tiles_y, int tiles_z, int total_tiles,
-                                                               int units_per_wg, unsigned long long* dbg) {
+                                                               int units_per_wg, int halves, float* part, unsigned long long* dbg) {
     (void)dbg;
 #ifdef SE_STAMP67
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
@@ -98,11 +98,13 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
 
     for (int i = tid; i < n; i += 512) {
         int t = u_first + i * u_stride;
+        const int half = halves == 2 ? (t & 1) : 0;       // halves == 2: unit = (tile, half of its chunks); total_tiles counts units
+        if (halves == 2) t >>= 1;
         i32x4 e;
         e.w = t % tiles_x; t /= tiles_x;
         e.z = t % tiles_y; t /= tiles_y;
         e.y = t % tiles_z; t /= tiles_z;
-        e.x = t;
+        e.x = t | (half << 30);
         utab[i] = e;
     }
 
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
         f_gz0 = e.y * S_TZ - 3;
         const bool okc = s_on && (unsigned)gy < (unsigned)dim && (unsigned)gx < (unsigned)dim;
         f_shift = PLANAR ? 0 : max(0, c * 3 + 3 - a.cin_pad);
-        const int b = __builtin_amdgcn_readfirstlane(e.x);
+        const int b = __builtin_amdgcn_readfirstlane(e.x) & 0x3fffffff;
         f_xb = PLANAR ? a.in + ((long long)b * chunks + c) * dim * dim * dim * 3
                       : a.in + (long long)b * dim * dim * dim * a.cin_pad + c * 3 - f_shift;
         f_voff = okc ? (unsigned)((gy * dim + gx) * (PLANAR ? 12 : a.cin_pad * 4)) : 0x80000000u;
@@ -226,9 +228,17 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
     const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bpack + 4 * h);
 
     __syncthreads();   // utab
-    fetch(0, 0);
+    // chunk range of a unit: all of them, or (halves == 2: a launch with fewer than two tiles per CU, batch 1 at 64^3) the first / second
+    // half - the first half's sums go to the output tensor with the bias, the second half's to `part`; k7_combine_kernel adds them
+    const int c_mid = (chunks + 1) >> 1;
+    auto unit_half = [&](int kk) { return (__builtin_amdgcn_readfirstlane(utab[kk].x) >> 30) & 1; };
+    auto c_lo = [&](int hf) { return hf ? c_mid : 0; };
+    auto c_hi = [&](int hf) { return (halves == 2 && !hf) ? c_mid : chunks; };
+    int k = 0, half_k = unit_half(0), c = c_lo(half_k);
+    fetch(0, c);
     commit();
-    for (int i = tid; i < S_WA_F4; i += 512) reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(a.wpack_h)[i];   // region A of chunk 0
+    for (int i = tid; i < S_WA_F4; i += 512)     // region A of the first chunk
+        reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(a.wpack_h + (size_t)c * S_W_FLOATS)[i];
     __syncthreads();
 
     auto read_ops = [&](K7SOps& r, auto g_tag) {
@@ -243,13 +253,14 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
     f32x4 y[S_TZ];
 #pragma unroll
     for (int i = 0; i < S_TZ; ++i) y[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int n_items = chunks * n;
-    int k = 0, c = 0;
-    for (int item = 0; item < n_items; ++item) {
-        const bool has_next = item + 1 < n_items;
-        const bool last_chunk = c == chunks - 1;
-        const int c_next = has_next ? (last_chunk ? 0 : c + 1) : c;
-        const int k_next = has_next ? (last_chunk ? k + 1 : k) : k;
+    int n_items = 0;
+    for (;;) {
+        ++n_items;
+        const bool last_chunk = c == c_hi(half_k) - 1;
+        const bool has_next = !(last_chunk && k == n - 1);
+        const int k_next = (has_next && last_chunk) ? k + 1 : k;
+        const int half_next = (has_next && last_chunk) ? unit_half(k_next) : half_k;
+        const int c_next = has_next ? (last_chunk ? c_lo(half_next) : c + 1) : c;
         const float* w_cur_b = a.wpack_h + (size_t)c * S_W_FLOATS + S_GA * 768;     // region B of this chunk
         const float* w_next_a = a.wpack_h + (size_t)c_next * S_W_FLOATS;            // region A of the next item's chunk
 
@@ -339,12 +350,15 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
         if (last_chunk) {   // bias, ReLU, the only store of this tile
             const i32x4 e = utab[k];
             const int oz0 = e.y * S_TZ, oy = e.z * S_TY + wave, ox = e.w * S_TX + vl;
-            float* op = a.out + ((((long long)e.x * dim + oz0) * dim + oy) * dim + ox) * 16 + 4 * h;
+            float* ob = (halves == 2 && half_k) ? part : a.out;           // second half of the chunks: raw sums beside the output tensor
+            float* op = ob + ((((long long)(e.x & 0x3fffffff) * dim + oz0) * dim + oy) * dim + ox) * 16 + 4 * h;
             const long long zstride = (long long)dim * dim * 16;
+            const bool fin = halves != 2;
 #pragma unroll
             for (int i = 0; i < S_TZ; ++i) {
-                f32x4 v = y[i] + bias;
-                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                f32x4 v = y[i];
+                if (fin || !half_k) v += bias;
+                if (fin && relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (oz0 + i < dim) *reinterpret_cast<f32x4*>(op + i * zstride) = v;
                 y[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // region A of the next chunk has landed
         lds_barrier();
         T67(6);
-        k = k_next; c = c_next;
+        k = k_next; c = c_next; half_k = half_next;
     }
 #ifdef SE_STAMP67
     if (lane == 0 && dbg) {
@@ -363,6 +377,15 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
         o[7] = n_items;
     }
 #endif
+}
+
+// halves == 2: out = [relu](out + part), thread = 4 floats
+__global__ __launch_bounds__(256) void k7_combine_kernel(float* __restrict__ out, const float* __restrict__ part, long long n4, int relu) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = reinterpret_cast<f32x4*>(out)[i] + reinterpret_cast<const f32x4*>(part)[i];
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    reinterpret_cast<f32x4*>(out)[i] = v;
 }
 
 }  // namespace
@@ -379,17 +402,30 @@ int se_conv3d_k7_wino67_launch(const ConvArgs& a, int batch, int num_cus, hipStr
     const int tx = dim / S_TX, ty = dim / S_TY, tz = (dim + S_TZ - 1) / S_TZ;
     const long long total_ll = (long long)batch * tx * ty * tz;
     if (total_ll > (1 << 30)) return SE_TILED_NOT_TAKEN;
-    const int total = (int)total_ll;
+#ifndef SE_K67_SPLIT
+#define SE_K67_SPLIT 1
+#endif
+    // fewer than two tiles per CU (batch 1 at 64^3: 352 tiles = two rounds for 1.4 tiles' worth of work): units of half a tile's chunks
+    // (704 units, at most 17 instead of 22 items per workgroup); needs the caller's workspace for the second halves' sums
+    const long long out_elems = a.total_vox * 16;
+    const bool split = SE_K67_SPLIT && total_ll < 2LL * num_cus && (a.cin + 2) / 3 >= 2 && a.ws && a.ws_elems >= out_elems;
+    const int halves = split ? 2 : 1;
+    const int total = (int)total_ll * halves;
     const int grid = total < num_cus ? total : num_cus;
     const int per = (total + grid - 1) / grid;
     if (per > MAX_UNITS) return SE_TILED_NOT_TAKEN;
     if (a.flags & SE_IN_PLANAR3) {
         SE_ENSURE_LDS(conv3d_k7_wino67_kernel<true>, LDS_BYTES);
-        hipLaunchKernelGGL(conv3d_k7_wino67_kernel<true>, dim3((total + per - 1) / per), dim3(512), LDS_BYTES, s, a, tx, ty, tz, total, per, dbg);
+        hipLaunchKernelGGL(conv3d_k7_wino67_kernel<true>, dim3((total + per - 1) / per), dim3(512), LDS_BYTES, s, a, tx, ty, tz, total, per, halves, a.ws, dbg);
     } else {
         SE_ENSURE_LDS(conv3d_k7_wino67_kernel<false>, LDS_BYTES);
-        hipLaunchKernelGGL(conv3d_k7_wino67_kernel<false>, dim3((total + per - 1) / per), dim3(512), LDS_BYTES, s, a, tx, ty, tz, total, per, dbg);
+        hipLaunchKernelGGL(conv3d_k7_wino67_kernel<false>, dim3((total + per - 1) / per), dim3(512), LDS_BYTES, s, a, tx, ty, tz, total, per, halves, a.ws, dbg);
     }
     SE_CHECK_LAUNCH();
+    if (split) {
+        const long long n4 = out_elems / 4;
+        hipLaunchKernelGGL(k7_combine_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.out, a.ws, n4, (a.flags & SE_EPI_RELU) ? 1 : 0);
+        SE_CHECK_LAUNCH();
+    }
     return 0;
 }

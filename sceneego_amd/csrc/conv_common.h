@@ -94,6 +94,8 @@ struct ConvArgs {
     int cout;      // real output channels
     int nts;       // cout tiles of 16 in the packed weights
     int flags;
+    float* ws = nullptr;          // the caller's workspace (se_conv3d_f32): split-K partial sums of the small levels, second-half sums of a split 7^3 launch
+    long long ws_elems = 0;
 };
 
 // Epilogue for one accumulator fragment: this lane owns output channels co0..co0+3 of one voxel

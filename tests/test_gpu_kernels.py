@@ -154,7 +154,12 @@ CONV_CASES = [
     (8, 2, 128, 128, 3, True, True, True),      # split-K shapes of the real pyramid at B = 8
     (8, 4, 128, 128, 3, True, False, True),
     (2, 8, 128, 128, 3, True, True, True),
-    (4, 8, 128, 128, 3, True, True, True),      # 2048..8192 voxels: in-workgroup split-K (conv3d_k3_wavesplit_kernel)
+    (4, 8, 128, 128, 3, True, True, True),      # 2048..8192 voxels at 8^3 / 16^3, cin % 32 == 0: 64-voxel LDS-halo tiles (conv3d_k3_halo64_kernel)
+    (8, 8, 128, 128, 3, True, True, True),      # ... the 8^3 level of the pyramid at B = 8
+    (1, 16, 128, 128, 3, True, True, True),     # ... the 16^3 level at B = 1 (four-row tiles)
+    (8, 8, 64, 128, 3, True, False, True),      # ... two 32-channel stages
+    (16, 8, 32, 64, 3, False, True, False),     # ... one stage, 8192 voxels, skip tensor without a ReLU
+    (4, 8, 48, 64, 3, True, True, True),        # cin % 32 != 0: in-workgroup split-K from the vector cache (conv3d_k3_wavesplit_kernel)
     (8, 8, 64, 64, 3, False, False, True),
     (1, 8, 128, 64, 3, True, False, False),
     (2, 8, 16, 32, 1, False, False, True),
@@ -866,6 +871,38 @@ def test_conv7_front_layer_64_planar3_vs_torch():
           f"{err_last:.2e}; against float64 at {n} samples: hip {e_hip:.2e} ({e_hip / scale:.2e}), torch-CPU f32 {e_cpu:.2e}")
     assert err < 2e-5 * scale, (err, scale)
     assert e_hip < 1.5e-5 * scale, (e_hip, scale)          # accuracy regression guard of the F(6,7) transform (measured ~4e-6)
+    # batch 1 with a workspace (what V2VProgram passes): 352 tiles < 2 x 256 CUs -> every tile's 11 chunks are split 6 + 5 between two
+    # workgroups, the second halves' sums go through the workspace and k7_combine_kernel adds them (round 5).  The workspace is
+    # NaN-filled: a voxel the second halves did not write would surface as NaN.
+    ws = torch.full((dim ** 3 * 16 + 4096,), float("nan"), device=DEV)
+    out1 = torch.full((1, dim, dim, dim, 16), -77.0, device=DEV)
+    _lib.conv3d(_to_planar3(xin[:1].contiguous(), 33), pc.w, pc.b, None, out1, 1, dim, 33, 48, 16, 7, _lib.EPI_RELU | _lib.IN_PLANAR3, ws)
+    got1 = _ncdhw(out1.cpu())
+    assert bool(torch.isfinite(got1).all())
+    err1 = float((got1 - want[:1]).abs().max())
+    print(f"   B=1 with a workspace (chunk halves split over two workgroups): max|hip - torch f32| = {err1:.2e} ({err1 / scale:.2e} of max|y|), "
+          f"max|split - unsplit| = {float((got1 - got[:1]).abs().max()):.2e}")
+    assert err1 < 2e-5 * scale, (err1, scale)
+    assert bool(torch.isnan(ws[dim ** 3 * 16:]).all())      # nothing written behind the B * D^3 * 16 floats the header names
+
+
+def test_conv7_split_small_volume_channels_last_vs_unsplit():
+    """The chunk-half split of conv3d_k7_wino67_kernel on a small channels-last volume (16^3, 32 channels = 11 chunks, the last one with
+    two real channels; 6 tiles): with a workspace the launch splits, without one it does not; both against torch."""
+    B, dim, cin = 1, 16, 32
+    conv, bn = _conv_bn(cin, 16, 7, 77)
+    x = torch.from_numpy(synth.normal(77, "x", (B, cin, dim, dim, dim)))
+    with torch.no_grad():
+        want = F.relu(bn(conv(x)))
+    pc = _PackedConv(conv.to(DEV), bn.to(DEV))
+    xin = _ndhwc(x).to(DEV).contiguous()
+    outs = []
+    for ws in (None, torch.full((B * dim ** 3 * 16,), float("nan"), device=DEV)):
+        out = torch.full((B, dim, dim, dim, 16), -77.0, device=DEV)
+        _lib.conv3d(xin, pc.w, pc.b, None, out, B, dim, cin, cin, 16, 7, _lib.EPI_RELU, ws)
+        outs.append(_ncdhw(out.cpu()))
+        assert float((outs[-1] - want).abs().max()) < 2e-5 * float(want.abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) < 1e-5 * float(want.abs().max())      # the two forms differ by summation order only
 
 
 def test_conv7_channels_last_16_channels_with_nan_behind_the_tensor():
