@@ -31,6 +31,23 @@ __host__ __device__ inline bool se_k7b_slot(int slot, int& dx, int& dy, int& dz)
     return false;
 }
 
+// 7^3 front layer, row-reuse form (conv_bf16_k7r_kernel, round 5): second section of the packed weights, [octet][q 14][dy 7][lane][8].
+// Slot 4 q + g of a k group q names a (dx, dz) pair; the two slots of a lane-group pair (g = 0,1 and g = 2,3) share dz and differ in
+// dx, so their LDS addresses differ by a multiple of 256 B (conflict-free, as above).  dz-major: per dz the dx pairs (0,1) (2,3) (4,5)
+// (6, pad): 28 pairs = 14 groups = 56 slots for the 49 (dx, dz) combinations.  dy is the axis along which B fragments are reused.
+#define SE_K7R_GROUPS 14
+__host__ __device__ inline bool se_k7r_slot(int slot, int& dx, int& dz) {
+    const int p = slot >> 1;
+    dz = p >> 2;
+    dx = 2 * (p & 3) + (slot & 1);
+    if (dx < 7) return true;
+    dx = 6;       // padding slot: zero weights, the partner's address
+    return false;
+}
+__host__ __device__ inline long long se_k7r_elems(int cout, int cin_pad, int ksize, int transposed) {
+    return (!transposed && ksize == 7 && cout <= 16) ? (long long)(cin_pad / 8) * SE_K7R_GROUPS * 7 * 512 : 0;
+}
+
 struct PackGeomB {
     int taps;     // k^3, or 8 output parities for the k2s2 transposed conv
     int oc;       // octets (8-channel groups) per channel chunk
@@ -111,7 +128,7 @@ __device__ __forceinline__ void epi_store_pair(const ConvBArgs& a, f32x4 lo, f32
     u16x8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
-    *reinterpret_cast<u16x8*>(a.out + off) = o;
+    __builtin_nontemporal_store(o, reinterpret_cast<u16x8*>(a.out + off));      // written once, read by the NEXT launch after 0.5 GB of other traffic
 }
 __device__ __forceinline__ void epilogue_pair_bf16(const ConvBArgs& a, f32x4 lo, f32x4 hi, long long ovox, int cb, int g) {
     const long long off = ovox * a.cout + cb * 32 + 8 * g;

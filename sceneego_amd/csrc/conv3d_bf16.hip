@@ -26,6 +26,27 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, const float* __res
         bpack[e] = v;
     }
     if (e >= total) return;
+    const long long total_a = (long long)p.mtiles * p.ksteps * 512;
+    if (e >= total_a) {       // section R (7^3, cout <= 16): [octet][q][dy][lane][8], bf16_common.h se_k7r_slot
+        const long long eb = e - total_a;
+        const int j = (int)(eb & 7);
+        const int lane = (int)((eb >> 3) & 63);
+        const long long blk = eb >> 9;
+        const int dy = (int)(blk % 7);
+        const int q = (int)((blk / 7) % SE_K7R_GROUPS);
+        const int c = (int)(blk / (7 * SE_K7R_GROUPS));
+        const int g = lane >> 4, co = lane & 15;
+        int dx, dz;
+        const bool valid = se_k7r_slot(4 * q + g, dx, dz);
+        const int ci = c * 8 + j;
+        float v = 0.f;
+        if (valid && co < cout && ci < cin) {
+            const float sc = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.f;
+            v = w[((size_t)co * cin + ci) * 343 + (dx * 7 + dy) * 7 + dz] * sc;
+        }
+        wpack[e] = f2bf(v);
+        return;
+    }
     const int j = (int)(e & 7);
     const int lane = (int)((e >> 3) & 63);
     const long long blk = e >> 9;
@@ -379,7 +400,7 @@ extern "C" long long se_conv3d_packed_elems_bf16(int cout, int cin_pad, int ksiz
     if (cout <= 0 || cin_pad <= 0 || (cin_pad & 7)) return SE_ERR_BAD_ARG;
     if (cout % 32 != 0 && cout > 16) return SE_ERR_BAD_ARG;
     const PackGeomB p = pack_geom_b(cout, cin_pad, ksize, transposed);
-    return (long long)p.mtiles * p.ksteps * 512;
+    return (long long)p.mtiles * p.ksteps * 512 + se_k7r_elems(cout, cin_pad, ksize, transposed);
 }
 
 extern "C" int se_conv3d_pack_bf16(const float* w, const float* b, const float* gamma, const float* beta,

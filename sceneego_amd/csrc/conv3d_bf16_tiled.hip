@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void conv_bf16_k3_kernel(Conv
 #pragma unroll
     for (int n = 0; n < TY; ++n) {
         rv[n] = zero8();
-        if (has_res) rv[n] = *reinterpret_cast<const u16x8*>(a.res + (obase + (long long)n * D) * a.cout + mb * 32 + 8 * g);
+        // skip tensor: read once, by this launch only -> non-temporal (round 5: -2.5 % / -5 % per launch with the non-temporal stores of the epilogue)
+        if (has_res) rv[n] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(a.res + (obase + (long long)n * D) * a.cout + mb * 32 + 8 * g));
     }
     k3_compute<TY>(acc, brow, arow, g);
     K3_STAMP(5);
@@ -398,6 +399,131 @@ __global__ __launch_bounds__(256, ROW16 ? 2 : 1) void conv_bf16_k7_kernel(ConvBA
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 7x7x7 front layer, row-reuse form (round 5; tile 8(x) x 4(y) x 16(z), dim % 16 == 0, cout = 16, octet-planar input).
+// conv_bf16_k7_kernel<true> issues 8 B-fragment reads + 1 A read per 8 MFMAs and a weight phase (stage + barrier) per dz plane.  The B
+// fragment of voxel row (x, y) for tap (dx, dy, dz) IS the fragment of row (x, y + 1) for tap (dx, dy - 1, dz): with the k groups made of
+// (dx, dz) slots only (bf16_common.h: se_k7r_slot; 14 groups of 4 slots for the 49 combinations) a wave reads the 10 halo rows of an
+// x once per group and uses row r for every (y, dy) with y + dy = r: 20 B reads per 56 MFMAs (0.36 per MFMA instead of 1.0) for 8 %
+// more MFMAs (56 slots per dy instead of 52 per dz).  The seven weight fragments of a k group come straight from global memory one
+// group ahead (the same 7 KB for every wave of the launch: cache hits) - no weight image in LDS, no barrier inside an octet.
+// 33 -> 16 @64^3, B = 32 (tools/diag/bf16_ab.py): dz-phase kernel 3.06-3.13 ms; this walk with the weights staged through LDS (a
+// barrier and an exposed load per group) 3.02; weights from global 2.67-2.82.  Knock-outs of this form: no halo staging after the
+// first octet 2.36, no weight loads 2.49, no B reads 2.39, none of the three 2.21 = the MFMA stream at the clock it gets.
+// ------------------------------------------------------------------------------------------------
+constexpr int K7R_LDS_BYTES = K7Geo<true>::HALO_BYTES;   // 53760: the halo of one octet; two workgroups per CU
+
+__global__ __launch_bounds__(256, 2) void conv_bf16_k7r_kernel(ConvBArgs a, int tiles_x, int tiles_y, int tiles_z) {
+    using G = K7Geo<true>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* halo = lds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int v = lane & 15, g = lane >> 4;
+    const int D = a.dim;
+    const int octs = a.nchunk;
+    int t = blockIdx.x;
+    const int tz = t % tiles_z; t /= tiles_z;
+    const int ty = t % tiles_y; t /= tiles_y;
+    const int tx = t % tiles_x;
+    const int b = t / tiles_x;
+    const int x0 = tx * G::TX, y0 = ty * G::TY, z0 = tz * G::TZ;
+    const long long N = (long long)D * D * D;
+    const unsigned short* inb = a.in + (long long)b * octs * N * 8;
+    // section R behind section A (cout <= 16: one cout tile): [octet][q][dy][lane][8]; a k group's seven fragments come straight from
+    // global memory (every wave of the launch reads the same 7 KB per group: L2 / vector-cache hits), one group ahead of their use
+    const unsigned short* wr = a.wpack + (size_t)a.ksteps * 512 + lane * 8;
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto halo_load = [&](u16x8 (&hreg)[G::HP], const unsigned short* plane) {
+#pragma unroll
+        for (int j = 0; j < G::HP; ++j) {
+            const int i = tid + 256 * j;
+            const int hz = i % G::HZ, hy = (i / G::HZ) % G::HY, hx = i / (G::HZ * G::HY);
+            const int gx = x0 + hx - 3, gy = y0 + hy - 3, gz = z0 + hz - 3;
+            const bool ok = i < G::PIECES && (unsigned)gx < (unsigned)D && (unsigned)gy < (unsigned)D && (unsigned)gz < (unsigned)D;
+            const u16x8 val = *reinterpret_cast<const u16x8*>(plane + (ok ? ((gx * D + gy) * D + gz) * 8 : 0));
+            hreg[j] = ok ? val : zero8();
+        }
+    };
+    auto halo_commit = [&](const u16x8 (&hreg)[G::HP]) {
+#pragma unroll
+        for (int j = 0; j < G::HP; ++j) {
+            const int i = tid + 256 * j;
+            const int hz = i % G::HZ, hy = (i / G::HZ) % G::HY, hx = i / (G::HZ * G::HY);
+            if (i < G::PIECES) *reinterpret_cast<u16x8*>(halo + ((hx * G::HY + hy) * K7_P + hz) * 16) = hreg[j];
+        }
+    };
+    auto a_load = [&](u16x8 (&A)[7], int ph) {
+        const unsigned short* src = wr + (size_t)ph * 7 * 512;
+#pragma unroll
+        for (int dy = 0; dy < 7; ++dy) A[dy] = *reinterpret_cast<const u16x8*>(src + dy * 512);
+    };
+    // rows (xi, r), r = 0..9: fragment of halo row r of x = 2 w + xi; used by the tiles y = r - dy, 0 <= y < 4, 0 <= dy < 7
+    auto group = [&](const u16x8 (&A)[7], int q) {
+        int dx, dz;
+        se_k7r_slot(4 * q + g, dx, dz);
+        // lane base: halo row (x = 2 w, y = 0) of the tile, column z = v, + the slot's (dx, dz)
+        const unsigned char* bp = halo + (((2 * w + dx) * G::HY) * K7_P + v + dz) * 16;
+        constexpr int AH = 1;                         // rows of B fragments in flight ahead of the MFMAs (3 and 6 measured the same)
+        u16x8 Br[AH + 1];
+#pragma unroll
+        for (int i = 0; i < AH; ++i) Br[i] = lds_read16(bp + (((i / 10) * G::HY + i % 10) * K7_P) * 16);
+#pragma unroll
+        for (int rr = 0; rr < 20; ++rr) {
+            const int xi = rr / 10, r = rr % 10;
+            if (rr + AH < 20) Br[(rr + AH) % (AH + 1)] = lds_read16(bp + ((((rr + AH) / 10) * G::HY + (rr + AH) % 10) * K7_P) * 16);
+#pragma unroll
+            for (int dy = 0; dy < 7; ++dy) {
+                const int y = r - dy;
+                if (y >= 0 && y < 4) acc[xi * 4 + y] = mfma_bf16(A[dy], Br[rr % (AH + 1)], acc[xi * 4 + y]);
+            }
+        }
+    };
+
+    u16x8 hreg[G::HP], A0[7], A1[7];
+    halo_load(hreg, inb);
+    a_load(A0, 0);
+    const int phases = octs * SE_K7R_GROUPS;
+    for (int c = 0; c < octs; ++c) {
+        __syncthreads();                      // previous octet fully consumed
+        halo_commit(hreg);
+        __syncthreads();
+        for (int q = 0; q < SE_K7R_GROUPS; q += 2) {      // two groups per iteration: the fragment sets A0 / A1 alternate
+            const int ph = c * SE_K7R_GROUPS + q;
+            a_load(A1, ph + 1);
+            group(A0, q);
+            if (q == SE_K7R_GROUPS - 2 && c + 1 < octs) halo_load(hreg, inb + (long long)(c + 1) * N * 8);   // in flight under the last group
+            a_load(A0, ph + 2 < phases ? ph + 2 : ph);
+            group(A1, q + 1);
+        }
+    }
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.bpack + 4 * g);
+    const bool relu = a.flags & SE_EPI_RELU;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int x = x0 + G::tx(w, n), y = y0 + G::ty(n, v), z = z0 + G::tz(v);
+        const long long ovox = (((long long)b * D + x) * D + y) * D + z;
+        f32x4 r = acc[n] + bias4;
+        if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        u16x4 o;
+        o[0] = f2bf(r.x); o[1] = f2bf(r.y); o[2] = f2bf(r.z); o[3] = f2bf(r.w);
+        *reinterpret_cast<u16x4*>(a.out + ovox * 16 + 4 * g) = o;
+    }
+}
+
+static int launch_k7r(const ConvBArgs& a, int batch, hipStream_t s) {
+    using G = K7Geo<true>;
+    SE_ENSURE_LDS(conv_bf16_k7r_kernel, K7R_LDS_BYTES);
+    const int tx = a.dim / G::TX, ty = a.dim / G::TY, tz = a.dim / G::TZ;
+    hipLaunchKernelGGL(conv_bf16_k7r_kernel, dim3((unsigned)(batch * tx * ty * tz)), dim3(256), K7R_LDS_BYTES, s, a, tx, ty, tz);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
 template <bool ROW16>
 int launch_k7(const ConvBArgs& a, int batch, hipStream_t s) {
     using G = K7Geo<ROW16>;
@@ -455,7 +581,8 @@ int se_conv3d_bf16_tiled_try(const ConvBArgs& a, int batch, int ksize, hipStream
         return g_variant == 4 ? launch_k3<4>(a, batch, s) : launch_k3<8>(a, batch, s);   // 4: tile 4x4x16, 3 workgroups per CU (A/B)
     if (ksize == 7 && a.dim % 8 == 0 && a.cout == 16 && a.kpc == SE_K7B_KPC && !epi_has_res_host(a) &&
         (long long)a.dim * a.dim * a.dim * 8 < (1LL << 31)) {
-        return (a.dim % 16 == 0 && g_variant != 1) ? launch_k7<true>(a, batch, s) : launch_k7<false>(a, batch, s);
+        if (a.dim % 16 == 0 && g_variant != 1) return g_variant == 5 ? launch_k7<true>(a, batch, s) : launch_k7r(a, batch, s);   // 5: the dz-phase form (A/B)
+        return launch_k7<false>(a, batch, s);
     }
     return SE_TILED_NOT_TAKEN_B;
 }

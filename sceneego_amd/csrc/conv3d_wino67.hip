@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512) void conv3d_k7_wino67_kernel(ConvArgs a, int t
     f32x4 y[S_TZ];
 #pragma unroll
     for (int i = 0; i < S_TZ; ++i) y[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int n_items = 0;
+    [[maybe_unused]] int n_items = 0;
     for (;;) {
         ++n_items;
         const bool last_chunk = c == c_hi(half_k) - 1;

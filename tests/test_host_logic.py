@@ -320,6 +320,7 @@ def test_bf16_kernel_lds_reads_are_conflict_free():
     spec.loader.exec_module(m)
     assert m.k3() == 1
     assert m.k7(24, False) == 1 and m.k7(24, True) == 1
+    assert m.k7r(24) == 1               # the row-reuse 7^3 kernel: slot pairs share dz, differ in dx (a multiple of 256 B apart)
     assert m.k7(16, False) > 1          # the naive pitch is not conflict-free: the padding is what buys it
 
 

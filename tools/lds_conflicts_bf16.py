@@ -65,7 +65,30 @@ def k7(P=24, row16=False):
     return res
 
 
+def k7r_slot(slot):
+    p = slot >> 1
+    dz, dx = p >> 2, 2 * (p & 3) + (slot & 1)
+    return min(dx, 6), dz
+
+
+def k7r(P=24):
+    """conv_bf16_k7r_kernel (row-reuse form, tile 8x4x16): slot 4q+g = a (dx, dz) pair, the B fragment of halo row (xi, r)."""
+    HY = 10
+    res = 1
+    for q in range(14):
+        for wv in range(4):
+            for rr in range(20):
+                def addr(l):
+                    v, g = l & 15, l >> 4
+                    dx, dz = k7r_slot(4 * q + g)
+                    x = 2 * wv + rr // 10 + dx
+                    return ((x * HY + rr % 10) * P + v + dz) * 16
+                res = max(res, worst(addr))
+    return res
+
+
 if __name__ == "__main__":
+    print("conv_bf16_k7r_kernel (8x4x16 tile, row reuse) z pitch 24: worst pass multiplicity:", k7r())
     print("conv_bf16_k3_kernel  B reads, worst pass multiplicity:", k3())
     for P in (14, 16, 20, 24):
         print(f"conv_bf16_k7_kernel<false> (8x8x8 tile)   z pitch {P}: worst pass multiplicity:", k7(P))
