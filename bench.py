@@ -608,13 +608,16 @@ def config3_extra(net, rank, device, depth_kind):
         ms = prof.get(("conv3d_bf16", 3, 32, 32, 64))
         if ms:
             avg = sum(ms) / len(ms)
-            nbytes = 2.0 * 32 * 64 ** 3 * (32 + 32)                 # bf16 input + output records of one launch (skip reads excluded)
+            # bf16 input + output records of a launch, + the skip tensor for the launches that read one (flags of the profiled pass)
+            det = [f for k, f, _ in _lib.last_launch_detail if k == ("conv3d_bf16", 3, 32, 32, 64)]
+            skip = sum(1 for f in det if f is not None and f & (_lib.EPI_RES_PRE_RELU | _lib.EPI_RES_POST_RELU)) / max(1, len(det))
+            nbytes = 2.0 * 32 * 64 ** 3 * (32 + 32 + 32 * skip)
             flop = 2.0 * 32 * 64 ** 3 * 27 * 32 * 32
             st = {k[1]: statistics.median(v) for k, v in prof.items() if k[0] == "stage"}
             r["roofline"] = {"bound": "hbm", "achieved": round(nbytes / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(nbytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "kernel": f"conv3d 3x3x3 32->32 @64^3 bf16 storage (v_mfma_f32_16x16x32_bf16), B=32, {len(ms) // 3} launches/step",
-                             "avg_launch_ms": round(avg, 4), "bytes_per_launch": nbytes,
+                             "avg_launch_ms": round(avg, 4), "bytes_per_launch": nbytes, "launches_with_skip_tensor_frac": round(skip, 3),
                              "mfma_frac_of_2500": round(flop / (avg * 1e-3) / 2.5e15, 4),
                              "stage_ms": {k: round(v, 3) for k, v in st.items()},
                              "v2v_hbm_frac": round(0.5 * V2V_GB_PER_FRAME[64] * 32 / (st["v2v"] * 1e-3) / HBM_PEAK_GBS, 4) if st.get("v2v") else None}

@@ -6,6 +6,10 @@
 #pragma once
 #include "common.h"
 
+// Workgroup b runs on XCD b % 8 (conv_common.h: se_xcd_walk_index): tile index such that the workgroups of one XCD take consecutive
+// tiles - neighbouring halos meet in one L2 (round 5, tools/diag/bf16_ab.py: 64 -> 64 @32^3 -4 %, 32 -> 32 @64^3 +1 %, forward +0.7 %)
+__device__ __forceinline__ int se_xcd_tile_bf16(int wg, int n_wg) { return (n_wg & 7) == 0 ? (wg & 7) * (n_wg >> 3) + (wg >> 3) : wg; }
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));

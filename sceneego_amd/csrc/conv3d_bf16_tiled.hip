@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, TY == 8 ? 2 : 3) void conv_bf16_k3_kernel(Conv
     const int v = lane & 15, g = lane >> 4;
     const int D = a.dim;
     const int mb = blockIdx.y;
-    int t = blockIdx.x;
+    int t = se_xcd_tile_bf16((int)blockIdx.x, (int)gridDim.x);
     const int tz = t % tiles_z; t /= tiles_z;
     const int ty = t % tiles_y; t /= tiles_y;
     const int tx = t % tiles_x;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, ROW16 ? 2 : 1) void conv_bf16_k7_kernel(ConvBA
     const int v = lane & 15, g = lane >> 4;
     const int D = a.dim;
     const int octs = a.nchunk;
-    int t = blockIdx.x;
+    int t = se_xcd_tile_bf16((int)blockIdx.x, (int)gridDim.x);
     const int tz = t % tiles_z; t /= tiles_z;
     const int ty = t % tiles_y; t /= tiles_y;
     const int tx = t % tiles_x;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_k7r_kernel(ConvBArgs a, int 
     const int v = lane & 15, g = lane >> 4;
     const int D = a.dim;
     const int octs = a.nchunk;
-    int t = blockIdx.x;
+    int t = se_xcd_tile_bf16((int)blockIdx.x, (int)gridDim.x);
     const int tz = t % tiles_z; t /= tiles_z;
     const int ty = t % tiles_y; t /= tiles_y;
     const int tx = t % tiles_x;
