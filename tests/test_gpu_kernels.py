@@ -1103,3 +1103,30 @@ def test_wino44pp_and_wino67_repeat_launches_bit_identical():
             first = out7.clone()
         else:
             assert torch.equal(out7, first), f"wino67 launch {i} differs"
+    # round 5: the chunk-half split of the same kernel at batch 1 (two workgroups per tile + k7_combine_kernel through the workspace) and the
+    # LDS-halo kernel of the 4096-voxel levels (8 waves' partial sums meet in LDS in wave order): both deterministic by construction
+    ws = torch.empty(dim ** 3 * 16, device=DEV)
+    x7s = x7p[:1].contiguous()
+    out7s = torch.empty(1, dim, dim, dim, 16, device=DEV)
+    first = None
+    for i in range(20):
+        out7s.fill_(float(i))
+        ws.fill_(float(-i))
+        _lib.conv3d(x7s, pc7.w, pc7.b, None, out7s, 1, dim, 33, 48, 16, 7, _lib.EPI_RELU | _lib.IN_PLANAR3, ws)
+        if first is None:
+            first = out7s.clone()
+        else:
+            assert torch.equal(out7s, first), f"split wino67 launch {i} differs"
+    convh, bnh = _conv_bn(128, 128, 3, 93)
+    pch = _PackedConv(convh.to(DEV), bnh.to(DEV))
+    xh = torch.randn(8, 8, 8, 8, 128, device=DEV)
+    rh = torch.randn(8, 8, 8, 8, 128, device=DEV)
+    outh = torch.empty_like(xh)
+    first = None
+    for i in range(20):
+        outh.fill_(float(i))
+        _lib.conv3d(xh, pch.w, pch.b, rh, outh, 8, 8, 128, 128, 128, 3, _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU)
+        if first is None:
+            first = outh.clone()
+        else:
+            assert torch.equal(outh, first), f"halo64 launch {i} differs"
