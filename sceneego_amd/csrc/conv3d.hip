@@ -433,8 +433,8 @@ __global__ __launch_bounds__(256) void deconv3d_k2s2_kernel(ConvArgs a) {
                     f32x4 ra = odd ? a1 : a0, rb = odd ? b1 : b0;
                     const long long qo = (((((long long)vb[m] * (a.cout >> 2) + n * 4 + h) * odim + oz) * odim + oy) * odim + ox0) * 4;
                     if constexpr (RESQ) {       // quad-planar skip tensor: the records this lane stores
-                        ra += *reinterpret_cast<const f32x4*>(a.res + qo);
-                        rb += *reinterpret_cast<const f32x4*>(a.res + qo + 64);
+                        ra += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.res + qo));          // the skip tensor: read once
+                        rb += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.res + qo + 64));
                     }
                     float* o = a.out + qo;
                     *reinterpret_cast<f32x4*>(o) = ra;

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino2d_kernel(ConvArgs a, const
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int z = 0; z < 4; ++z) resv[r][z] = *reinterpret_cast<const f32x4*>(rb + z * rzstride + r * rystride + rvoff);
+            for (int z = 0; z < 4; ++z) resv[r][z] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rb + z * rzstride + r * rystride + rvoff));   // read once
     };
     auto epilogue = [&](const Unit& u, const f32x4 (&resv_all)[2][4], const f32x4& bias_e) {
         // uniform 64-bit base of the wave's first output row + a 32-bit per-lane offset (global_* saddr form); raw buffer

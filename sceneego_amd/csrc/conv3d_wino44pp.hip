@@ -424,6 +424,11 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
     // Raw buffer loads, issued for EVERY tile: without a skip tensor the descriptor has zero records and the loads return zeros
     // without touching memory - no run-time condition around the 16 loads or the 16 adds (with one, hipcc kept the skip registers
     // live on the path that never loads them and spilled 44 registers per wave).
+    // the skip tensor is read once, by this launch: non-temporal loads (aux 2).  Round 5, tools/ab_libs.py: 32->32 @64^3 0.3792 -> 0.3682 ms,
+    // 64->64 @32^3 0.1754 -> 0.1714 in isolation; inside the forward 0.3292 -> 0.3269 ms per launch; non-temporal output STORES: nothing (+0.2 %)
+#ifndef SE_K44P_RES_AUX
+#define SE_K44P_RES_AUX 2
+#endif
     const int rk_ys = dim * 16, rk_zs = dim * dim * 16;
     auto load_rv = [&](f32x4 (&rv)[4][4], const gfloat* rb) {
         int l = lane;
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
         for (int y = 0; y < 4; ++y)
 #pragma unroll
             for (int z = 0; z < 4; ++z)
-                rv[y][z] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, r_lane * 4, (skc ? z * rk_zs + y * rk_ys : z * r_zs + y * r_ys) * 4, 0));
+                rv[y][z] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, r_lane * 4, (skc ? z * rk_zs + y * rk_ys : z * r_zs + y * r_ys) * 4, SE_K44P_RES_AUX));
     };
     // Part 1 (staging half 1, behind pass 1; the other group is in the first half of its MFMA phase): the first half of the skip
     // tensor goes out, the output transform along y runs IN PLACE in the accumulator registers - xi_z by xi_z,
