@@ -218,6 +218,29 @@ int se_voxelize_planar3_f64(const float* depth, const double* ray_tab, float* bu
                             int triplets_total, int channel, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The 7x7x7 front layer in the frequency domain (round 6; csrc/conv3d_fft7.hip).  Same reference call site as se_conv3d_f32 with
+ * ksize 7: Basic3DBlock(33 -> 16, 7) = Conv3d(k 7, pad 3) + BatchNorm3d + ReLU, network/v2v.py:8-18 (built :147, run :166).
+ * Three launches per chunk of samples: a 24^3 real-to-complex DFT of every (16^3-output tile, input channel), one complex GEMM over the
+ * channels per frequency on the matrix cores, the inverse DFT of every (tile, output channel) with bias and ReLU.  float32 throughout;
+ * results differ from the direct convolution by float32 rounding of the transforms (~1e-6 of max|y|).
+ *   in   PLANAR float32 [B][cin][D][D][D]  (se_unproject_gather_planar1_f32 / se_voxelize_planar1_f64 write it)
+ *   out  channels-last [B][D][D][D][16], or with SE_OUT_QUAD quad-planar [B][4][D][D][D][4]; flags: SE_EPI_RELU, SE_OUT_QUAD only
+ *   hfrag  se_conv3d_k7_fft_packed_elems(cin, cout) floats from se_conv3d_k7_fft_pack_f32: the weight spectra (BatchNorm scale folded
+ *          in: gamma / var / eps as for se_conv3d_pack_f32, NULL = no BatchNorm) in MFMA fragment order;  bpack: the folded bias that
+ *          se_conv3d_pack_f32 writes (16 floats)
+ *   workspace  the spectra of one chunk of samples: se_conv3d_k7_fft_workspace_elems(n, dim, cin) floats hold n samples (0.19 GB per
+ *          sample at 64^3); the call walks the batch in chunks of as many samples as the workspace holds (>= 1, else SE_ERR_BAD_ARG).
+ *          A workspace serves one stream at a time.
+ * Shapes: cin = 33, cout = 16, dim % 16 == 0; the *_elems functions return -1 and the calls SE_ERR_BAD_ARG for anything else
+ * (se_conv3d_f32 serves those). */
+long long se_conv3d_k7_fft_packed_elems(int cin, int cout);
+int se_conv3d_k7_fft_pack_f32(const float* w, const float* gamma, const float* var, float eps, float* hfrag, int cout, int cin,
+                              void* stream);
+long long se_conv3d_k7_fft_workspace_elems(int batch, int dim, int cin);
+int se_conv3d_k7_fft_f32(const float* in, const float* hfrag, const float* bpack, float* out, int batch, int dim, int cin, int cout,
+                         int flags, float* workspace, long long workspace_elems, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * bf16-storage V2V (BASELINE config 3): activations and weights bfloat16 in HBM, float32 accumulation on
  * v_mfma_f32_16x16x32_bf16, float32 bias / BN shift, one round-to-nearest-even to bfloat16 per layer output.
  * Same reference call sites as the _f32 entry points above; `se_bf16` is the raw 16-bit pattern.

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -67,6 +67,10 @@ SIGNATURES = {
     "se_bias_act_nchw_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_conv3d_f32_algo": (_i, [_i, _i, _i, _i]),
     "se_conv3d_f32_variant": (_i, [_i, _i, _i, _i, _i, _i]),
+    "se_conv3d_k7_fft_packed_elems": (_ll, [_i, _i]),
+    "se_conv3d_k7_fft_pack_f32": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
+    "se_conv3d_k7_fft_workspace_elems": (_ll, [_i, _i, _i]),
+    "se_conv3d_k7_fft_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
     "se_conv3d_split3_packed_elems": (_ll, [_i, _i]),
     "se_conv3d_split3_pack": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "se_conv3d_k3_split3_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -403,6 +407,39 @@ def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksi
     if _prof is not None:
         e1.record()
         _prof.append((("conv3d" if inp.dtype == torch.float32 else "conv3d_bf16", ksize, cin_pad, cout, dim), e0, e1, flags))
+
+
+def conv3d_k7_fft_supported(dim, cin, cout) -> bool:
+    """Shapes the frequency-domain form of the 7x7x7 layer covers (se_conv3d_k7_fft_f32)."""
+    return dim >= 16 and dim % 16 == 0 and int(load().se_conv3d_k7_fft_packed_elems(cin, cout)) > 0
+
+
+def conv3d_k7_fft_pack(w, gamma, var, eps, cout, cin):
+    """Conv3d weight [cout][cin][7][7][7] (+ the BatchNorm3d scale) -> its spectra in MFMA fragment order (se_conv3d_k7_fft_pack_f32)."""
+    require_hip(w)
+    _chk_f32(w, gamma, var)
+    n = int(load().se_conv3d_k7_fft_packed_elems(cin, cout))
+    if n <= 0:
+        raise HipExtensionError(f"frequency-domain 7x7x7 convolution does not cover cin={cin} cout={cout}")
+    out = torch.empty(n, device=w.device, dtype=torch.float32)
+    _check(load().se_conv3d_k7_fft_pack_f32(_ptr(w), _ptr(gamma), _ptr(var), float(eps), _ptr(out), cout, cin, _stream()),
+           "se_conv3d_k7_fft_pack_f32")
+    return out
+
+
+def conv3d_k7_fft_workspace_elems(batch, dim, cin) -> int:
+    return int(load().se_conv3d_k7_fft_workspace_elems(batch, dim, cin))
+
+
+def conv3d_k7_fft(inp, hfrag, bpack, out, batch, dim, cin, cout, flags, workspace):
+    """``inp`` planar [B, cin, D, D, D]; ``out`` channels-last [B, D, D, D, 16] or (OUT_QUAD) quad-planar [B, 4, D, D, D, 4];
+    ``workspace``: float32 scratch for the spectra of >= 1 sample (conv3d_k7_fft_workspace_elems); one stream at a time."""
+    require_hip(inp, hfrag, bpack, out, workspace)
+    _chk_f32(inp, hfrag, bpack, out, workspace)
+    assert inp.numel() == batch * cin * dim ** 3 and out.numel() == batch * cout * dim ** 3
+    with _timed(("conv3d_fft", 7, cin, cout, dim), flags):
+        _check(load().se_conv3d_k7_fft_f32(_ptr(inp), _ptr(hfrag), _ptr(bpack), _ptr(out), batch, dim, cin, cout, flags,
+                                           _ptr(workspace), workspace.numel(), _stream()), "se_conv3d_k7_fft_f32")
 
 
 def conv3d_split3_pack(w_folded, cout, cin, cin_pad):

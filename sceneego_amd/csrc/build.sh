@@ -16,12 +16,12 @@ OBJ=_obj/$KEY
 mkdir -p "$OBJ"
 pids=()
 newer() {  # source $1, a shared header or (development builds) a devtools/ include newer than object $2
-  [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ common.h -nt "$2" ] || [ conv_common.h -nt "$2" ] || [ bf16_common.h -nt "$2" ] || [ wino67_matrices.h -nt "$2" ] || [ ../../include/sceneego_hip.h -nt "$2" ] && return 0
+  [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ common.h -nt "$2" ] || [ conv_common.h -nt "$2" ] || [ bf16_common.h -nt "$2" ] || [ wino67_matrices.h -nt "$2" ] || [ fft24.h -nt "$2" ] || [ ../../include/sceneego_hip.h -nt "$2" ] && return 0
   if [ -n "$DEV" ]; then for i in devtools/*.inc; do [ "$i" -nt "$2" ] && return 0; done; fi
   return 1
 }
 OBJS=()
-for f in voxelize gather softargmax conv3d conv3d_tiled conv3d_wino conv3d_wino2d conv3d_wino44pp conv3d_wino67 conv3d_bf16 conv3d_bf16_tiled conv3d_split; do
+for f in voxelize gather softargmax conv3d conv3d_tiled conv3d_wino conv3d_wino2d conv3d_wino44pp conv3d_wino67 conv3d_fft7 conv3d_bf16 conv3d_bf16_tiled conv3d_split; do
   [ -f $f.hip ] || { echo "build.sh: source $f.hip is missing" >&2; exit 1; }
   OBJS+=($OBJ/$f.o)
   extra=""
