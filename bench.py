@@ -238,6 +238,9 @@ def launch_flops(lib, key, flags, batch):
             return direct, ex, var
         direct = 2.0 * vox * cin * cout
         return direct, direct, 0
+    if kind == "conv3d_fft":                                # the 7^3 front layer in the frequency domain (csrc/conv3d_fft7.hip): what the
+        direct = 2.0 * vox * 343 * cin * cout               # matrix cores execute is pass 2, a real GEMM [M x 68] . [68 x 32] per frequency
+        return direct, 2.0 * batch * (dim // 16) ** 3 * 68 * 32 * 7488, 70
     if kind == "deconv":                                    # k2s2 transposed convolution: 8 output voxels per input voxel
         direct = 2.0 * vox * 8 * cin * cout
         return direct, direct, 0
@@ -445,7 +448,8 @@ def main():
                           f"({per_var[v]['ms'] / per_var[v]['launches']:.4f} ms, executed/direct {K3_ALGOS.get(v, K3_ALGOS[0])[1]:.3f})"
                           for v in sorted(per_var, key=lambda v: -per_var[v]["launches"]))
         ach = exec_flop / (avg_ms * 1e-3) / 1e12
-        k7 = [v for k, v in launches.items() if k[0] == "conv3d" and k[1] == 7]
+        k7 = [v for k, v in launches.items() if k[0] in ("conv3d", "conv3d_fft") and k[1] == 7]
+        k7_fft = [k for k in launches if k[0] == "conv3d_fft"]
         # algorithmic bytes of a launch: input read + output written once + the skip tensor where the launch has one (its own flags:
         # SE_EPI_RES_PRE_RELU = 2; the fused 16-channel skip convolution, 256, reads half a tensor), mean over the launches of the shape
         per_launch_bytes = [4.0 * args.batch * G ** 3 * (32 + 32 + (16 if (fl_ or 0) & 256 else 32 if (fl_ or 0) & 2 else 0))
@@ -486,11 +490,26 @@ def main():
                       "v2v_executed_frac": round(v2v_exec / (stage_ms["v2v"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)
                       if stage_ms.get("v2v") else None,
                       "v2v_executed_frac_what": "executed matrix-core FLOP of every V2V launch of the timing pass (3^3 at their kernels' ratios, "
-                                                "7^3 at 12/42, 1^3 / transposed / fused tail as is) / stage_ms.v2v / the f32 MFMA peak",
+                                                "7^3: the per-frequency GEMM of the frequency-domain form, or 12/42 on the Winograd kernel; 1^3 / transposed / fused tail "
+                                                "as is) / stage_ms.v2v / the f32 MFMA peak",
                       "v2v_hbm_frac": round(V2V_GB_PER_FRAME.get(G, 0) * args.batch / (stage_ms["v2v"] * 1e-3) / HBM_PEAK_GBS, 4)
                       if stage_ms.get("v2v") else None,
                       "conv7_avg_ms": round(sum(k7[0]) / len(k7[0]), 4) if k7 else None},
         }
+        if k7_fft and k7:
+            # the frequency-domain front layer is three HBM-bound passes: bytes = input + spectra X (written, read) + Y (written, read) +
+            # weight spectra + output (csrc/conv3d_fft7.hip header; tools/fft7_model.py prints the same model)
+            m_tiles = args.batch * (G // 16) ** 3
+            fbytes = 4.0 * args.batch * G ** 3 * (33 + 16) + 2.0 * m_tiles * (33 + 16) * 7488 * 8 + 7488 * 17 * 128 * 4.0
+            f_ms = sum(k7[0]) / len(k7[0])
+            line["roofline"]["front_layer"] = {
+                "kernel": "7x7x7 33->16 in the frequency domain: fft7_fwd_kernel + fft7_gemm_kernel<33> + fft7_inv_kernel (one se_conv3d_k7_fft_f32 call)",
+                "bound": "hbm", "avg_call_ms": round(f_ms, 4), "bytes_per_call": fbytes,
+                "achieved_gbs": round(fbytes / (f_ms * 1e-3) / 1e9, 1), "frac": round(fbytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "executed_gflop_per_call": round(2.0 * m_tiles * 68 * 32 * 7488 / 1e9, 2),
+                "direct_gflop_per_call": round(2.0 * args.batch * G ** 3 * 343 * 33 * 16 / 1e9, 1),
+                "what": "bytes = input + output + the float32 complex spectra X (33 ch) and Y (16 ch) of every 24^3 tile written once and read "
+                        "once + the weight spectra; the F(6,7) Winograd kernel it replaces (SCENEEGO_FFT7=0) executed 217 GFLOP at B=8"}
     keyb = ("conv3d_bf16", 3, 32, 32, G)
     if keyb in launches:
         ms = launches[keyb]

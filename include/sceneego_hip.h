@@ -154,7 +154,8 @@ int se_conv3d_pool_f32(const float* in, const float* wpack, const float* bpack, 
 /* 3x3x3 convolution + folded BN with the Res3DBlock's 1x1x1 skip convolution computed in the same launch (reference
  * network/v2v.py:21-43: res_branch's second convolution and skip_con of a block whose channel count changes):
  *     out = act( conv3(in; wpack) + skip_w . skip_in + bpack )
- * `skip_in` is the block input, 16 channels, channels-last [B][D][D][D][16]; `skip_w` its BN-folded weights [cout][16];
+ * `skip_in` is the block input, 16 channels, channels-last [B][D][D][D][16] - or, with SE_RES_QUAD beside SE_IN_QUAD | SE_OUT_QUAD,
+ * quad-planar [B][4][D][D][D][4] (what se_conv3d_k7_fft_f32 writes with SE_OUT_QUAD); `skip_w` its BN-folded weights [cout][16];
  * `bpack` must hold the SUM of both folded biases.  2-D Winograd shapes (se_conv3d_f32_algo() == 2) with octet-planar `in`
  * and `out` only (flags must carry SE_IN_OCTET | SE_OUT_OCTET, or SE_IN_QUAD | SE_OUT_QUAD where se_conv3d_f32_variant(..., those
  * flags) == 3; SE_EPI_RELU optional); SE_ERR_BAD_ARG otherwise.  Saves the
@@ -216,6 +217,16 @@ int se_unproject_gather_planar3_f32(const float* feat, const int* idx, const flo
 int se_voxelize_planar3_f64(const float* depth, const double* ray_tab, float* buf, int batch, int depth_h, int depth_w,
                             int up, int pad_x, int volume_size, double cuboid_side,
                             int triplets_total, int channel, void* stream);
+
+/* Producers of the fully PLANAR float32 V2V input [B][planes_total][voxels] (round 6: what se_conv3d_k7_fft_f32 reads).  Same
+ * arithmetic, bit for bit, as se_unproject_gather_f32 / se_voxelize_strided_f64.  The gather writes planes [0, channels) (channels = 16,
+ * 32 or 64) and ZEROES planes [channels, planes_total); se_voxelize_planar1_f64 then only scatters 1.0 into plane `channel` (call it
+ * after the gather, with `channel` in that cleared range: 32 for 32 feature channels).  Reference call sites as for the planar3 pair. */
+int se_unproject_gather_planar1_f32(const float* feat, const int* idx, const float* w, float* out,
+                                    int batch, int texels, int channels, int voxels, int planes_total, void* stream);
+int se_voxelize_planar1_f64(const float* depth, const double* ray_tab, float* buf, int batch, int depth_h, int depth_w,
+                            int up, int pad_x, int volume_size, double cuboid_side,
+                            int planes_total, int channel, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The 7x7x7 front layer in the frequency domain (round 6; csrc/conv3d_fft7.hip).  Same reference call site as se_conv3d_f32 with

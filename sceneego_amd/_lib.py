@@ -39,6 +39,8 @@ SIGNATURES = {
     "se_unproject_gather_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "se_unproject_gather_planar3_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_voxelize_planar3_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _i, _i, _vp]),
+    "se_unproject_gather_planar1_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_voxelize_planar1_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "se_intersection_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "se_bias_act_nchw_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_deconv2d_k4s2_assemble_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -200,6 +202,17 @@ def voxelize_planar3(depth, ray_tab, buf, batch, depth_h, depth_w, up, pad_x, vo
            "se_voxelize_planar3_f64")
 
 
+def voxelize_planar1(depth, ray_tab, buf, batch, depth_h, depth_w, up, pad_x, volume_size, cuboid_side, planes_total, channel):
+    """Scatter the occupancy into plane `channel` of a planar float32 buffer [B, planes_total, G^3] (cleared by unproject_gather_planar1)."""
+    require_hip(depth, ray_tab, buf)
+    _chk_f32(depth, buf)
+    assert ray_tab.dtype == torch.float64 and ray_tab.is_contiguous()
+    assert buf.numel() == batch * planes_total * volume_size ** 3
+    _check(load().se_voxelize_planar1_f64(_ptr(depth), _ptr(ray_tab), _ptr(buf), batch, depth_h, depth_w, up, pad_x,
+                                          volume_size, float(cuboid_side), planes_total, channel, _stream()),
+           "se_voxelize_planar1_f64")
+
+
 def voxelize_full(depth, ray_tab, occ, batch, depth_h, depth_w, volume_size, cuboid_side):
     require_hip(depth, ray_tab, occ)
     _chk_f32(depth, occ)
@@ -240,6 +253,15 @@ def unproject_gather_planar3(feat, idx, w, out, batch, texels, channels, voxels,
     assert out.numel() == batch * triplets_total * voxels * 3
     _check(load().se_unproject_gather_planar3_f32(_ptr(feat), _ptr(idx), _ptr(w), _ptr(out), batch, texels, channels,
                                                   voxels, triplets_total, _stream()), "se_unproject_gather_planar3_f32")
+
+
+def unproject_gather_planar1(feat, idx, w, out, batch, texels, channels, voxels, planes_total):
+    require_hip(feat, idx, w, out)
+    _chk_f32(feat, w, out)
+    assert idx.dtype == torch.int32 and idx.is_contiguous()
+    assert out.numel() == batch * planes_total * voxels
+    _check(load().se_unproject_gather_planar1_f32(_ptr(feat), _ptr(idx), _ptr(w), _ptr(out), batch, texels, channels,
+                                                  voxels, planes_total, _stream()), "se_unproject_gather_planar1_f32")
 
 
 def intersection(buf, occ, batch, voxels, channels, stride_c):
@@ -466,11 +488,14 @@ def conv3d_k3_split3(inp, wsplit, bpack, residual, out, batch, dim, cin_pad, cou
 
 
 def conv3d_skip16(inp, wpack, bpack_sum, skip_in, skip_w, out, batch, dim, cin, cout, flags):
-    """3x3x3 convolution (2-D Winograd kernel, octet-planar in / out) + the block's 1x1x1 skip convolution over the 16-channel
-    channels-last ``skip_in`` in one launch (se_conv3d_skip16_f32); ``bpack_sum`` = sum of both folded biases."""
+    """3x3x3 convolution (2-D Winograd kernels, planar in / out) + the block's 1x1x1 skip convolution over the 16-channel ``skip_in``
+    (channels-last, or quad-planar with RES_QUAD on the quad family) in one launch (se_conv3d_skip16_f32); ``bpack_sum`` = sum of both
+    folded biases."""
     require_hip(inp, out, skip_in, skip_w, bpack_sum)
     _chk_f32(inp, out, skip_in, skip_w, bpack_sum)
-    assert skip_in.shape[-1] == 16 and tuple(skip_w.shape) == (cout, 16) and skip_w.is_contiguous() and skip_in.is_contiguous()
+    # skip_in: channels-last [B, D, D, D, 16], or with RES_QUAD quad-planar [B, 4, D, D, D, 4]
+    assert skip_in.numel() == batch * dim ** 3 * 16 and skip_in.shape[-1] == (4 if flags & RES_QUAD else 16)
+    assert tuple(skip_w.shape) == (cout, 16) and skip_w.is_contiguous() and skip_in.is_contiguous()
     with _timed(("conv3d", 3, cin, cout, dim), flags | 256):        # 256 = SE_EPI_SKIPCONV16 (the entry point sets it)
         _check(load().se_conv3d_skip16_f32(_ptr(inp), _ptr(wpack), _ptr(bpack_sum), _ptr(skip_in), _ptr(skip_w), _ptr(out), batch,
                                            dim, cin, cout, flags, _stream()), "se_conv3d_skip16_f32")

@@ -1293,7 +1293,7 @@ extern "C" int se_conv3d_skip16_f32(const float* in, const float* wpack, const f
                                     void* stream) {
     if (!skip_in || !skip_w) return SE_ERR_BAD_ARG;
     const int lay = flags & ~SE_EPI_RELU;
-    if (lay != (SE_IN_OCTET | SE_OUT_OCTET) && lay != (SE_IN_QUAD | SE_OUT_QUAD)) return SE_ERR_BAD_ARG;
+    if (lay != (SE_IN_OCTET | SE_OUT_OCTET) && lay != (SE_IN_QUAD | SE_OUT_QUAD) && lay != (SE_IN_QUAD | SE_OUT_QUAD | SE_RES_QUAD)) return SE_ERR_BAD_ARG;
     return conv3d_f32_impl(in, wpack, bpack, skip_in, out, nullptr, skip_w, batch, dim, cin, cin, cout, 3,
                            flags | SE_EPI_SKIPCONV16, nullptr, 0, stream);
 }

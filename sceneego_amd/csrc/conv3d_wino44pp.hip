@@ -168,7 +168,7 @@ __device__ __forceinline__ void at43p(const f32x4& m0, const f32x4& m1, const f3
 
 // LAYOUT: bit 0 = input QUAD-planar [B][cin/4][D][D][D][4] (SE_IN_QUAD), bit 1 = output quad-planar (SE_OUT_QUAD), bit 2 = skip
 // tensor quad-planar (SE_RES_QUAD), bit 3 = also write the 2x2x2 max-pool of the output (se_conv3d_pool_f32), bit 4 = the skip path
-// is a 1x1x1 convolution over a 16-channel channels-last tensor computed in the epilogue (se_conv3d_skip16_f32).
+// is a 1x1x1 convolution over a 16-channel tensor computed in the epilogue (se_conv3d_skip16_f32): channels-last, or with bit 2 quad-planar.
 // Quad-planar (round 5; rounds 2-4 handed octet-planar tensors [B][C/8][D^3][8] between these launches): a 4-channel step reads WHOLE
 // 16-byte records, 18 of them contiguous per halo row (288 B), instead of half of every 32-byte octet record - that half was the
 // 1.57 x of the counter traffic over the algorithmic bytes; an MFMA D fragment (4 couts of a voxel per lane) is
@@ -416,6 +416,9 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
     auto res_ptr = [&](const UnitP& u) {
         if constexpr (skc) {
             const int gz0 = u.z0 + 4 * zt, gy0 = u.y0 + 4 * G;
+            // the skip convolution's 16-channel input: channels-last [B][D^3][16], or (round 6, bit 2) quad-planar [B][4][D^3][4] - what
+            // the frequency-domain front layer writes: the lane's 4 channels are one record of plane h
+            if constexpr (res_pl) return uniform_ptr(a.res + ((((long long)u.b * 4 * dim + gz0) * dim + gy0) * dim + u.x0) * 4);
             return uniform_ptr(a.res + ((((long long)u.b * dim + gz0) * dim + gy0) * dim + u.x0) * 16);
         } else {
             return tile_base(a.res, u, res_pl);
@@ -429,11 +432,11 @@ __global__ __launch_bounds__(512) void conv3d_k3_wino44pp_kernel(ConvArgs a, con
 #ifndef SE_K44P_RES_AUX
 #define SE_K44P_RES_AUX 2
 #endif
-    const int rk_ys = dim * 16, rk_zs = dim * dim * 16;
+    const int rk_ys = (skc && res_pl) ? dim * 4 : dim * 16, rk_zs = rk_ys * dim;
     auto load_rv = [&](f32x4 (&rv)[4][4], const gfloat* rb) {
         int l = lane;
         asm volatile("" : "+v"(l));
-        const int r_lane = skc ? (l & 15) * 16 + 4 * (l >> 4) : lane_off(res_pl);
+        const int r_lane = skc ? (res_pl ? (l >> 4) * dim * dim * dim * 4 + (l & 15) * 4 : (l & 15) * 16 + 4 * (l >> 4)) : lane_off(res_pl);
         const bool on = (skc || use_res) && !(SE_K44P_EXP & 16);
         const auto rs = __builtin_amdgcn_make_buffer_rsrc((float*)rb, 0, on ? 0x7fffffff : 0, 0x00020000);
 #pragma unroll
@@ -822,8 +825,9 @@ int se_conv3d_wino44pp_launch(const ConvArgs& a, int batch, hipStream_t s) {
     } while (0)
     const int layout = ((a.flags & SE_IN_QUAD) ? 1 : 0) | ((a.flags & SE_OUT_QUAD) ? 2 : 0) | ((a.flags & SE_RES_QUAD) && a.res ? 4 : 0);
     if (a.flags & SE_EPI_SKIPCONV16) {
-        if (layout != 3 || a.pool_out || !a.skip_w || !a.res) return SE_ERR_BAD_ARG;
-        P_LAUNCH(19);
+        if ((layout != 3 && layout != 7) || a.pool_out || !a.skip_w || !a.res) return SE_ERR_BAD_ARG;
+        if (layout == 7) P_LAUNCH(23);      // the 16-channel skip input is quad-planar
+        else P_LAUNCH(19);
         SE_CHECK_LAUNCH();
         return 0;
     }

@@ -80,6 +80,50 @@ __global__ __launch_bounds__(256) void gather_planar3_kernel(const float* __rest
         *reinterpret_cast<f32x3s*>(o + (size_t)t * voxels * 3) = (f32x3s){f[3 * t], f[3 * t + 1], f[3 * t + 2]};
 }
 
+// Fully planar form [B][planes_total][voxels] (round 6: the input of the frequency-domain 7^3 layer, conv3d_fft7.hip, whose tile
+// transform walks one channel at a time): same taps, order and arithmetic as gather_kernel; a wave writes 256 contiguous bytes per
+// channel plane.  Planes [C, planes_total) are written as zero (the occupancy plane: se_voxelize_planar1_f64 only scatters).
+template <int CQ>
+__global__ __launch_bounds__(256) void gather_planar1_kernel(const float* __restrict__ feat, const int4* __restrict__ idx,
+                                                             const f32x4* __restrict__ w, float* __restrict__ out,
+                                                             int texels, int voxels, int planes_total) {
+    constexpr int C = CQ * 4;
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= voxels) return;
+    const int4 id = idx[v];
+    const f32x4 wt = w[v];
+    const float* fb = feat + (size_t)b * texels * C;
+    f32x4 acc[CQ];
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (id.x >= 0) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) acc[q] += *reinterpret_cast<const f32x4*>(fb + (size_t)id.x * C + q * 4) * wt.x;
+    }
+    if (id.y >= 0) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) acc[q] += *reinterpret_cast<const f32x4*>(fb + (size_t)id.y * C + q * 4) * wt.y;
+    }
+    if (id.z >= 0) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) acc[q] += *reinterpret_cast<const f32x4*>(fb + (size_t)id.z * C + q * 4) * wt.z;
+    }
+    if (id.w >= 0) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) acc[q] += *reinterpret_cast<const f32x4*>(fb + (size_t)id.w * C + q * 4) * wt.w;
+    }
+    float* o = out + (size_t)b * planes_total * voxels + v;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+        o[(size_t)(4 * q) * voxels] = acc[q].x;
+        o[(size_t)(4 * q + 1) * voxels] = acc[q].y;
+        o[(size_t)(4 * q + 2) * voxels] = acc[q].z;
+        o[(size_t)(4 * q + 3) * voxels] = acc[q].w;
+    }
+    for (int c = C; c < planes_total; ++c) o[(size_t)c * voxels] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void intersection_kernel(float* __restrict__ buf, const float* __restrict__ occ,
                                                            long long total_vox, int cq, int stride_c) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -121,6 +165,23 @@ extern "C" int se_unproject_gather_planar3_f32(const float* feat, const int* idx
         case 16: hipLaunchKernelGGL(gather_planar3_kernel<4>, grid, dim3(256), 0, s, feat, ip, wp, out, texels, voxels, triplets_total); break;
         case 32: hipLaunchKernelGGL(gather_planar3_kernel<8>, grid, dim3(256), 0, s, feat, ip, wp, out, texels, voxels, triplets_total); break;
         case 64: hipLaunchKernelGGL(gather_planar3_kernel<16>, grid, dim3(256), 0, s, feat, ip, wp, out, texels, voxels, triplets_total); break;
+        default: return SE_ERR_BAD_ARG;
+    }
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int se_unproject_gather_planar1_f32(const float* feat, const int* idx, const float* w, float* out, int batch,
+                                               int texels, int channels, int voxels, int planes_total, void* stream) {
+    if (batch <= 0 || texels <= 0 || voxels <= 0 || channels <= 0 || planes_total < channels) return SE_ERR_BAD_ARG;
+    dim3 grid((unsigned)((voxels + 255) / 256), batch);
+    hipStream_t s = se_stream(stream);
+    const int4* ip = reinterpret_cast<const int4*>(idx);
+    const f32x4* wp = reinterpret_cast<const f32x4*>(w);
+    switch (channels) {
+        case 16: hipLaunchKernelGGL(gather_planar1_kernel<4>, grid, dim3(256), 0, s, feat, ip, wp, out, texels, voxels, planes_total); break;
+        case 32: hipLaunchKernelGGL(gather_planar1_kernel<8>, grid, dim3(256), 0, s, feat, ip, wp, out, texels, voxels, planes_total); break;
+        case 64: hipLaunchKernelGGL(gather_planar1_kernel<16>, grid, dim3(256), 0, s, feat, ip, wp, out, texels, voxels, planes_total); break;
         default: return SE_ERR_BAD_ARG;
     }
     SE_CHECK_LAUNCH();

@@ -135,6 +135,20 @@ extern "C" int se_voxelize_planar3_f64(const float* depth, const double* ray_tab
     return 0;
 }
 
+extern "C" int se_voxelize_planar1_f64(const float* depth, const double* ray_tab, float* buf, int batch, int depth_h,
+                                       int depth_w, int up, int pad_x, int volume_size, double cuboid_side,
+                                       int planes_total, int channel, void* stream) {
+    if (batch <= 0 || depth_h <= 0 || depth_w <= 0 || up <= 0 || volume_size <= 0 || pad_x < 0) return SE_ERR_BAD_ARG;
+    if (planes_total <= 0 || channel < 0 || channel >= planes_total) return SE_ERR_BAD_ARG;
+    // planar [B][planes_total][N]: scatter only - the plane was zeroed by se_unproject_gather_planar1_f32
+    const long long N = (long long)volume_size * volume_size * volume_size;
+    dim3 grid((up * up + 255) / 256, batch);
+    hipLaunchKernelGGL(voxelize_kernel<float>, grid, dim3(256), 0, se_stream(stream), depth, ray_tab, buf, depth_h, depth_w, up, up,
+                       pad_x > 0 ? 1 : 0, volume_size, cuboid_side, 1, (long long)channel * N, (long long)planes_total * N);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int se_voxelize_strided_bf16(const float* depth, const double* ray_tab, se_bf16* buf, int batch, int depth_h,
                                         int depth_w, int up, int pad_x, int volume_size, double cuboid_side,
                                         int octs_total, int c_offset, void* stream) {

@@ -70,18 +70,29 @@ def calculated_ray_direction_numpy(fisheye_model, image_width: int, image_height
     return fisheye_model.camera2world_ray(points.reshape((-1, 2)))
 
 
-def build_gather_table(grid_coord_proj_norm: torch.Tensor, heatmap_shape, feat_hw: int = 64):
+def _nearest_src(dst: torch.Tensor, in_size: int, out_size: int) -> torch.Tensor:
+    """Source index of ``nn.Upsample(mode='nearest')`` (ATen ``nearest_neighbor_compute_source_index``): min(floor(dst * scale), in - 1) with
+    scale = in / out evaluated in float32 (exact for the power-of-two ratios of the 256x256 crop, and the reference's rounding elsewhere)."""
+    scale = torch.tensor(float(in_size), dtype=torch.float32) / torch.tensor(float(out_size), dtype=torch.float32)
+    src = torch.floor(dst.to(torch.float32) * scale).to(torch.int64)
+    return torch.clamp(src, max=in_size - 1)
+
+
+def build_gather_table(grid_coord_proj_norm: torch.Tensor, heatmap_shape, feat_hw=64):
     """Per-voxel 4-tap lookup into the compact feature map.
 
     ``grid_coord_proj_norm`` is [N,2] in grid_sample's normalised coordinates for an image of
     ``heatmap_shape`` = (H=1024, W=1280).  grid_sample(align_corners=True, bilinear, zeros) un-normalises
     ix = (gx+1)/2*(W-1), iy = (gy+1)/2*(H-1) and blends the 4 neighbouring texels; a texel (x,y) of the
-    virtual 1024x1280 image is ``F[y>>s, (x-128)>>s]`` inside the 1024 centre columns and 0 elsewhere
-    (s = log2(1024/feat_hw)).  Returns (idx int32 [N,4], w float32 [N,4]); idx = -1 marks a zero tap.
+    virtual 1024x1280 image is ``F[src(y), src(x-128)]`` inside the 1024 centre columns and 0 elsewhere, src = the nearest-neighbour
+    source index of ``nn.Upsample(size=(1024, 1024))`` for a feature map of ``feat_hw`` = (h, w) (an int means square; the reference
+    upsamples ANY feature-map size, ``network/voxel_net_depth.py:59-60,238``; 64 x 64 for the 256 x 256 crop: src = dst >> 4).
+    Returns (idx int32 [N,4], w float32 [N,4]); idx = fy * w + fx, -1 marks a zero tap.
     """
     H, W = int(heatmap_shape[0]), int(heatmap_shape[1])
-    assert UPSAMPLED % feat_hw == 0
-    scale = UPSAMPLED // feat_hw
+    fh, fw = (int(feat_hw), int(feat_hw)) if isinstance(feat_hw, int) else (int(feat_hw[0]), int(feat_hw[1]))
+    if fh <= 0 or fw <= 0 or H != UPSAMPLED or W != UPSAMPLED + 2 * PAD_X:
+        raise ValueError("gather table: heatmap %dx%d / feature map %dx%d not representable" % (H, W, fh, fw))
     g = grid_coord_proj_norm.detach().to(torch.float32).cpu()
     # same float32 arithmetic as ATen's grid_sampler_unnormalize(align_corners=True): ((g + 1) / 2) * (size - 1)
     ix = ((g[:, 0] + 1) / 2) * (W - 1)
@@ -95,9 +106,9 @@ def build_gather_table(grid_coord_proj_norm: torch.Tensor, heatmap_shape, feat_h
     taps_x = torch.stack([x0, x1, x0, x1], dim=1).to(torch.int64)
     taps_y = torch.stack([y0, y0, y1, y1], dim=1).to(torch.int64)
     inside = (taps_x >= PAD_X) & (taps_x < PAD_X + UPSAMPLED) & (taps_y >= 0) & (taps_y < H)
-    fx = torch.div(taps_x - PAD_X, scale, rounding_mode="floor")
-    fy = torch.div(taps_y * UPSAMPLED // H, scale, rounding_mode="floor")
-    idx = torch.where(inside, fy * feat_hw + fx, torch.full_like(fx, -1)).to(torch.int32)
+    fx = _nearest_src(torch.clamp(taps_x - PAD_X, 0, UPSAMPLED - 1), fw, UPSAMPLED)
+    fy = _nearest_src(torch.clamp(taps_y, 0, UPSAMPLED - 1), fh, UPSAMPLED)
+    idx = torch.where(inside, fy * fw + fx, torch.full_like(fx, -1)).to(torch.int32)
     w = torch.where(inside, w, torch.zeros_like(w)).to(torch.float32)
     return idx.contiguous(), w.contiguous()
 

@@ -147,6 +147,9 @@ class V2VModel(nn.Module):
         _lib.require_hip(x)
         B, C, G = x.shape[0], x.shape[1], x.shape[2]
         prog = self.program
+        if prog.fft7_ready(G) and C == prog.cin and G % 32 == 0:
+            # NCDHW is the planar input of the frequency-domain front layer as it stands
+            return prog.run(x.float().contiguous(), B, G, planar1=True).view(B, self.output_channels, G, G, G)
         buf = torch.zeros((B, G, G, G, prog.cin_pad), device=x.device, dtype=prog.dtype)
         buf[..., :C] = x.permute(0, 2, 3, 4, 1)
         if prog.dtype == torch.bfloat16:
@@ -224,6 +227,15 @@ class V2VProgram:
         fl, ed, bl = model.front_layers, model.encoder_decoder, model.back_layers
         basic = lambda m, cin_pad=None: _PackedConv(m.block[0], m.block[1], cin_pad, dtype)
         self.front0 = basic(fl[0], self.cin_pad)
+        # frequency-domain form of the 7^3 front layer (csrc/conv3d_fft7.hip, round 6): the weight spectra in MFMA fragment order.
+        # Used when run() gets the planar input [B, cin, G, G, G]; SCENEEGO_FFT7=0 keeps the F(6,7) Winograd kernel (A/B).
+        self.front0_fft = None
+        self._fft_ws = None
+        conv0, bn0 = fl[0].block[0], fl[0].block[1]
+        if (dtype == torch.float32 and os.environ.get("SCENEEGO_FFT7", "1") != "0"
+                and int(_lib.load().se_conv3d_k7_fft_packed_elems(self.cin, conv0.out_channels)) > 0):
+            self.front0_fft = _lib.conv3d_k7_fft_pack(conv0.weight.detach().float().contiguous(), bn0.weight.detach().float().contiguous(),
+                                                      bn0.running_var.detach().float().contiguous(), bn0.eps, conv0.out_channels, self.cin)
         self.front_res = [self._pack_res(fl[i]) for i in (1, 2, 3)]
         self.enc = [self._pack_res(getattr(ed, f"encoder_res{k}")) for k in range(1, 6)]
         self.skip = [self._pack_res(getattr(ed, f"skip_res{k}")) for k in range(1, 6)]
@@ -283,13 +295,17 @@ class V2VProgram:
         kind = self._planar(blk, dim, B)    # both convolutions take the planar / pooled / fused-skip forms of this kernel family
         assert kind or not (x_lay or out_planar)
         assert x_lay in (None, kind)
-        assert sk is None or not x_lay           # the 1x1x1 skip convolution reads channels-last
+        fused = sk.fused if sk is not None else None
+        fuse = fused is not None and kind and not self.split3 and out_planar and pool_out is None and (not x_lay or x_lay == "quad")
+        # a 1x1x1 skip convolution reads channels-last - except the fused 16-channel one of the quad family, which also takes the
+        # quad-planar tensor the frequency-domain front layer writes (SE_RES_QUAD of se_conv3d_skip16_f32)
+        assert sk is None or not x_lay or fuse
         IN, OUT, RES = self._LAY[kind] if kind else (0, 0, 0)
         a = self._conv(x, c1, B, dim, _lib.EPI_RELU | OUT | (IN if x_lay else 0))
-        fused = sk.fused if sk is not None else None
-        if fused is not None and kind and not self.split3 and out_planar and pool_out is None and not x_lay:
+        if fuse:
             out = torch.empty((B, dim, dim, dim, c2.cout), device=self.device, dtype=self.dtype)
-            _lib.conv3d_skip16(a, c2.w, fused[1], x, fused[0], out, B, dim, c2.cin, c2.cout, _lib.EPI_RELU | IN | OUT)
+            _lib.conv3d_skip16(a, c2.w, fused[1], x, fused[0], out, B, dim, c2.cin, c2.cout,
+                               _lib.EPI_RELU | IN | OUT | (RES if x_lay == "quad" else 0))
             return out
         s = x if sk is None else self._conv(x, sk, B, dim, 0)
         f2 = _lib.EPI_RELU | _lib.EPI_RES_PRE_RELU | IN
@@ -354,27 +370,54 @@ class V2VProgram:
         return dim % 16 == 0 and (pc.cin_pad, pc.cout) in ((64, 32), (128, 64))
 
     # -- the network -------------------------------------------------------------------------
-    def run(self, x, B, G, out=None, softargmax=None, scaled=False):
+    def fft7_ready(self, G):
+        """True when run(..., planar1=True) can take the planar input [B, cin, G, G, G] (the frequency-domain front layer covers it)."""
+        return self.front0_fft is not None and G >= 16 and G % 16 == 0
+
+    def _front0_fft(self, x, B, G, out_quad):
+        """front_layers.0 in the frequency domain (se_conv3d_k7_fft_f32): planar x [B,cin,G,G,G] -> 16 channels, channels-last or quad-planar.
+        The spectra of up to 8 samples live in a workspace owned by the program (1.5 GB at 64^3; larger batches walk it in chunks)."""
+        need = _lib.conv3d_k7_fft_workspace_elems(min(B, 8), G, self.cin)
+        if self._fft_ws is None or self._fft_ws.numel() < need:
+            self._fft_ws = torch.empty(need, device=self.device, dtype=torch.float32)
+        out = self._new(B, G, self.front0.cout)
+        _lib.conv3d_k7_fft(x, self.front0_fft, self.front0.b, out, B, G, self.cin, self.front0.cout,
+                           _lib.EPI_RELU | (_lib.OUT_QUAD if out_quad else 0), self._fft_ws)
+        return out
+
+    def run(self, x, B, G, out=None, softargmax=None, scaled=False, planar1=False):
         """x: [B,G,G,G,cin_pad] channels-last (channels >= cin zero; bf16: octet-planar [B,cin_pad/8,G,G,G,8]; float32 may
-        also be triplet-planar [B,ceil(cin/3),G,G,G,3], which the 7^3 front layer reads with ~5x fewer cache-line requests)
+        also be triplet-planar [B,ceil(cin/3),G,G,G,3], which the 7^3 Winograd front layer reads with ~5x fewer cache-line requests,
+        or - ``planar1`` - fully planar [B,cin,G,G,G] for the frequency-domain front layer, see fft7_ready())
         -> planar logits [B,cout,G^3] (``scaled``: times ``output_scale``)."""
         assert x.is_contiguous() and x.dtype == self.dtype
         outc = self.out_scaled if scaled else self.out
         planar3 = self.dtype == torch.float32 and x.dim() == 6       # float32 triplet-planar [B,ceil(cin/3),G,G,G,3]
-        if planar3:
+        if planar1:
+            assert self.fft7_ready(G) and tuple(x.shape) == (B, self.cin, G, G, G)
+        elif planar3:
             assert tuple(x.shape) == (B, (self.cin + 2) // 3, G, G, G, 3)
         else:
             assert tuple(x.shape) == ((B, self.cin_pad // 8, G, G, G, 8) if self.dtype == torch.bfloat16 else (B, G, G, G, self.cin_pad))
         if G % 32:
             raise ValueError("volume_size must be a multiple of 32 (five 2x max-pools), got %d" % G)
-        x = self._conv(x, self.front0, B, G, _lib.EPI_RELU | (_lib.IN_PLANAR3 if planar3 else 0))
+        x_lay = None
+        if planar1:
+            # quad-planar hand-over when front_layers.1 takes it: both its 3^3 convolutions on the F(4,3) x F(4,3) kernel and the fused
+            # 16-channel skip convolution (which then reads the quad-planar tensor too)
+            blk0 = self.front_res[0]
+            q = (not self.split3 and self._planar(blk0, G, B) == "quad" and blk0[2] is not None and blk0[2].fused is not None
+                 and len(self.front_res) > 1)
+            x = self._front0_fft(x, B, G, q)
+            x_lay = "quad" if q else None
+        else:
+            x = self._conv(x, self.front0, B, G, _lib.EPI_RELU | (_lib.IN_PLANAR3 if planar3 else 0))
         # Tensor layouts of the float32 program: a Res3DBlock output that is read only by 2-D Winograd convolutions of the same kernel
         # family (as input or as skip tensor) and by a max-pool is kept in that family's planar layout (_planar: quad-planar at 64^3 /
         # 32^3, octet-planar at 16^3); what the deconvolutions, the 1x1x1 convolutions and the fused tail read stays channels-last.
         # x_lay tracks the layout of the running tensor.
         # A block whose output goes to an encoder max-pool writes the pooled tensor from its last convolution's epilogue when
         # that convolution runs on a 2-D Winograd kernel (`pooled`); the pool kernel is then not launched.
-        x_lay = None
         pooled = None
         for i, blk in enumerate(self.front_res):
             kind = self._planar(blk, G, B)

@@ -182,13 +182,17 @@ class VoxelNetwork_depth(nn.Module):
         self.volume_net.compile(self.v2v_dtype, output_scale=float(self.volume_multiplier), split3=getattr(self, "v2v_split3", False))
         return self
 
-    def _device_tables(self, grid_coord_proj_batch, coord_volumes, device):
-        key = (grid_coord_proj_batch.data_ptr(), coord_volumes.data_ptr(), str(device))
+    def _device_tables(self, grid_coord_proj_batch, coord_volumes, device, feat_hw=(64, 64)):
+        """Device constants of the forward.  ``feat_hw``: size of the backbone's feature map - the reference upsamples ANY size to
+        1024 x 1024 (``network/voxel_net_depth.py:59-60,238``), so the 4-tap table is built for the map this call really has (64 x 64
+        for the 256 x 256 crop) and the largest texel index it holds is kept beside it (checked against the map in _forward_impl)."""
+        key = (grid_coord_proj_batch.data_ptr(), coord_volumes.data_ptr(), str(device), tuple(feat_hw))
         if self._tables_for == key:
             return
         G = self.volume_size
         grid = grid_coord_proj_batch[0].reshape(-1, 2)
-        idx, w = op.build_gather_table(grid, self.heatmap_shape, feat_hw=64)
+        idx, w = op.build_gather_table(grid, self.heatmap_shape, feat_hw=tuple(feat_hw))
+        self._gather_max = int(idx.max())
         self._gather_idx, self._gather_w = idx.to(device), w.to(device)
         self._coord_flat = coord_volumes[0].reshape(G * G * G, 3).to(device=device, dtype=torch.float32).contiguous()
         ray_tab = op.build_voxelizer_ray_table(self.ray, self.image_width, self.image_height)
@@ -199,7 +203,7 @@ class VoxelNetwork_depth(nn.Module):
     def depth_map_to_voxel(self, depth_map_batch):
         """[B,H,W] depth (metres) -> [B,G,G,G] occupancy, on device (reference ``:194-222`` for the whole batch)."""
         dev = depth_map_batch.device
-        self._device_tables(self.grid_coord_proj_batch, self.coord_volumes, dev)
+        self._device_tables(self.grid_coord_proj_batch, self.coord_volumes, dev, feat_hw=getattr(self, "_feat_hw", (64, 64)))
         B = depth_map_batch.shape[0]
         depth = depth_map_batch.reshape(B, depth_map_batch.shape[-2], depth_map_batch.shape[-1]).float().contiguous()
         G = self.volume_size
@@ -265,15 +269,16 @@ class VoxelNetwork_depth(nn.Module):
         B = images.shape[0]
         G = self.volume_size
         N = G * G * G
-        self._device_tables(grid_coord_proj_batch, coord_volumes, dev)
         fb, pw, pb = self._folded
 
         # 2D: backbone (MIOpen) + 1x1 channel reduction, channels-last
         with _lib.stage("backbone"):
-            feat2d = torch.nn.functional.conv2d(fb(images), pw, pb)              # [B,32,64,64]
+            feat2d = torch.nn.functional.conv2d(fb(images), pw, pb)              # [B,32,64,64] for the 256 x 256 crop
             feat_nhwc = feat2d.permute(0, 2, 3, 1)
             if feat_nhwc.dtype != torch.float32 or not feat_nhwc.is_contiguous():
                 feat_nhwc = feat_nhwc.float().contiguous()
+        self._feat_hw = (int(feat2d.shape[2]), int(feat2d.shape[3]))
+        self._device_tables(grid_coord_proj_batch, coord_volumes, dev, feat_hw=self._feat_hw)
 
         # lift to the volume: V2V input buffer [B,G,G,G,cin_pad], zero beyond the real channels
         prog = self.volume_net.program
@@ -287,13 +292,19 @@ class VoxelNetwork_depth(nn.Module):
                     and prog.cin_pad >= C + (8 if bf16 else 4))
         # float32 production case (features + depth occupancy): triplet-planar input [B,11,G,G,G,3] for the 7^3 front layer
         planar3 = (fast_occ and not bf16 and prog.cin == C + 1 and G % 8 == 0 and G >= 16 and self.planar3_input)
-        xkey = (B, G, prog.cin_pad, str(dev), prog.dtype, planar3)
+        # ... fully planar [B,33,G,G,G] when the frequency-domain front layer takes it (round 6; csrc/conv3d_fft7.hip)
+        planar1 = planar3 and prog.fft7_ready(G)
+        if planar1:
+            planar3 = False
+        xkey = (B, G, prog.cin_pad, str(dev), prog.dtype, planar3, planar1)
         x = self._xbuf.get(xkey)
         if x is None:
             self._xbuf.clear()
             shape = (B, prog.cin_pad // 8, G, G, G, 8) if bf16 else (B, G, G, G, prog.cin_pad)   # bf16: octet-planar
             if planar3:
                 shape = (B, (C + 3) // 3, G, G, G, 3)
+            if planar1:
+                shape = (B, C + 1, G, G, G)
             x = torch.zeros(shape, device=dev, dtype=prog.dtype)
             self._xbuf[xkey] = x
         xb = None
@@ -301,14 +312,18 @@ class VoxelNetwork_depth(nn.Module):
             # scene_volumes / with_intersection inputs: assembled in float32 by the _f32 operators, rounded once
             xb, x = x, torch.zeros((B, G, G, G, prog.cin_pad), device=dev, dtype=torch.float32)
         texels = feat_nhwc.shape[1] * feat_nhwc.shape[2]
+        if self._gather_max >= texels:      # cannot happen with the table built above for this very map; the kernels do not check
+            raise ValueError("gather table addresses texel %d of a %d-texel feature map" % (self._gather_max, texels))
         with _lib.stage("gather"):
-            if planar3:
+            if planar1:
+                _lib.unproject_gather_planar1(feat_nhwc, self._gather_idx, self._gather_w, x, B, texels, C, N, C + 1)
+            elif planar3:
                 _lib.unproject_gather_planar3(feat_nhwc, self._gather_idx, self._gather_w, x, B, texels, C, N, x.shape[1])
             else:
                 _lib.unproject_gather(feat_nhwc, self._gather_idx, self._gather_w, x, B, texels, C, N, prog.cin_pad, 0)
 
         with _lib.stage("voxelise"):
-            self._voxelise(x, planar3, fast_occ, prog, scene_volumes, depth_map_batch, B, G, N, C, dev)
+            self._voxelise(x, planar3, fast_occ, prog, scene_volumes, depth_map_batch, B, G, N, C, dev, planar1)
         if xb is not None:
             xb.copy_(x.view(B, G, G, G, prog.cin_pad // 8, 8).permute(0, 4, 1, 2, 3, 5))
             x = xb
@@ -318,7 +333,7 @@ class VoxelNetwork_depth(nn.Module):
                     and ((N + 31) // 32 + 3) // 4 * 4 % 16 == 0)
         sa_scratch = torch.empty(_lib.softargmax3d_scratch_elems(B * self.num_joints), device=dev, dtype=torch.float32) if fused_sa else None
         with _lib.stage("v2v"):
-            logits = prog.run(x, B, G, softargmax=(self._coord_flat, sa_scratch) if fused_sa else None, scaled=True)   # [B,J,N] planar, x volume_multiplier
+            logits = prog.run(x, B, G, softargmax=(self._coord_flat, sa_scratch) if fused_sa else None, scaled=True, planar1=planar1)   # [B,J,N] planar, x volume_multiplier
         joints = torch.empty((B, self.num_joints, 3), device=dev, dtype=torch.float32)
         volumes = torch.empty_like(logits)
         with _lib.stage("softargmax"):
@@ -334,9 +349,14 @@ class VoxelNetwork_depth(nn.Module):
             features = self.process_features[2](self.process_features[1](feat2d.float()))
         return joints, features, volumes, self.coord_volumes
 
-    def _voxelise(self, x, planar3, fast_occ, prog, scene_volumes, depth_map_batch, B, G, N, C, dev):
+    def _voxelise(self, x, planar3, fast_occ, prog, scene_volumes, depth_map_batch, B, G, N, C, dev, planar1=False):
         """Occupancy into the V2V input buffer ``x`` (reference ``:246-262``)."""
-        if planar3:
+        if planar1:
+            # the gather zeroed plane 32; the voxeliser scatters the occupancy into it
+            depth = depth_map_batch.reshape(B, depth_map_batch.shape[-2], depth_map_batch.shape[-1]).float().contiguous()
+            _lib.voxelize_planar1(depth, self._ray_tab, x, B, depth.shape[1], depth.shape[2], op.UPSAMPLED, op.PAD_X, G,
+                                  self.cuboid_side, C + 1, C)
+        elif planar3:
             # the gather zeroed slot (10, 2) = channel 32; the voxeliser scatters the occupancy into it
             depth = depth_map_batch.reshape(B, depth_map_batch.shape[-2], depth_map_batch.shape[-1]).float().contiguous()
             _lib.voxelize_planar3(depth, self._ray_tab, x, B, depth.shape[1], depth.shape[2], op.UPSAMPLED, op.PAD_X, G,

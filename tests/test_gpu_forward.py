@@ -503,3 +503,49 @@ def test_pipelined_forward_matches_plain_forward(net64):
         assert all(len(r._graphs) == 1 for r in pf.nets)
     finally:
         pf.enable_graphs(False)
+
+
+@pytest.mark.parametrize("side", [128, 512])
+def test_forward_other_image_sizes_vs_oracle(side, oracle_constants):
+    """the reference upsamples ANY feature map to 1024 x 1024 (`nn.Upsample(size=(1024, 1024))`,
+    network/voxel_net_depth.py:59-60,238) before it samples it, so an image that is not 256 x 256 is legal input: 128^2 gives a 32 x 32
+    feature map (1024 texels), 512^2 a 128 x 128 one.  Until round 6 the 4-tap table was hard-wired to 64 x 64: a 512^2 image sampled the
+    first quarter of its map, a 128^2 image read past its buffer.  The table is now built for the map the call has; whole forward
+    against the oracle (literal Upsample + pad + grid_sample)."""
+    net = _build()
+    sd = synthetic_state_dict(False)
+    const = oracle_constants(64)
+    img = torch.from_numpy(synth.normal(900 + side, "img", (1, 3, side, side)))
+    _, depth = synth.make_inputs(900 + side, 1, "floor")
+    taps = {}
+    oj, _, ovols = O.forward(sd, const, img, depth, taps=taps, accumulate64=True)
+    kp, feats, vols, _ = _forward(net, img, depth)
+    assert tuple(feats.shape[-2:]) == (side // 4, side // 4) and net._gather_max < (side // 4) ** 2
+    f_err = float((feats.float().cpu() - taps["features64"]).abs().max())
+    j_err = float((kp.cpu() - oj).abs().max())
+    print(f"{side}x{side} image: feature map {side // 4}^2, features {f_err:.2e}, joints vs oracle {j_err:.2e} m")
+    assert f_err < 2e-3 and j_err <= JOINT_TOL
+    assert float((vols.cpu() - ovols).abs().max()) <= 2e-3 * float(ovols.max())
+    # back to the 256 x 256 crop on the same module: the table follows the map
+    img2, depth2 = synth.make_inputs(7, 1, "floor")
+    oj2, _, _ = O.forward(sd, const, img2, depth2, accumulate64=True)
+    assert float((_forward(net, img2, depth2)[0].cpu() - oj2).abs().max()) <= JOINT_TOL
+
+
+def test_forward_fft_front_layer_matches_winograd_front_layer(monkeypatch):
+    """The frequency-domain front layer (round 6, csrc/conv3d_fft7.hip) against the F(6,7) Winograd kernel it replaces in the same
+    forward: SCENEEGO_FFT7=0 compiles the program without the spectra (triplet-planar input, conv3d_wino67.hip).  Joints of both
+    programs agree to 1e-4 m and both meet the reference golden."""
+    from sceneego_amd import _lib
+    img, depth = synth.make_inputs(311, 2, "uniform")
+    net = _build()
+    kp_fft = _forward(net, img, depth)[0]
+    assert net.volume_net.program.front0_fft is not None
+    assert any(k[-1] for k in net._xbuf), "the forward did not take the planar (frequency-domain) input path"
+    monkeypatch.setenv("SCENEEGO_FFT7", "0")
+    net2 = _build()
+    kp_w = _forward(net2, img, depth)[0]
+    assert net2.volume_net.program.front0_fft is None
+    d = float((kp_fft - kp_w).abs().max())
+    print(f"fft7 vs wino67 front layer: joints differ by {d:.2e} m")
+    assert d < 1e-4

@@ -1130,3 +1130,156 @@ def test_wino44pp_and_wino67_repeat_launches_bit_identical():
             first = outh.clone()
         else:
             assert torch.equal(outh, first), f"halo64 launch {i} differs"
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: the 7x7x7 front layer in the frequency domain (csrc/conv3d_fft7.hip) and what feeds / reads it
+# ------------------------------------------------------------------------------------------------
+def _fft7_pack(conv, bn):
+    pc = _PackedConv(conv, bn, cin_pad=48)
+    hf = _lib.conv3d_k7_fft_pack(conv.weight.detach().float().contiguous(), bn.weight.detach().float().contiguous(),
+                                 bn.running_var.detach().float().contiguous(), bn.eps, 16, 33)
+    return pc, hf
+
+
+def _fft7_unquad(out, B, dim):
+    return out.view(B, 4, dim, dim, dim, 4).permute(0, 1, 5, 2, 3, 4).reshape(B, 16, dim, dim, dim)
+
+
+def test_conv7_fft_front_layer_vs_torch():
+    """front_layers.0 (Conv3d(33, 16, 7) + BN + ReLU, reference network/v2v.py:8-18,147) in the frequency domain - se_conv3d_k7_fft_f32:
+    24^3 tile DFT, per-frequency MFMA GEMM, inverse - against torch-CPU float32 at the production size (64^3, B = 2: interior and face
+    tiles), at 32^3 / 48^3 (every tile touches a face; 48 = 3 tiles) and B = 3 walked in chunks of 1 and 2 samples through a NaN-filled
+    workspace; both output layouts.  Bound: the 2e-5 of max|y| of the Winograd kernel it replaces; the error against a float64
+    evaluation at sampled outputs is printed and bounded (the orthogonal transform has no conditioning penalty: measured ~2e-7 of max|y|,
+    below torch's own float32 summation error)."""
+    conv, bn = _conv_bn(33, 16, 7, 67)
+    cw, cb = conv.weight.detach().double(), conv.bias.detach().double()
+    bw, bb, bm, bv = (t.detach().double() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    cases = ((2, 64, (2,)), (1, 32, (1,)), (3, 48, (1, 2)))
+    pc = hf = None
+    for B, dim, chunks in cases:
+        x = torch.from_numpy(synth.normal(67, "x%d" % dim, (B, 33, dim, dim, dim)))
+        with torch.no_grad():
+            want = F.relu(bn(conv(x)))
+        if pc is None:
+            pc, hf = _fft7_pack(conv.to(DEV), bn.to(DEV))
+            conv, bn = conv.cpu(), bn.cpu()
+        scale = float(want.abs().max())
+        xd = x.to(DEV).contiguous()
+        for chunk in chunks:
+            ws = torch.full((_lib.conv3d_k7_fft_workspace_elems(chunk, dim, 33),), float("nan"), device=DEV)
+            for quad in (False, True):
+                out = torch.full((B, 16 * dim ** 3), -77.0, device=DEV)
+                _lib.conv3d_k7_fft(xd, hf, pc.b, out, B, dim, 33, 16, _lib.EPI_RELU | (_lib.OUT_QUAD if quad else 0), ws)
+                got = (_fft7_unquad(out, B, dim) if quad else out.view(B, dim, dim, dim, 16).permute(0, 4, 1, 2, 3)).cpu()
+                assert bool(torch.isfinite(got).all())
+                err = float((got - want).abs().max())
+                assert err < 2e-5 * scale, (B, dim, chunk, quad, err, scale)
+        # float64 evaluation at sampled positions (a quarter of them on the volume faces)
+        g = torch.Generator().manual_seed(6)
+        n = 1024
+        pos = torch.randint(0, dim, (n, 3), generator=g)
+        pos[: n // 4, 0] = torch.randint(0, 2, (n // 4,), generator=g) * (dim - 1)
+        bi = torch.randint(0, B, (n,), generator=g)
+        xp = F.pad(x.double(), (3, 3, 3, 3, 3, 3))
+        ar = torch.arange(7)
+        patches = xp[bi[:, None, None, None], :, (pos[:, 0, None] + ar)[:, :, None, None], (pos[:, 1, None] + ar)[:, None, :, None],
+                     (pos[:, 2, None] + ar)[:, None, None, :]]
+        y64 = torch.einsum("nzyxc,zyxco->no", patches, cw.permute(2, 3, 4, 1, 0)) + cb
+        y64 = F.relu((y64 - bm) * (bw / torch.sqrt(bv + bn.eps)) + bb)
+        e_hip = float((got[bi, :, pos[:, 0], pos[:, 1], pos[:, 2]].double() - y64).abs().max())
+        e_cpu = float((want[bi, :, pos[:, 0], pos[:, 1], pos[:, 2]].double() - y64).abs().max())
+        print(f"fft7 33->16 @{dim}^3 B={B}: max|hip - torch f32| = {err:.2e} ({err / scale:.2e} of max|y| = {scale:.2f}); against float64 at "
+              f"{n} samples: hip {e_hip:.2e} ({e_hip / scale:.2e}), torch-CPU f32 {e_cpu:.2e}")
+        assert e_hip < 3e-6 * scale, (e_hip, scale)
+    # without ReLU (negative outputs survive), and the shapes the entry point refuses
+    out = torch.empty((1, 16 * 32 ** 3), device=DEV)
+    x = torch.from_numpy(synth.normal(67, "x32", (1, 33, 32, 32, 32)))
+    with torch.no_grad():
+        want = bn(conv(x))
+    ws = torch.empty((_lib.conv3d_k7_fft_workspace_elems(1, 32, 33),), device=DEV)
+    _lib.conv3d_k7_fft(x.to(DEV), hf, pc.b, out, 1, 32, 33, 16, 0, ws)
+    got = out.view(1, 32, 32, 32, 16).permute(0, 4, 1, 2, 3).cpu()
+    assert float(got.min()) < 0 and float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+    lib = _lib.load()
+    assert lib.se_conv3d_k7_fft_packed_elems(32, 16) == -1 and lib.se_conv3d_k7_fft_workspace_elems(1, 24, 33) == -1
+    p = ctypes.c_void_p(out.data_ptr())
+    assert lib.se_conv3d_k7_fft_f32(p, p, p, p, 1, 24, 33, 16, 0, p, 1 << 40, None) == -1               # dim % 16
+    assert lib.se_conv3d_k7_fft_f32(p, p, p, p, 1, 32, 33, 16, 0, p, 1000, None) == -1                   # workspace below one sample
+    assert lib.se_conv3d_k7_fft_f32(p, p, p, p, 1, 32, 33, 16, _lib.EPI_RES_PRE_RELU, p, 1 << 40, None) == -1
+
+
+def test_conv7_fft_repeat_launches_bit_identical_and_batch_invariant():
+    """The three passes have no atomics and no split sums: 20 launches give the same bits, and a sample's result does not depend on the
+    batch it rides in or on the workspace chunking (unlike the chunk-half split of the Winograd kernel)."""
+    B, dim = 3, 64
+    conv, bn = _conv_bn(33, 16, 7, 92)
+    pc, hf = _fft7_pack(conv.to(DEV), bn.to(DEV))
+    x = torch.randn(B, 33, dim, dim, dim, device=DEV)
+    ws = torch.empty((_lib.conv3d_k7_fft_workspace_elems(B, dim, 33),), device=DEV)
+    out = torch.empty((B, 16 * dim ** 3), device=DEV)
+    first = None
+    for i in range(20):
+        out.fill_(float(i))
+        ws.fill_(float(-i))
+        _lib.conv3d_k7_fft(x, hf, pc.b, out, B, dim, 33, 16, _lib.EPI_RELU | _lib.OUT_QUAD, ws)
+        if first is None:
+            first = out.clone()
+        else:
+            assert torch.equal(out, first), f"fft7 launch {i} differs"
+    one = torch.empty((1, 16 * dim ** 3), device=DEV)
+    for b in range(B):
+        _lib.conv3d_k7_fft(x[b:b + 1].contiguous(), hf, pc.b, one, 1, dim, 33, 16, _lib.EPI_RELU | _lib.OUT_QUAD, ws)
+        assert torch.equal(one[0], first[b]), f"sample {b}: batch-1 launch differs from its batch-{B} result"
+
+
+def test_planar1_producers_bit_exact(voxel_setup, oracle_constants):
+    """se_unproject_gather_planar1_f32 + se_voxelize_planar1_f64 write exactly the bits of the channels-last pair, as planes."""
+    c, tab = voxel_setup
+    feat = torch.from_numpy(synth.normal(31, "feat", (2, 64, 64, 32))).to(DEV)
+    idx, w = op.build_gather_table(c.grid, (1024, 1280), 64)
+    idx, w = idx.to(DEV), w.to(DEV)
+    _, depth = synth.make_inputs(22, 2, "floor")
+    N = 64 ** 3
+    cl = torch.zeros((2, N, 48), device=DEV)
+    _lib.unproject_gather(feat, idx, w, cl, 2, 4096, 32, N, 48, 0)
+    _lib.voxelize_strided(depth.to(DEV), tab, cl, 2, 1024, 1280, 1024, 128, 64, 2, 48, 32)
+    p1 = torch.full((2, 33, N), 7.0, device=DEV)          # poison: every plane must be written
+    _lib.unproject_gather_planar1(feat, idx, w, p1, 2, 4096, 32, N, 33)
+    assert float(p1[:, 32].abs().max()) == 0.0            # the occupancy plane is cleared by the gather
+    _lib.voxelize_planar1(depth.to(DEV), tab, p1, 2, 1024, 1280, 1024, 128, 64, 2, 33, 32)
+    assert torch.equal(p1, cl[..., :33].permute(0, 2, 1).contiguous())
+    assert float(p1[:, 32].sum()) > 0
+    lib = _lib.load()
+    p = ctypes.c_void_p(p1.data_ptr())
+    assert lib.se_unproject_gather_planar1_f32(p, p, p, p, 1, 4096, 32, N, 31, None) == -1             # fewer planes than channels
+    assert lib.se_unproject_gather_planar1_f32(p, p, p, p, 1, 4096, 24, N, 33, None) == -1             # channel count not instantiated
+    assert lib.se_voxelize_planar1_f64(p, p, p, 1, 1024, 1280, 1024, 128, 64, 2.0, 33, 33, None) == -1
+
+
+@pytest.mark.parametrize("B,dim", [(1, 64), (2, 32)])
+def test_conv3d_fused_skip_convolution_quad_planar_skip_input(B, dim):
+    """se_conv3d_skip16_f32 with SE_RES_QUAD: the 16-channel input of the fused 1x1x1 skip convolution is quad-planar [B][4][D^3][4]
+    (what the frequency-domain front layer writes) - same bits as the channels-last form of the same launch."""
+    cin = cout = 32
+    if _lib.conv3d_variant(B, dim, cin, cout, 3, _lib.IN_QUAD) != 3:
+        pytest.skip("shape not on the F(4,3) x F(4,3) kernel at this batch")
+    conv, bn = _conv_bn(cin, cout, 3, 75)
+    skip, bns = _conv_bn(16, cout, 1, 77)
+    pc, ps = _PackedConv(conv.to(DEV), bn.to(DEV)), _PackedConv(skip.to(DEV), bns.to(DEV))
+    scale = (bns.weight / torch.sqrt(bns.running_var + bns.eps)).detach()
+    w_skip = (skip.weight.detach().reshape(cout, 16) * scale[:, None]).contiguous().to(DEV)
+    a = _quad(torch.randn(B, dim, dim, dim, cin, device=DEV))
+    xs = torch.randn(B, dim, dim, dim, 16, device=DEV)
+    bsum = (pc.b + ps.b).contiguous()
+    want = torch.full((B, 8, dim, dim, dim, 4), -77.0, device=DEV)
+    got = torch.full_like(want, -78.0)
+    _lib.conv3d_skip16(a, pc.w, bsum, xs, w_skip, want, B, dim, cin, cout, _lib.EPI_RELU | _lib.IN_QUAD | _lib.OUT_QUAD)
+    _lib.conv3d_skip16(a, pc.w, bsum, _quad(xs), w_skip, got, B, dim, cin, cout, _lib.EPI_RELU | _lib.IN_QUAD | _lib.OUT_QUAD | _lib.RES_QUAD)
+    assert torch.equal(got, want)
+    # and against torch for the whole fused launch
+    with torch.no_grad():
+        ref = F.relu(bn.cpu()(conv.cpu()(_ncdhw(_unquad(a).cpu()))) + bns.cpu()(skip.cpu()(_ncdhw(xs.cpu()))))
+    err = float((_ncdhw(_unquad(got).cpu()) - ref).abs().max())
+    assert err < 2e-5 * float(ref.abs().max()), err
