@@ -622,7 +622,11 @@ def config3_extra(net, rank, device, depth_kind):
              "dtype": "bf16 storage + f32 accumulate (V2V), bf16 backbone",
              "joint_diff_to_f32_program_m": {"median": round(float(diff.median()), 6), "p95": round(float(diff.kthvalue(int(0.95 * diff.numel()))[0]), 6),
                                              "max": round(float(diff.max()), 6), "joints": int(diff.numel()),
-                                             "spec": "4e-2 m (DESIGN.md 4b): bf16 storage does not meet the 1e-3 m parity tolerance"},
+                                             "spec": "over the 480 joints of a B=32 batch: median <= 1.5e-2 m, p95 <= 4e-2 m, max <= 0.15 m (what "
+                                                     "tests/test_gpu_configs.py::test_config3_b32_bf16_accuracy gates; the 4e-2 m of DESIGN.md 4b is the bound on "
+                                                     "the 45 golden joints, tests/test_gpu_bf16.py); bf16 storage does not meet the 1e-3 m parity tolerance",
+                                             "pass": bool(float(diff.median()) <= 1.5e-2 and float(diff.kthvalue(int(0.95 * diff.numel()))[0]) <= 4e-2
+                                                          and float(diff.max()) <= 0.15)},
              "note": "lower precision than the reference: reported beside the float32 headline, never in `value`"}
         ms = prof.get(("conv3d_bf16", 3, 32, 32, 64))
         if ms:

@@ -306,10 +306,11 @@ def conv3d_packed_elems(cout, cin_pad, ksize, transposed, bf16=False) -> int:
 
 
 def conv3d_variant(batch, dim, cin, cout, ksize, flags=0) -> int:
-    """The kernel a launch of ``batch`` samples with these layout flags (IN_OCTET ...) runs on: conv3d_algo()'s value, except 3 = the
-    F(4,3) x F(4,3) member of the 2-D Winograd family (same flags / layouts as 2; it takes an octet-planar input or a channels-last one
-    with < 32 channels) and 0 for a 2-D Winograd shape with <= 4096 voxels in the batch (16^3 at batch 1) called without octet-planar
-    forms, which the in-workgroup split-K kernel serves better; the V2V program keeps such a level channels-last."""
+    """The kernel a launch of ``batch`` samples with these layout flags (IN_OCTET / IN_QUAD ...) runs on: conv3d_algo()'s value, except
+    3 = the F(4,3) x F(4,3) member of the 2-D Winograd family (same fused forms as 2; its planar layout is QUAD-planar: it takes a
+    quad-planar input or a channels-last one with < 32 channels; any octet-planar flag keeps the launch on 2) and 0 for a 2-D Winograd
+    shape with <= 4096 voxels in the batch (16^3 at batch 1) called without planar forms, which the in-workgroup split-K kernel serves
+    better; the V2V program keeps such a level channels-last."""
     return int(load().se_conv3d_f32_variant(batch, dim, cin, cout, ksize, flags))
 
 
@@ -405,7 +406,11 @@ def _tag(t):
 
 def conv3d(inp, wpack, bpack, residual, out, batch, dim, cin, cin_pad, cout, ksize, flags, workspace=None, pool_out=None):
     """``pool_out`` (float32, 2-D Winograd 3x3x3 shapes only): channels-last [B, D/2, D/2, D/2, cout] tensor that also receives
-    max_pool3d(out, 2, 2) from the kernel's epilogue (se_conv3d_pool_f32)."""
+    max_pool3d(out, 2, 2) from the kernel's epilogue (se_conv3d_pool_f32).
+    ``workspace`` serves ONE stream at a time: the split-K levels (4^3, 2^3) and - when given - the chunk-half split of the 7^3 Winograd
+    layer at batch 1 pass partial sums through it (a second stream needs its own: V2VProgram.workspace_side).  With a workspace the 7^3
+    Winograd layer sums a frame in a different float32 order at batch 1 than at batch > 1; the frequency-domain front
+    layer (conv3d_k7_fft, the production path since round 6) is batch-invariant bit for bit."""
     require_hip(inp, out)
     if _prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -494,7 +499,7 @@ def conv3d_skip16(inp, wpack, bpack_sum, skip_in, skip_w, out, batch, dim, cin, 
     require_hip(inp, out, skip_in, skip_w, bpack_sum)
     _chk_f32(inp, out, skip_in, skip_w, bpack_sum)
     # skip_in: channels-last [B, D, D, D, 16], or with RES_QUAD quad-planar [B, 4, D, D, D, 4]
-    assert skip_in.numel() == batch * dim ** 3 * 16 and skip_in.shape[-1] == (4 if flags & RES_QUAD else 16)
+    assert skip_in.numel() == batch * dim ** 3 * 16
     assert tuple(skip_w.shape) == (cout, 16) and skip_w.is_contiguous() and skip_in.is_contiguous()
     with _timed(("conv3d", 3, cin, cout, dim), flags | 256):        # 256 = SE_EPI_SKIPCONV16 (the entry point sets it)
         _check(load().se_conv3d_skip16_f32(_ptr(inp), _ptr(wpack), _ptr(bpack_sum), _ptr(skip_in), _ptr(skip_w), _ptr(out), batch,

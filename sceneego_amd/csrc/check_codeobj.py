@@ -9,35 +9,75 @@ operation of its own between the DMAs and the wait, and while nobody but the asm
   * in the disassembly M0 may be written ONLY by the `s_mov_b32 m0, sN` that the asm statement itself emits in front of each
     `global_load_lds_dwordx4` (so: as many lines mentioning m0 as LDS-DMA instructions, each directly ahead of its s_nop + DMA).
 
-Usage: check_codeobj.py OBJECT.o [--kernels SUBSTRING]      exit code 0 = clean, 1 = violated (message on stderr).
+Usage: check_codeobj.py OBJECT.o [--kernels SUBSTRING]
+Exit code 0 = clean, 1 = a condition is VIOLATED, 2 = the check could not run (an LLVM tool is missing, or the code-object metadata did
+not parse): build.sh stops on 1 and on 2, with different messages; SE_SKIP_CODEOBJ_CHECK=1 skips the check (exit 0, says so).
+The tools are looked up in $SE_LLVM_BIN, then `hipconfig --rocmpath`/lib/llvm/bin, /opt/rocm/lib/llvm/bin, then PATH.
 """
 import os
 import re
+import shutil
 import subprocess
 import sys
 import tempfile
 
-LLVM = os.environ.get("SE_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+
+class CannotCheck(Exception):
+    pass
+
+
+def tool(name):
+    dirs = [os.environ.get("SE_LLVM_BIN")]
+    try:
+        dirs.append(os.path.join(subprocess.run(["hipconfig", "--rocmpath"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                                timeout=20).stdout.strip(), "lib", "llvm", "bin"))
+    except (OSError, subprocess.SubprocessError):
+        pass
+    dirs.append("/opt/rocm/lib/llvm/bin")
+    for d in dirs:
+        if d and os.path.isfile(os.path.join(d, name)):
+            return os.path.join(d, name)
+    p = shutil.which(name)
+    if p is None:
+        raise CannotCheck(f"{name} not found (set SE_LLVM_BIN to the directory of the ROCm LLVM tools)")
+    return p
 
 
 def run(*cmd):
-    return subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True).stdout
+    try:
+        return subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True).stdout
+    except subprocess.CalledProcessError as e:
+        raise CannotCheck(f"{os.path.basename(cmd[0])} failed: {e.stderr.strip()[-300:]}")
 
 
 def main(argv):
     obj = argv[1]
     want = argv[3] if len(argv) > 3 and argv[2] == "--kernels" else ""
+    if os.environ.get("SE_SKIP_CODEOBJ_CHECK") == "1":
+        print(f"check_codeobj: {os.path.basename(obj)}: SKIPPED (SE_SKIP_CODEOBJ_CHECK=1)")
+        return 0
+    try:
+        return check(obj, want)
+    except CannotCheck as e:
+        print(f"check_codeobj: {obj}: the check could NOT RUN - {e}", file=sys.stderr)
+        return 2
+
+
+def check(obj, want):
     with tempfile.TemporaryDirectory() as d:
         fat, co = os.path.join(d, "x.fatbin"), os.path.join(d, "x.co")
-        run(f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat)
-        run(f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}",
+        run(tool("llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", obj, fat)
+        run(tool("clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}",
             f"--output={co}")
-        notes = run(f"{LLVM}/llvm-readelf", "--notes", co)
-        asm = run(f"{LLVM}/llvm-objdump", "-d", co)
+        notes = run(tool("llvm-readelf"), "--notes", co)
+        asm = run(tool("llvm-objdump"), "-d", co)
     bad = []
-    # ---- kernel metadata (YAML inside the note): one block per kernel, keys in alphabetical order ----
+    # ---- kernel metadata (YAML inside the note): one block per kernel; split at the list items that carry a `.name` ----
     kernels = 0
-    for blk in re.split(r"\n\s*- \.agpr_count:", notes)[1:]:
+    blocks = [b for b in re.split(r"\n\s*- (?=\.[a-z_]+:)", notes) if re.search(r"\.name:\s*\S+", b) and ".vgpr_count" in b]
+    if not blocks:
+        raise CannotCheck("no kernel metadata block found in the code object's notes (format changed?)")
+    for blk in blocks:
         name = re.search(r"\.name:\s*(\S+)", blk).group(1)
         if want and want not in name:
             continue

@@ -34,16 +34,14 @@ def _ray_table(ray, height, width, device):
     """x-major reference rays [W*H,3] (index x*H + y) -> device table [H][W][3] float64."""
     global _TABLE
     shape = (height, width, str(device))
-    if _TABLE is not None and _TABLE[0] is ray and _TABLE[2:5] == shape:
-        return _TABLE[5]            # the very same (still referenced) array object: nothing to hash
-    # another object: compare CONTENT (an `id()` key can be reused by a different calibration's array once the first one is freed)
+    # keyed on CONTENT, hashed on every call (ADVICE r5: an `is`-shortcut for the same array object returned a stale table after an
+    # in-place edit of the calibration rays; an `id()` key can be reused by another array).  blake2b over 31 MB: a few ms per item.
     r64 = np.ascontiguousarray(np.asarray(ray, dtype=np.float64))
     digest = hashlib.blake2b(r64.view(np.uint8).reshape(-1), digest_size=16).digest()
-    if _TABLE is not None and _TABLE[1] == digest and _TABLE[2:5] == shape:
-        _TABLE = (ray,) + _TABLE[1:]
-        return _TABLE[5]
+    if _TABLE is not None and _TABLE[0] == digest and _TABLE[1:4] == shape:
+        return _TABLE[4]
     tab = torch.from_numpy(np.ascontiguousarray(r64.reshape(width, height, 3).transpose(1, 0, 2))).to(device)
-    _TABLE = (ray, digest) + shape + (tab,)
+    _TABLE = (digest,) + shape + (tab,)
     return tab
 
 

@@ -229,22 +229,24 @@ def test_two_ranks_launch_sharding_and_all_gather():
           f"{line['parity']['max_joint_err_m']:.2e} m, shard check {line['shard_check']['max_abs_diff_m']:.2e} m")
 
 
-def test_eight_ranks_launch_on_whatever_gpus_there_are():
+@pytest.mark.parametrize("batch,steps,streams", [(1, 3, 2), (32, 2, 1)])
+def test_eight_ranks_launch_on_whatever_gpus_there_are(batch, steps, streams):
     """configs[3] is 8 ranks on one node.  The launcher, rendezvous, per-rank core pinning, sharded seeds, step-ordered all-gather
-    and the cross-rank shard check at WORLD_SIZE 8 - `python bench.py --gpus 8 --batch 1` as the driver will type it - every round:
+    and the cross-rank shard check at WORLD_SIZE 8 - `python bench.py --gpus 8 --batch N` as the driver will type it - every round:
     one rank per GPU over RCCL when the box has 8 devices, otherwise all ranks share the visible device(s) with gloo for the
-    collective (RCCL refuses two ranks on one device)."""
+    collective (RCCL refuses two ranks on one device).  batch 1: the launch path; batch 32: configs[3]'s REAL
+    per-rank workload - 32 frames per rank, the [256, 15, 3] gather, every rank's buffers at size (8 x ~12 GB on a shared device)."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     full = torch.cuda.device_count() >= 8
     if not full:
         env.update(SCENEEGO_SHARE_GPU="1", SCENEEGO_DIST_BACKEND="gloo")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", "1",
-                        "--streams", "2", "--no-cpu-baseline", "--no-extras", "--no-kernel-events", "--no-repeats"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", str(steps), "--warmup", "1", "--batch", str(batch),
+                        "--streams", str(streams), "--no-cpu-baseline", "--no-extras", "--no-kernel-events", "--no-repeats"],
                        capture_output=True, text=True, env=env, timeout=2400)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 8
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 8 * batch
     assert line["rccl_ranks"] == {"world_size": 8, "backend": "nccl" if full else "gloo"} and len(line["rank_ms_per_step"]) == 8
     assert line["parity"]["pass"] and line["parity"]["max_joint_err_m"] <= JOINT_TOL
     assert line["shard_check"]["max_abs_diff_m"] <= line["shard_check"]["tol"]

@@ -86,17 +86,19 @@ def timeit(fn, n=20, warm=3):
     return e0.elapsed_time(e1) / n
 
 
-def time_it(B, chunk, dim=64):
+def time_it(B, chunk, dim=64, quick=False):
     conv, bn = make_layer()
     conv, bn = conv.to(DEV), bn.to(DEV)
     pc, hf = pack(conv, bn)
     x = torch.from_numpy(synth.normal(5, "xt", (B, 33, dim, dim, dim))).to(DEV).contiguous()
     ws = torch.empty((_lib.conv3d_k7_fft_workspace_elems(chunk, dim, 33),), device=DEV)
     out = torch.empty((B, 16 * dim ** 3), device=DEV)
-    for quad in (True, False):
+    for quad in ((True,) if quick else (True, False)):
         fl = _lib.EPI_RELU | (_lib.OUT_QUAD if quad else 0)
         ms = timeit(lambda: _lib.conv3d_k7_fft(x, hf, pc.b, out, B, dim, 33, 16, fl, ws))
         print(f"fft7 B={B} dim={dim} chunk={chunk} quad={quad}: {ms:.3f} ms per call", flush=True)
+    if quick:
+        return
     # the F(6,7) Winograd kernel on the same data (triplet-planar input)
     xin = torch.zeros(B, dim, dim, dim, 33, device=DEV)
     xin.copy_(x.permute(0, 2, 3, 4, 1))
@@ -114,10 +116,11 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--quick", action="store_true", help="--time: the quad-planar form only, no Winograd comparison (attribution builds)")
     a = ap.parse_args()
     rc = 0
     if a.check:
         rc = 0 if check() else 1
     if a.time:
-        time_it(a.batch, a.chunk or a.batch, a.dim)
+        time_it(a.batch, a.chunk or a.batch, a.dim, a.quick)
     sys.exit(rc)
