@@ -572,6 +572,7 @@ def main():
                          "b32_f32": batch_extra(net, pipe, 32, rank, device, args.depth_kind, graphs=False),
                          "split_bf16_v2v_b8": split_extra(net, img, depth, timed_joints, j64),
                          "config3_bf16_b32": config3_extra(net, rank, device, args.depth_kind),
+                         "config2_floor_depth_b8": floor_depth_extra(net, rank, device, args.batch),
                          "no_scene_v2v32_b8": no_scene_extra(device),
                          "config5_g128_b8": config5_extra(device, args.depth_kind)}
     if dt_single is not None:
@@ -665,6 +666,23 @@ def _time_forward(net, img, depth, steps=5, warm=2):
         dt = (time.perf_counter() - t0) / steps
     assert bool(torch.isfinite(out[0]).all())
     return dt
+
+
+def floor_depth_extra(net, rank, device, batch):
+    """BASELINE configs[1]'s second variant (Config 2): the analytic floor-plane depth (realistic sparsity: ~4.6 k occupied voxels
+    against ~137 k for iid-uniform depth) at the headline batch, one stream; joints against the uniform-depth forward are NOT comparable
+    (different scene): parity of this input kind is tests/test_gpu_forward.py::test_forward_b1_floor_vs_golden."""
+    import torch
+    try:
+        img, depth = device_inputs(batch, rank, device, "floor")
+        dt = _time_forward(net, img, depth, steps=10)
+        with torch.no_grad():
+            occ = net.depth_map_to_voxel(depth)
+        return {"value": round(batch / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "batch": batch, "dtype": "f32", "streams": 1,
+                "occupied_voxels_per_frame": round(float(occ.sum()) / batch, 1),
+                "note": "depth = 1.4 / ray_z clamped to 10 m (synth.make_inputs kind 'floor'), one stream, eager; compare extra.single_stream"}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
 
 
 def batch_extra(net, pipe, batch, rank, device, depth_kind, graphs):

@@ -275,23 +275,45 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : (PF ? 3 : 4)) void fft7_fwd_ker
     // trip and unpacked at its end - the loads fly under two transform stages and no loaded register is carried around the loop (with
     // loop-carried prefetch registers hipcc's wait-count pass lost the order of the outstanding operations and put an
     // `s_waitcnt vmcnt(0)` in front of every unpack: the prefetch bought nothing - disassembly, round 6).
-    if ((int)blockIdx.x >= n_units) return;
+    // XCD-aware walk (SE_FFT7_XCD_WALK, speed only - workgroup b runs on XCD b % 8 by round-robin dispatch): a (sample, channel) PLANE
+    // belongs to one XCD, whose resident workgroups walk its 64 tiles together - the 24^3 / 16^3 halo a tile shares with its neighbours
+    // (2.4 of the 3.4 x the tile loads beyond its core) is then a hit in that XCD's L2 instead of the Infinity Cache.  Unit = m * C + c.
+#ifndef SE_FFT7_XCD_WALK
+#define SE_FFT7_XCD_WALK 1
+#endif
+    const int TT = T * T * T;
+    const bool walk = SE_FFT7_XCD_WALK && (gridDim.x & 7) == 0;
+    auto unit_of = [&](int i) {          // the i-th unit of this workgroup, or -1
+        if (!walk) {
+            const int u = (int)blockIdx.x + i * (int)gridDim.x;
+            return u < n_units ? u : -1;
+        }
+        // granule dealt to an XCD: a whole plane when the planes divide evenly over the 8 XCDs (batch % 8 == 0), else a z slab of T x T
+        // tiles (33 planes at batch 1 would leave one XCD with 5 planes against 4)
+        const int G = (n_units / TT) % 8 == 0 ? TT : T * T;
+        const int j = ((int)blockIdx.x >> 3) + i * ((int)gridDim.x >> 3);
+        const int lt = (((int)blockIdx.x & 7) + 8 * (j / G)) * G + j % G;       // (plane = sample * C + channel) * TT + tile in plane
+        if (lt >= n_units) return -1;
+        const int pl = lt / TT;
+        return ((pl / C) * TT + lt % TT) * C + pl % C;
+    };
+    if (unit_of(0) < 0) return;
     auto load_tile = [&](int u) {
 #pragma unroll
         for (int round = 0; round < ROUNDS; ++round) issue_loads(u, round);
     };
     if (PF) {
-        load_tile(blockIdx.x);
+        load_tile(unit_of(0));
         stage1();
         __syncthreads();
     }
     FFT7_STAMP_DECL;
-    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+    for (int i = 0, u = unit_of(0); u >= 0; ++i) {
         const int c = u % C, m = u / C;
-        const int un = u + (int)gridDim.x;
+        const int un = unit_of(i + 1);
         FFT7_MARK(0);
         if (PF) {
-            if (un < n_units) load_tile(un);
+            if (un >= 0) load_tile(un);
         } else {
             load_tile(u);
             stage1();
@@ -348,11 +370,12 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : (PF ? 3 : 4)) void fft7_fwd_ker
         __syncthreads();       // every stage-3 read of the LDS image is done
         FFT7_MARK(5);          // barrier
         if (PF) {
-            if (un < n_units) stage1();
+            if (un >= 0) stage1();
             FFT7_MARK(6);      // wait for the next tile + its stage 1
             __syncthreads();
             FFT7_MARK(7);      // barrier
         }
+        u = un;
     }
     FFT7_FLUSH(0);
 }

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--no-res", action="store_true")
     ap.add_argument("--only", type=int, default=-1, help="index into SHAPES")
     ap.add_argument("--octet", type=int, default=0, help="extra flags for 2-D Winograd shapes: 1 = IN_OCTET, 2 = OUT_OCTET, 3 = both (timing only)")
+    ap.add_argument("--quad", type=int, default=0, help="extra flags for shapes of the F(4,3) x F(4,3) kernel: 1 = IN_QUAD, 2 = OUT_QUAD, 4 = RES_QUAD (timing only: the tensors are random, the bytes moved are the same)")
     ap.add_argument("--bf16", action="store_true", help="time se_conv3d_bf16 (bf16 storage) instead")
     args = ap.parse_args()
     lib = _lib.load()
@@ -58,6 +59,8 @@ def main():
         octet = 0
         if args.octet and not args.bf16 and k == 3 and _lib.conv3d_algo(dim, cin_pad, cout, 3) == 2:
             octet = (_lib.IN_OCTET if args.octet & 1 else 0) | (_lib.OUT_OCTET if args.octet & 2 else 0)
+        if args.quad and not args.bf16 and k == 3 and _lib.conv3d_variant(B, dim, cin_pad, cout, 3, _lib.IN_QUAD) == 3:
+            octet = (_lib.IN_QUAD if args.quad & 1 else 0) | (_lib.OUT_QUAD if args.quad & 2 else 0) | (_lib.RES_QUAD if args.quad & 4 and not args.no_res else 0)
         times = {v: [] for v in variants}
         outs = {}
         for r in range(args.rounds + 2):
