@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0
 # algorithmic work of V2V + soft-argmax per frame at 64^3 / 128^3, fp32
 V2V_GFLOP_PER_FRAME = {64: 299.1, 128: 2393.0}
 V2V_GB_PER_FRAME = {64: 1.372, 128: 10.98}
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc.json")
 JOINT_TOL = 1e-3               # BASELINE.json north_star: joints within 1e-3 m of the reference's CPU forward
 # se_conv3d_f32_algo() -> (kernel name, executed MFMA FLOP / direct-convolution FLOP)
 K3_ALGOS = {
@@ -463,6 +463,13 @@ def main():
         line["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": counter_bytes,
+            # what this kernel STRUCTURE can reach (DESIGN.md section 4, round-5 finding 3): the float32 MFMA issues on
+            # the vector ALUs, so a 4-channel step costs the SUM of its MFMA issue (108 x 32 x 2 waves = 6.9 k cycles per SIMD) and of the
+            # transform / epilogue vector instructions beside it (~1.8 k) = 8.7 k cycles, against 6.9 k for the matrix instructions alone
+            "structural_frac": round(6.9 / 8.7, 3),
+            "structural_frac_what": "ceiling of the F(4,3)xF(4,3) ping-pong structure as a fraction of the f32 MFMA peak: MFMA issue / (MFMA + "
+                                    "vector-ALU issue on the shared ALUs) = 6.9 k / 8.7 k cycles per 4-channel step; the measured step takes "
+                                    "10.5 k (frac = 0.56-0.57): two rounds of issue-side experiments moved it by layout only (profiles/r04_*, r05_*)",
             "kernel": f"conv3d 3x3x3 32->32 @{G}^3 f32, {n_l // psteps} launches/step on v_mfma_f32_16x16x4_f32: {kname}",
             "note": "achieved = EXECUTED matrix-core FLOP per launch / mean launch duration (HIP events on the launch stream, "
                     f"separate {psteps}-step pass outside the timed region), every launch priced at the kernel it ran on "
@@ -509,7 +516,10 @@ def main():
                 "executed_gflop_per_call": round(2.0 * m_tiles * 68 * 32 * 7488 / 1e9, 2),
                 "direct_gflop_per_call": round(2.0 * args.batch * G ** 3 * 343 * 33 * 16 / 1e9, 1),
                 "what": "bytes = input + output + the float32 complex spectra X (33 ch) and Y (16 ch) of every 24^3 tile written once and read "
-                        "once + the weight spectra; the F(6,7) Winograd kernel it replaces (SCENEEGO_FFT7=0) executed 217 GFLOP at B=8"}
+                        "once + the weight spectra; the F(6,7) Winograd kernel it replaces (SCENEEGO_FFT7=0) executed 217 GFLOP at B=8",
+                "traffic": (pmc or {}).get("front_layer_fft", {}).get("hbm_bytes_per_call"),
+                "traffic_what": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 summed over the three passes, from the same committed counter record as "
+                                "roofline.traffic (null when the record is missing or was taken on other kernel sources)"}
     keyb = ("conv3d_bf16", 3, 32, 32, G)
     if keyb in launches:
         ms = launches[keyb]

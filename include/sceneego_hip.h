@@ -230,7 +230,7 @@ int se_voxelize_planar1_f64(const float* depth, const double* ray_tab, float* bu
 
 /* ------------------------------------------------------------------------------------------------
  * The 7x7x7 front layer in the frequency domain (round 6; csrc/conv3d_fft7.hip).  Same reference call site as se_conv3d_f32 with
- * ksize 7: Basic3DBlock(33 -> 16, 7) = Conv3d(k 7, pad 3) + BatchNorm3d + ReLU, network/v2v.py:8-18 (built :147, run :166).
+ * ksize 7: Basic3DBlock(33 | 32 -> 16, 7) = Conv3d(k 7, pad 3) + BatchNorm3d + ReLU, network/v2v.py:8-18 (built :147, run :166).
  * Three launches per chunk of samples: a 24^3 real-to-complex DFT of every (16^3-output tile, input channel), one complex GEMM over the
  * channels per frequency on the matrix cores, the inverse DFT of every (tile, output channel) with bias and ReLU.  float32 throughout;
  * results differ from the direct convolution by float32 rounding of the transforms (~1e-6 of max|y|).
@@ -242,7 +242,7 @@ int se_voxelize_planar1_f64(const float* depth, const double* ray_tab, float* bu
  *   workspace  the spectra of one chunk of samples: se_conv3d_k7_fft_workspace_elems(n, dim, cin) floats hold n samples (0.19 GB per
  *          sample at 64^3); the call walks the batch in chunks of as many samples as the workspace holds (>= 1, else SE_ERR_BAD_ARG).
  *          A workspace serves one stream at a time.
- * Shapes: cin = 33, cout = 16, dim % 16 == 0; the *_elems functions return -1 and the calls SE_ERR_BAD_ARG for anything else
+ * Shapes: cin = 33 (features + occupancy) or 32 (`with_scene: False`), cout = 16, dim % 16 == 0; the *_elems functions return -1 and the calls SE_ERR_BAD_ARG for anything else
  * (se_conv3d_f32 serves those). */
 long long se_conv3d_k7_fft_packed_elems(int cin, int cout);
 int se_conv3d_k7_fft_pack_f32(const float* w, const float* gamma, const float* var, float eps, float* hfrag, int cout, int cin,

@@ -662,7 +662,7 @@ extern "C" int se_debug_fft7_stamps(unsigned long long* host, long long bytes) {
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" long long se_conv3d_k7_fft_packed_elems(int cin, int cout) {
-    if (cin != 33 || cout != 16) return -1;
+    if ((cin != 33 && cin != 32) || cout != 16) return -1;       // 33: features + occupancy; 32: `with_scene: False` (network/voxel_net_depth.py:65-77)
     return (long long)FNF * G_HF_PER_FREQ;
 }
 
@@ -678,14 +678,14 @@ extern "C" int se_conv3d_k7_fft_pack_f32(const float* w, const float* gamma, con
 
 // floats of workspace for `batch` samples in ONE chunk (spectra X and Y of every tile)
 extern "C" long long se_conv3d_k7_fft_workspace_elems(int batch, int dim, int cin) {
-    if (batch <= 0 || dim < 16 || (dim & 15) || cin != 33) return -1;
+    if (batch <= 0 || dim < 16 || (dim & 15) || (cin != 33 && cin != 32)) return -1;
     const long long T = dim / 16, M = ((long long)batch * T * T * T + 15) / 16 * 16;       // whole groups of 16 tiles
     return M * (cin + 16) * FNF * 2;
 }
 
 extern "C" int se_conv3d_k7_fft_f32(const float* in, const float* hfrag, const float* bpack, float* out, int batch, int dim, int cin,
                                     int cout, int flags, float* workspace, long long workspace_elems, void* stream) {
-    if (batch <= 0 || dim < 16 || (dim & 15) || cin != 33 || cout != 16 || !in || !hfrag || !bpack || !out || !workspace) return SE_ERR_BAD_ARG;
+    if (batch <= 0 || dim < 16 || (dim & 15) || (cin != 33 && cin != 32) || cout != 16 || !in || !hfrag || !bpack || !out || !workspace) return SE_ERR_BAD_ARG;
     if (flags & ~(SE_EPI_RELU | SE_OUT_QUAD)) return SE_ERR_BAD_ARG;
     const long long per_sample = se_conv3d_k7_fft_workspace_elems(1, dim, cin);
     int chunk = (int)(workspace_elems / per_sample < batch ? workspace_elems / per_sample : batch);
@@ -709,6 +709,8 @@ extern "C" int se_conv3d_k7_fft_f32(const float* in, const float* hfrag, const f
     auto invq = fft7_inv_kernel<true, SE_FFT7_INV_NT>;
     auto invc = fft7_inv_kernel<false, SE_FFT7_INV_NT>;
     SE_ENSURE_LDS(fwd, f1_lds);
+    SE_ENSURE_LDS(fft7_gemm_kernel<33>, G_LDS_BYTES);
+    SE_ENSURE_LDS(fft7_gemm_kernel<32>, G_LDS_BYTES);
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = batch - b0 < chunk ? batch - b0 : chunk;
         const int M = nb * T * T * T;
@@ -726,7 +728,9 @@ extern "C" int se_conv3d_k7_fft_f32(const float* in, const float* hfrag, const f
             int split = (4 * cus + FNFB - 1) / FNFB;                    // ~4 workgroups per CU over the launch
             if (split > n_groups) split = n_groups;
             const int gpw = (n_groups + split - 1) / split;
-            hipLaunchKernelGGL(fft7_gemm_kernel<33>, dim3(FNFB, (n_groups + gpw - 1) / gpw), dim3(G_THREADS), G_LDS_BYTES, s, X, hfrag, Yb, M, gpw);
+            const dim3 ggrid(FNFB, (n_groups + gpw - 1) / gpw);
+            if (cin == 33) hipLaunchKernelGGL(fft7_gemm_kernel<33>, ggrid, dim3(G_THREADS), G_LDS_BYTES, s, X, hfrag, Yb, M, gpw);
+            else hipLaunchKernelGGL(fft7_gemm_kernel<32>, ggrid, dim3(G_THREADS), G_LDS_BYTES, s, X, hfrag, Yb, M, gpw);
             SE_CHECK_LAUNCH();
         }
         {

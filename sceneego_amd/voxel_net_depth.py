@@ -296,6 +296,9 @@ class VoxelNetwork_depth(nn.Module):
         planar1 = planar3 and prog.fft7_ready(G)
         if planar1:
             planar3 = False
+        # `with_scene: False` (V2VModel(32, 15) on the feature volume alone, reference :65-77): the same planar form, 32 planes, no occupancy
+        if self.with_scene is not True and not bf16 and prog.cin == C and prog.fft7_ready(G) and self.planar3_input:
+            planar1 = True
         xkey = (B, G, prog.cin_pad, str(dev), prog.dtype, planar3, planar1)
         x = self._xbuf.get(xkey)
         if x is None:
@@ -304,7 +307,7 @@ class VoxelNetwork_depth(nn.Module):
             if planar3:
                 shape = (B, (C + 3) // 3, G, G, G, 3)
             if planar1:
-                shape = (B, C + 1, G, G, G)
+                shape = (B, prog.cin, G, G, G)
             x = torch.zeros(shape, device=dev, dtype=prog.dtype)
             self._xbuf[xkey] = x
         xb = None
@@ -316,7 +319,7 @@ class VoxelNetwork_depth(nn.Module):
             raise ValueError("gather table addresses texel %d of a %d-texel feature map" % (self._gather_max, texels))
         with _lib.stage("gather"):
             if planar1:
-                _lib.unproject_gather_planar1(feat_nhwc, self._gather_idx, self._gather_w, x, B, texels, C, N, C + 1)
+                _lib.unproject_gather_planar1(feat_nhwc, self._gather_idx, self._gather_w, x, B, texels, C, N, prog.cin)
             elif planar3:
                 _lib.unproject_gather_planar3(feat_nhwc, self._gather_idx, self._gather_w, x, B, texels, C, N, x.shape[1])
             else:
@@ -351,6 +354,8 @@ class VoxelNetwork_depth(nn.Module):
 
     def _voxelise(self, x, planar3, fast_occ, prog, scene_volumes, depth_map_batch, B, G, N, C, dev, planar1=False):
         """Occupancy into the V2V input buffer ``x`` (reference ``:246-262``)."""
+        if planar1 and self.with_scene is not True:
+            return                    # no occupancy channel
         if planar1:
             # the gather zeroed plane 32; the voxeliser scatters the occupancy into it
             depth = depth_map_batch.reshape(B, depth_map_batch.shape[-2], depth_map_batch.shape[-1]).float().contiguous()

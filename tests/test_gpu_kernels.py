@@ -1203,11 +1203,33 @@ def test_conv7_fft_front_layer_vs_torch():
     got = out.view(1, 32, 32, 32, 16).permute(0, 4, 1, 2, 3).cpu()
     assert float(got.min()) < 0 and float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
     lib = _lib.load()
-    assert lib.se_conv3d_k7_fft_packed_elems(32, 16) == -1 and lib.se_conv3d_k7_fft_workspace_elems(1, 24, 33) == -1
+    assert lib.se_conv3d_k7_fft_packed_elems(65, 16) == -1 and lib.se_conv3d_k7_fft_workspace_elems(1, 24, 33) == -1
+    assert lib.se_conv3d_k7_fft_packed_elems(33, 32) == -1
     p = ctypes.c_void_p(out.data_ptr())
     assert lib.se_conv3d_k7_fft_f32(p, p, p, p, 1, 24, 33, 16, 0, p, 1 << 40, None) == -1               # dim % 16
     assert lib.se_conv3d_k7_fft_f32(p, p, p, p, 1, 32, 33, 16, 0, p, 1000, None) == -1                   # workspace below one sample
     assert lib.se_conv3d_k7_fft_f32(p, p, p, p, 1, 32, 33, 16, _lib.EPI_RES_PRE_RELU, p, 1 << 40, None) == -1
+
+
+def test_conv7_fft_32_input_channels_vs_torch():
+    """`with_scene: False` (reference network/voxel_net_depth.py:65-77): V2VModel(32, 15), the front layer has 32 input channels and no
+    occupancy plane - fft7_gemm_kernel<32> (K = 64: the 17th k-step meets zero weights and the zeroed LDS padding)."""
+    B, dim = 2, 32
+    conv, bn = _conv_bn(32, 16, 7, 68)
+    x = torch.from_numpy(synth.normal(68, "x", (B, 32, dim, dim, dim)))
+    with torch.no_grad():
+        want = F.relu(bn(conv(x)))
+    conv, bn = conv.to(DEV), bn.to(DEV)
+    pc = _PackedConv(conv, bn, cin_pad=32)
+    hf = _lib.conv3d_k7_fft_pack(conv.weight.detach().float().contiguous(), bn.weight.detach().float().contiguous(),
+                                 bn.running_var.detach().float().contiguous(), bn.eps, 16, 32)
+    ws = torch.full((_lib.conv3d_k7_fft_workspace_elems(B, dim, 32),), float("nan"), device=DEV)
+    out = torch.full((B, 16 * dim ** 3), -77.0, device=DEV)
+    _lib.conv3d_k7_fft(x.to(DEV), hf, pc.b, out, B, dim, 32, 16, _lib.EPI_RELU | _lib.OUT_QUAD, ws)
+    got = _fft7_unquad(out, B, dim).cpu()
+    err, scale = float((got - want).abs().max()), float(want.abs().max())
+    print(f"fft7 32->16 @{dim}^3 B={B}: max|hip - torch f32| = {err:.2e} ({err / scale:.2e} of max|y|)")
+    assert bool(torch.isfinite(got).all()) and err < 2e-5 * scale, (err, scale)
 
 
 def test_conv7_fft_repeat_launches_bit_identical_and_batch_invariant():

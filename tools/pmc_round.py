@@ -27,7 +27,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-TAG = "r05"
+TAG = "r06"
 PASSES = [
     ["FETCH_SIZE"],
     ["WRITE_SIZE"],
@@ -39,7 +39,8 @@ PASSES = [
 ]
 BENCH = ["python3", "bench.py", "--steps", "2", "--warmup", "1", "--streams", "1", "--no-cpu-baseline", "--no-parity",
          "--no-kernel-events", "--no-extras"]
-OURS = ("conv3d_", "deconv3d_", "maxpool2", "pointwise_chain3", "softargmax_", "::gather_", "voxelize_", "splitk_reduce")
+OURS = ("conv3d_", "deconv3d_", "maxpool2", "pointwise_chain3", "softargmax_", "::gather_", "voxelize_", "splitk_reduce", "fft7_")
+FRONT = ("conv3d_k7", "fft7_fwd")       # the 7^3 front layer: Winograd kernel, or pass 1 of the frequency-domain form
 
 
 def short(n):
@@ -76,12 +77,12 @@ def run_pass(counters, batch, G):
     for e in disp.values():
         n = e["name"]
         if "::gather_" in n or "voxelize_kernel" in n:
-            if cur is None or any("conv3d_k7" in x["name"] for x in cur):
+            if cur is None or any(any(f in x["name"] for f in FRONT) for x in cur):
                 cur = []
                 steps.append(cur)
         if cur is not None and any(k in n for k in OURS) and "pack" not in n:
             cur.append(e)
-    steps = [s for s in steps if any("conv3d_k7" in x["name"] for x in s)]
+    steps = [s for s in steps if any(any(f in x["name"] for f in FRONT) for x in s)]
     return steps[-1] if steps else None
 
 
@@ -227,6 +228,19 @@ def main():
                         "algorithmic_bytes_per_launch": 4 * batch * G ** 3 * (33 + 16),
                         "mfma_busy_cycles": c.get("SQ_VALU_MFMA_BUSY_CYCLES"),
                         "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"), "lds_active_cycles": c.get("SQ_LDS_IDX_ACTIVE")}
+    fft = [t for t in table if "fft7_" in t["kernel"]]
+    if fft:       # the frequency-domain front layer: its three passes, counter bytes against the byte model of bench.py's roofline.front_layer
+        m_tiles = batch * (G // 16) ** 3
+        rec["front_layer_fft"] = {
+            "passes": [{"kernel": t["kernel"], "fetch_kib_raw": t["counters"].get("FETCH_SIZE"), "write_kib": t["counters"].get("WRITE_SIZE"),
+                        "hbm_bytes": int((2 * t["counters"].get("FETCH_SIZE", 0) + t["counters"].get("WRITE_SIZE", 0)) * 1024),
+                        "mfma_busy_cycles": t["counters"].get("SQ_VALU_MFMA_BUSY_CYCLES"), "lds_bank_conflict_cycles": t["counters"].get("SQ_LDS_BANK_CONFLICT"),
+                        "lds_active_cycles": t["counters"].get("SQ_LDS_IDX_ACTIVE"), "insts_vmem_rd": t["counters"].get("SQ_INSTS_VMEM_RD"),
+                        "insts_vmem_wr": t["counters"].get("SQ_INSTS_VMEM_WR"), "wait_any": t["counters"].get("SQ_WAIT_ANY"),
+                        "wave_cycles": t["counters"].get("SQ_WAVE_CYCLES")} for t in fft],
+            "hbm_bytes_per_call": int(sum((2 * t["counters"].get("FETCH_SIZE", 0) + t["counters"].get("WRITE_SIZE", 0)) * 1024 for t in fft)),
+            "model_bytes_per_call": int(4.0 * batch * G ** 3 * (33 + 16) + 2.0 * m_tiles * (33 + 16) * 7488 * 8 + 7488 * 17 * 128 * 4.0),
+            "algorithmic_bytes_per_call": 4 * batch * G ** 3 * (33 + 16)}
     with open(os.path.join(OUT, TAG + "_pmc.json"), "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec)[:600])
