@@ -300,6 +300,14 @@ int se_pointwise_chain3_bf16(const se_bf16* in, const se_bf16* wpack1, const flo
                              const se_bf16* wpack2, const float* bpack2, const se_bf16* wpack3, const float* bpack3,
                              float* out, int batch, int dim, int cout3, void* stream);
 
+/* se_pointwise_chain3_bf16 with pass 1 of se_softargmax3d_f32 (mode 1: softmax) folded in, as se_pointwise_chain3_softargmax_f32 does for
+ * the float32 program (round 6): the float32 logits are written to `out` and, while in registers, reduced to the per-chunk partial records
+ * in `scratch` (se_softargmax3d_scratch_elems(batch * cout3) floats); finish with se_softargmax3d_finish_f32.  network/v2v.py:155-161 +
+ * the first half of utils/op.py:83-96. */
+int se_pointwise_chain3_softargmax_bf16(const se_bf16* in, const se_bf16* wpack1, const float* bpack1, const se_bf16* wpack2,
+                                        const float* bpack2, const se_bf16* wpack3, const float* bpack3, float* out,
+                                        const float* coord, float* scratch, int batch, int dim, int cout3, void* stream);
+
 int se_deconv3d_k2s2_bf16(const se_bf16* in, const se_bf16* wpack, const float* bpack, const se_bf16* residual,
                           se_bf16* out, int batch, int dim, int cin, int cout, int flags, void* stream);
 int se_maxpool3d_2_bf16(const se_bf16* in, se_bf16* out, int batch, int dim, int channels, void* stream);

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -61,6 +61,7 @@ SIGNATURES = {
     "se_conv3d_packed_elems_bf16": (_ll, [_i, _i, _i, _i]),
     "se_conv3d_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "se_pointwise_chain3_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "se_pointwise_chain3_softargmax_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "se_deconv3d_k2s2_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_maxpool3d_2_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "se_unproject_gather_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -516,8 +517,16 @@ def pointwise_chain3(inp, pc1, pc2, pc3, out, batch, dim, softargmax=None, in_qu
     if softargmax is not None:
         coord, scratch = softargmax
         require_hip(coord, scratch)
-        _chk_f32(inp, coord, scratch)
+        _chk_f32(coord, scratch)
         assert scratch.numel() >= softargmax3d_scratch_elems(batch * pc3.cout) and coord.numel() == 3 * dim ** 3
+        if inp.dtype == torch.bfloat16:
+            assert not in_quad
+            with _timed(("tail_bf16", 1, 32, pc3.cout, dim)):
+                _check(load().se_pointwise_chain3_softargmax_bf16(_ptr(inp), _ptr(pc1.w), _ptr(pc1.b), _ptr(pc2.w), _ptr(pc2.b), _ptr(pc3.w),
+                                                                  _ptr(pc3.b), _ptr(out), _ptr(coord), _ptr(scratch), batch, dim, pc3.cout,
+                                                                  _stream()), "se_pointwise_chain3_softargmax_bf16")
+            return
+        _chk_f32(inp)
         with _timed(("tail", 1, 32, pc3.cout, dim)):
             _check(load().se_pointwise_chain3_softargmax_f32(_ptr(inp), _ptr(pc1.w), _ptr(pc1.b), _ptr(pc2.w), _ptr(pc2.b), _ptr(pc3.w),
                                                              _ptr(pc3.b), _ptr(out), _ptr(coord), _ptr(scratch), batch, dim, pc3.cout,

@@ -358,6 +358,93 @@ __global__ __launch_bounds__(256) void pointwise_chain3_bf16_kernel(
     }
 }
 
+// The same chain with pass 1 of the soft-argmax folded in (round 6; the float32 program has had this since round 4:
+// pointwise_chain3_sa_kernel in conv3d.hip, same chunking, same SE_SA_PART records, same fixed-order fold): the workgroup (chunk s,
+// sample b) owns the voxels [s * chunk, (s + 1) * chunk) of its sample, every lane keeps a running (max, sum exp, sum exp * coord) for its
+// 4 joints while the float32 logits are in registers, and softargmax_finish_kernel does pass 2.  Saves the two stand-alone launches of
+// se_softargmax3d_f32's pass 1 and their re-read of the logits (0.35 ms at B = 32).  Reference: utils/op.py:83-96.
+constexpr int PWB_SA_WAVES = 16;
+__global__ __launch_bounds__(PWB_SA_WAVES * 64) void pointwise_chain3_sa_bf16_kernel(
+    const unsigned short* __restrict__ in, const unsigned short* __restrict__ w1, const float* __restrict__ b1,
+    const unsigned short* __restrict__ w2, const float* __restrict__ b2, const unsigned short* __restrict__ w3,
+    const float* __restrict__ b3, float* __restrict__ out, const float* __restrict__ coord, float* __restrict__ scratch, int vox_per_b,
+    int chunk, int cout3, int splits) {
+    extern __shared__ __attribute__((aligned(16))) float pwb_sa_lds[];
+    float (*red)[64][20] = reinterpret_cast<float (*)[64][20]>(pwb_sa_lds);        // [PWB_SA_WAVES][64][20]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int v = lane & 15, g = lane >> 4;
+    const int s = blockIdx.x, b = blockIdx.y;
+    const int v0 = s * chunk, v1 = min(v0 + chunk, vox_per_b);
+    const u16x8 A10 = *reinterpret_cast<const u16x8*>(w1 + lane * 8);
+    const u16x8 A11 = *reinterpret_cast<const u16x8*>(w1 + 512 + lane * 8);
+    const u16x8 A20 = *reinterpret_cast<const u16x8*>(w2 + lane * 8);
+    const u16x8 A21 = *reinterpret_cast<const u16x8*>(w2 + 512 + lane * 8);
+    const u16x8 A30 = *reinterpret_cast<const u16x8*>(w3 + lane * 8);
+    const f32x4 bias3 = *reinterpret_cast<const f32x4*>(b3 + 4 * g);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const unsigned short* inb = in + (long long)b * vox_per_b * 32 + g * 8;
+    float m[4], l[4], sx[4], sy[4], sz[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = sx[r] = sy[r] = sz[r] = 0.f; }
+    for (int t0 = v0 + wave * 16; t0 < v1; t0 += PWB_SA_WAVES * 16) {
+        const int n = t0 + v;
+        const bool ok = n < v1;
+        u16x8 B0 = {0, 0, 0, 0, 0, 0, 0, 0};
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        if (ok) {
+            B0 = *reinterpret_cast<const u16x8*>(inb + (long long)n * 32);
+            cx = coord[(size_t)n * 3]; cy = coord[(size_t)n * 3 + 1]; cz = coord[(size_t)n * 3 + 2];
+        }
+        const u16x8 B1 = relu_pack(mfma_bf16(A10, B0, zero), mfma_bf16(A11, B0, zero), b1, g);
+        const u16x8 B2 = relu_pack(mfma_bf16(A20, B1, zero), mfma_bf16(A21, B1, zero), b2, g);
+        f32x4 r4 = mfma_bf16(A30, B2, zero);
+        r4 += bias3;
+        if (ok) {
+            float* o = out + ((long long)b * cout3 + 4 * g) * vox_per_b + n;
+            const float vv[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (4 * g + r < cout3) {
+                    o[(long long)r * vox_per_b] = vv[r];
+                    if (vv[r] > m[r]) {      // new running maximum: rescale the sums (exp(-inf) = 0 clears them the first time)
+                        const float sc = __expf(m[r] - vv[r]);
+                        l[r] *= sc; sx[r] *= sc; sy[r] *= sc; sz[r] *= sc;
+                        m[r] = vv[r];
+                    }
+                    const float e = __expf(vv[r] - m[r]);
+                    l[r] += e;
+                    sx[r] = fmaf(e, cx, sx[r]);
+                    sy[r] = fmaf(e, cy, sy[r]);
+                    sz[r] = fmaf(e, cz, sz[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float* e = &red[wave][lane][r * 5];
+        e[0] = m[r]; e[1] = l[r]; e[2] = sx[r]; e[3] = sy[r]; e[4] = sz[r];
+    }
+    __syncthreads();
+    const int j = threadIdx.x;
+    if (j < cout3) {          // joint j: the 16 x PWB_SA_WAVES (wave, voxel lane) partials of k lane j / 4, slot j % 4, folded in a fixed order
+        const int hh = j >> 2, rr = (j & 3) * 5;
+        float M = -INFINITY;
+        for (int w = 0; w < PWB_SA_WAVES; ++w)
+            for (int q = 0; q < 16; ++q) M = fmaxf(M, red[w][hh * 16 + q][rr]);
+        float L = 0.f, SX = 0.f, SY = 0.f, SZ = 0.f;
+        for (int w = 0; w < PWB_SA_WAVES; ++w)
+            for (int q = 0; q < 16; ++q) {
+                const float* e = &red[w][hh * 16 + q][rr];
+                const float f = (e[0] == -INFINITY) ? 0.f : __expf(e[0] - M);     // a lane that saw no voxel contributes nothing
+                L += e[1] * f; SX += e[2] * f; SY += e[3] * f; SZ += e[4] * f;
+            }
+        float* p = scratch + (((size_t)b * cout3 + j) * splits + s) * SE_SA_PART;
+        p[0] = M; p[1] = L; p[2] = SX; p[3] = SY; p[4] = SZ;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // bilinear voxel gather with bf16 output: thread = (voxel, octet); see gather.hip for the float32 form
 // ------------------------------------------------------------------------------------------------
@@ -499,6 +586,24 @@ extern "C" int se_pointwise_chain3_bf16(const se_bf16* in, const se_bf16* wpack1
     const unsigned grid = (unsigned)((tiles + 3) / 4 < 256 * 16 ? (tiles + 3) / 4 : 256 * 16);
     hipLaunchKernelGGL(pointwise_chain3_bf16_kernel, dim3(grid), dim3(256), 0, se_stream(stream), in, wpack1, bpack1, wpack2,
                        bpack2, wpack3, bpack3, out, total, vpb, cout3);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+// se_pointwise_chain3_bf16 + pass 1 of se_softargmax3d_f32 (mode 1) in one launch; finish with se_softargmax3d_finish_f32.
+extern "C" int se_pointwise_chain3_softargmax_bf16(const se_bf16* in, const se_bf16* wpack1, const float* bpack1, const se_bf16* wpack2,
+                                                   const float* bpack2, const se_bf16* wpack3, const float* bpack3, float* out,
+                                                   const float* coord, float* scratch, int batch, int dim, int cout3, void* stream) {
+    if (batch <= 0 || dim <= 0 || cout3 <= 0 || cout3 > 16 || !coord || !scratch) return SE_ERR_BAD_ARG;
+    const long long vox_per_b = (long long)dim * dim * dim;
+    if (vox_per_b >= (1LL << 31) || (vox_per_b & 3)) return SE_ERR_BAD_ARG;
+    const int splits = se_sa_splits(batch * cout3);                                               // as softargmax.hip
+    const int chunk = (int)((((vox_per_b + splits - 1) / splits) + 3) & ~3LL);
+    if (chunk & 15) return SE_ERR_BAD_ARG;                                                       // whole 16-voxel tiles per chunk
+    constexpr int LDS = PWB_SA_WAVES * 64 * 20 * 4;
+    SE_ENSURE_LDS(pointwise_chain3_sa_bf16_kernel, LDS);
+    hipLaunchKernelGGL(pointwise_chain3_sa_bf16_kernel, dim3(splits, batch), dim3(PWB_SA_WAVES * 64), LDS, se_stream(stream), in, wpack1,
+                       bpack1, wpack2, bpack2, wpack3, bpack3, out, coord, scratch, (int)vox_per_b, chunk, cout3, splits);
     SE_CHECK_LAUNCH();
     return 0;
 }

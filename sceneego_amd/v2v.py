@@ -490,8 +490,9 @@ class V2VProgram:
             dim *= 2
         # back layers + output (v2v.py:155-161)
         # the fused tail with the soft-argmax pass reads a quad-planar tensor as well: back_layers.0 then writes whole records
-        sa = softargmax if self.dtype == torch.float32 else None
-        tail_quad = self.cout <= 16 and sa is not None and not self.split3 and self._planar(self.back_res, G, B) == "quad"
+        sa = softargmax            # (coord, scratch): pass 1 of the soft-argmax rides in the tail launch (float32 since round 4, bf16 since round 6)
+        tail_quad = (self.dtype == torch.float32 and self.cout <= 16 and sa is not None and not self.split3
+                     and self._planar(self.back_res, G, B) == "quad")
         x = self._res(x, self.back_res, B, G, x_lay=x_lay, out_planar=tail_quad)
         if out is None:
             out = torch.empty((B, self.cout, G * G * G), device=self.device, dtype=torch.float32)

@@ -332,7 +332,7 @@ class VoxelNetwork_depth(nn.Module):
             x = xb
         # float32 V2V with softmax volumes: pass 1 of the soft-argmax is computed by the V2V tail launch while the (scaled) logits
         # are in registers (se_pointwise_chain3_softargmax_f32); otherwise the two-pass kernel reads them back
-        fused_sa = (prog.dtype == torch.float32 and self.volume_softmax and prog.cout <= 16
+        fused_sa = (self.volume_softmax and prog.cout <= 16
                     and ((N + 31) // 32 + 3) // 4 * 4 % 16 == 0)
         sa_scratch = torch.empty(_lib.softargmax3d_scratch_elems(B * self.num_joints), device=dev, dtype=torch.float32) if fused_sa else None
         with _lib.stage("v2v"):

@@ -95,21 +95,27 @@ def test_config3_b32_bf16_accuracy(golden, golden_meta):
     # logits of both programs on the same input: the bound that does not depend on the sharpness of the soft-argmax
     from test_gpu_bf16 import BF16_LOGIT_RMS_TOL
     cap = {}
-    orig = _lib.softargmax3d
+    orig, orig_finish = _lib.softargmax3d, _lib.softargmax3d_finish
 
-    def hook(vol, *a, **k):
+    def hook(vol, *a, **k):             # the two-pass kernel: (logits, coord, ...)
         cap["logits"] = vol.clone()
         return orig(vol, *a, **k)
-    _lib.softargmax3d = hook
+
+    def hook_finish(vol, *a, **k):      # pass 2 behind a fused tail (float32 since round 4, bf16 since round 6): (logits, scratch, ...)
+        cap["logits"] = vol.clone()
+        return orig_finish(vol, *a, **k)
+    _lib.softargmax3d, _lib.softargmax3d_finish = hook, hook_finish
     try:
         _forward(net, img[:4], depth[:4])
-        lg_b = cap["logits"].double()
+        lg_b = cap.pop("logits").double()
         net.set_v2v_dtype("fp32")
         kp32 = _forward(net, img, depth)[0]
+        cap.clear()
         _forward(net, img[:4], depth[:4])
-        lg_f = cap["logits"].double()
+        lg_f = cap.pop("logits").double()
     finally:
-        _lib.softargmax3d = orig
+        _lib.softargmax3d, _lib.softargmax3d_finish = orig, orig_finish
+    assert not torch.equal(lg_b, lg_f)          # two programs, two captures
     rel = float((lg_b - lg_f).pow(2).mean().sqrt() / lg_f.std())
     err = float((kp - kp32).abs().max())
     print(f"bf16 B=32: max joint difference to the float32 program over all 32 frames {err:.2e} m; logits rms error {rel:.2e} x std")
