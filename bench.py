@@ -464,12 +464,13 @@ def main():
             "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": counter_bytes,
             # what this kernel STRUCTURE can reach (DESIGN.md section 4, round-5 finding 3): the float32 MFMA issues on
-            # the vector ALUs, so a 4-channel step costs the SUM of its MFMA issue (108 x 32 x 2 waves = 6.9 k cycles per SIMD) and of the
-            # transform / epilogue vector instructions beside it (~1.8 k) = 8.7 k cycles, against 6.9 k for the matrix instructions alone
-            "structural_frac": round(6.9 / 8.7, 3),
-            "structural_frac_what": "ceiling of the F(4,3)xF(4,3) ping-pong structure as a fraction of the f32 MFMA peak: MFMA issue / (MFMA + "
-                                    "vector-ALU issue on the shared ALUs) = 6.9 k / 8.7 k cycles per 4-channel step; the measured step takes "
-                                    "10.5 k (frac = 0.56-0.57): two rounds of issue-side experiments moved it by layout only (profiles/r04_*, r05_*)",
+            # the vector ALUs, so a 4-channel step costs the SUM of its MFMA issue (6.9 k cycles per SIMD) and of the transform / epilogue
+            # vector instructions beside it (~1.8 k) = 8.7 k cycles; the measured step takes 10.5 k at frac 0.557 -> 0.557 x 10.5 / 8.7
+            "structural_frac": 0.67,
+            "structural_frac_what": "ceiling of the F(4,3)xF(4,3) ping-pong structure on this pipe: the measured fraction scaled from the 10.5 k "
+                                    "cycles a 4-channel step takes to the 8.7 k of its MFMA + vector-ALU issue (the float32 MFMA shares the "
+                                    "vector ALUs: the two add up; 6.9 k of it is MFMA): 0.557 x 10.5 / 8.7.  Two rounds of issue-side experiments "
+                                    "moved the kernel by layout only (profiles/r04_*, r05_*); round 6 left it alone (DESIGN.md section 6)",
             "kernel": f"conv3d 3x3x3 32->32 @{G}^3 f32, {n_l // psteps} launches/step on v_mfma_f32_16x16x4_f32: {kname}",
             "note": "achieved = EXECUTED matrix-core FLOP per launch / mean launch duration (HIP events on the launch stream, "
                     f"separate {psteps}-step pass outside the timed region), every launch priced at the kernel it ran on "

@@ -1280,7 +1280,7 @@ def test_planar1_producers_bit_exact(voxel_setup, oracle_constants):
     assert lib.se_voxelize_planar1_f64(p, p, p, 1, 1024, 1280, 1024, 128, 64, 2.0, 33, 33, None) == -1
 
 
-@pytest.mark.parametrize("B,dim", [(1, 64), (2, 32)])
+@pytest.mark.parametrize("B,dim", [(1, 64), (8, 32)])      # 32^3 is on the F(4,3) x F(4,3) kernel from 256 units on: batch 8
 def test_conv3d_fused_skip_convolution_quad_planar_skip_input(B, dim):
     """se_conv3d_skip16_f32 with SE_RES_QUAD: the 16-channel input of the fused 1x1x1 skip convolution is quad-planar [B][4][D^3][4]
     (what the frequency-domain front layer writes) - same bits as the channels-last form of the same launch."""
