@@ -101,6 +101,17 @@ int se_intersection_f32(float* buf, const float* occ, int batch, int voxels, int
 int se_bias_act_nchw_f32(const float* x, const float* bias, const float* residual, float* out,
                          int batch, int channels, int hw, int relu, void* stream);
 
+/* 1x1 convolution (stride 1) of the backbone as ONE float32 MFMA GEMM with its whole epilogue: replaces conv1 / conv3 / the stride-1
+ * downsample of Bottleneck.forward with their BatchNorm (folded into w and bias), `out += residual` and the ReLU
+ * (network/pose_resnet.py:72-90) - MIOpen's convolution plus the se_bias_act_nchw_f32 pass behind it (round 6; csrc/conv2d_1x1.hip).
+ *   x [batch][cin][hw], residual (or NULL) / out [batch][cout][hw] float32 NCHW;  bias [cout]
+ *   wpack = the folded [cout][cin] matrix as [cout / BC][cin / 16][BC][16] with BC = se_conv2d_1x1_tile_f32(batch, cin, cout, hw)
+ *   (128 when cout % 128 == 0, else 64; 0 = shape not covered: cin % 16, cout % 64, hw % 16, batch * hw % 64 must be 0).
+ * float32 in, float32 accumulate: differs from the MIOpen result by summation order only. */
+int se_conv2d_1x1_tile_f32(int batch, int cin, int cout, int hw);
+int se_conv2d_1x1_f32(const float* x, const float* wpack, const float* bias, const float* residual, float* out, int batch, int cin,
+                      int cout, int hw, int relu, void* stream);
+
 /* Output side of the 2-D pose head's transposed convolutions - ConvTranspose2d(k=4, s=2, p=1) + BatchNorm2d + ReLU,
  * network/pose_resnet.py:205-224 (built), :238 (run) - when the layer is computed as ONE GEMM over the un-shifted input:
  *   z    [batch][4 ky][4 kx][cout][h][w] = W_tap [cout x cin] @ x[b] [cin x h*w] for each of the 16 taps (any GEMM library;

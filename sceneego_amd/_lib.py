@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -44,6 +44,8 @@ SIGNATURES = {
     "se_intersection_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "se_bias_act_nchw_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_deconv2d_k4s2_assemble_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_conv2d_1x1_tile_f32": (_i, [_i, _i, _i, _i]),
+    "se_conv2d_1x1_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_packed_elems": (_ll, [_i, _i, _i, _i]),
     "se_conv3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
@@ -285,6 +287,30 @@ def bias_act_nchw(x, bias, residual, relu):
     _check(load().se_bias_act_nchw_f32(_ptr(x), _ptr(bias), _ptr(residual), _ptr(x), n, c, hh * ww, 1 if relu else 0,
                                        _stream()), "se_bias_act_nchw_f32")
     return x
+
+
+def conv2d_1x1_tile(batch, cin, cout, hw) -> int:
+    """Channel-tile width the packed weights of a 1x1 convolution need (128 / 64), 0 when se_conv2d_1x1_f32 does not cover the shape."""
+    return int(load().se_conv2d_1x1_tile_f32(batch, cin, cout, hw))
+
+
+def conv2d_1x1_pack(w2d, tile):
+    """Folded [cout, cin] matrix -> [cout / tile, cin / 16, tile, 16] (the layout se_conv2d_1x1_f32 streams per (channel tile, k step))."""
+    cout, cin = w2d.shape
+    return w2d.reshape(cout // tile, tile, cin // 16, 16).permute(0, 2, 1, 3).contiguous()
+
+
+def conv2d_1x1(x, wpack, bias, residual, relu):
+    """``x`` [B, cin, H, W] NCHW float32 -> relu?(W x + bias (+ residual)) [B, cout, H, W] in one launch (se_conv2d_1x1_f32)."""
+    require_hip(x, wpack, bias)
+    _chk_f32(x, wpack, bias, residual)
+    B, cin, H, W = x.shape
+    cout = wpack.shape[0] * wpack.shape[2]
+    assert wpack.dim() == 4 and wpack.shape[1] * 16 == cin and wpack.shape[2] == conv2d_1x1_tile(B, cin, cout, H * W)
+    out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+    _check(load().se_conv2d_1x1_f32(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(residual), _ptr(out), B, cin, cout, H * W,
+                                    1 if relu else 0, _stream()), "se_conv2d_1x1_f32")
+    return out
 
 
 def deconv2d_k4s2_assemble(z, bias, batch, cout, h, w, relu=True):

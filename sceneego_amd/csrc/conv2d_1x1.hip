@@ -1,0 +1,201 @@
+// 1x1 convolutions of the 2-D backbone as a float32 MFMA GEMM with the whole epilogue fused (round 6).
+//
+// Stands in for the three 1x1 convolutions of every ResNet-50 Bottleneck - conv1, conv3 and the stride-1 downsample - with their folded
+// BatchNorm, the residual add and the ReLU (reference network/pose_resnet.py:52-90, Bottleneck.forward :72-90): 32 of the backbone's 53
+// convolutions.  MIOpen runs them as strided-batched Tensile GEMMs at 32-68 TFLOP/s (profiles/r04_backbone_solvers.txt) and the bias /
+// residual / ReLU cost one more pass each (se_bias_act_nchw_f32): 1.04 + 0.22 ms of the 2.03 ms backbone at B = 8.  Most of these layers
+// are short-K products (K = 64 ... 512 channels) over tens of thousands of pixels: the expanding convolutions of layer1 move 75 MB for
+// 2 MFLOP per 64 KB - they are bound by bytes, and a fused epilogue removes two of their four tensor passes.
+//
+// NCHW in, NCHW out (what the 3x3 convolutions of MIOpen around them read and write).  GEMM roles: MFMA rows = PIXELS, MFMA columns =
+// output channels, so a lane's D fragment is 4 consecutive pixels of one channel: one 16-byte store (and one 16-byte residual load) in NCHW.
+//   workgroup (256 threads = 2 x 2 waves) = BP pixels x BC output channels; per 16 input channels: the X tile [16][BP] (rows of the NCHW
+//   tensor as they lie in memory, 16-byte loads) and the W tile [BC][16] (pre-packed per (channel tile, k step): one contiguous run) go
+//   through registers into the other half of a double-buffered LDS image while the matrix cores work on this one; operands: ds_read_b32
+//   of X[4 kg + j][pixel] and ds_read_b128 of W[cout][4 kg .. 4 kg + 3] (k = 4 kg + j on both sides), rows padded conflict-free.
+// float32 in, float32 accumulate (v_mfma_f32_16x16x4_f32: bitwise an fmaf chain) - results differ from MIOpen's by summation order only.
+#include "common.h"
+
+namespace {
+
+constexpr int C1_SPLIT_MIN_CIN = 128;   // k split over two wave groups from here on (8+ k steps): 17.4 -> 14.8 us at 512 -> 128 @32^2, 18.5 -> 16.1 at 256 -> 1024 @16^2; layer1's 64-channel inputs lose 1 us
+constexpr int C1_LDW = 24;          // floats per cout row of the W image (16 k + 8: conflict-free ds_read_b128 over the 4 x 16 lane groups)
+
+template <int BP>
+struct C1Geom {
+    static constexpr int LDX = BP + 4;                                  // floats per k row of the X image
+    static constexpr int X_FLOATS = 16 * LDX;
+};
+
+// one K step of 16 input channels on the LDS images xs [16][LDX], ws [BC][24]
+template <int PT, int CT, int LDX>
+__device__ __forceinline__ void c1_step(const float* __restrict__ xs, const float* __restrict__ ws, f32x4 (&acc)[PT][CT], int i, int kg) {
+    f32x4 wv[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) wv[ct] = *reinterpret_cast<const f32x4*>(ws + (ct * 16 + i) * C1_LDW + 4 * kg);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float xv[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) xv[pt] = xs[(4 * kg + j) * LDX + pt * 16 + i];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[pt], wv[ct][j], acc[pt][ct], 0, 0, 0);
+    }
+}
+
+// x [B][cin][P] (P = H * W), wpack [cout / BC][cin / 16][BC][16], bias [cout], res / out [B][cout][P]; total pixels B * P % BP == 0,
+// P % 16 == 0, cin % 16 == 0, cout % BC == 0.
+// KS = 2: two groups of four waves share the tile and take alternate k steps (each group has its own double-buffered LDS images and runs
+// the same rotated loop; the barriers are common), so a workgroup has half the serial k steps and a CU twice the waves to hide the
+// step's latencies behind; the groups swap half of their accumulators through LDS at the end and each finishes half of the channels.
+template <int BP, int BC, int KS>
+__global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ wpack, const float* __restrict__ bias,
+                                                      const float* __restrict__ res, float* __restrict__ out, int cin, int cout, int P, int relu) {
+    constexpr int PT = BP / 32, CT = BC / 32;                            // 16 x 16 tiles per wave: (BP / 2) pixels x (BC / 2) channels
+    constexpr int LDX = C1Geom<BP>::LDX;
+    constexpr int XF = C1Geom<BP>::X_FLOATS, WF = BC * C1_LDW;
+    constexpr int XV = BP * 16 / 4 / 256, WV = BC * 16 / 4 / 256;         // 16-byte pieces per thread and step
+    static_assert(XV >= 1 && WV >= 1 && PT >= 1 && CT >= 1, "tile too small for 256 threads");
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // [2][XF] X images, [2][WF] W images
+    const int grp = KS > 1 ? (int)(threadIdx.x >> 8) : 0;                  // k-split group (wave-uniform)
+    float* xs = lds + grp * (2 * XF + 2 * WF);
+    float* ws = xs + 2 * XF;
+    const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
+    const int i = lane & 15, kg = lane >> 4;
+    const int wp = wave & 1, wc = wave >> 1;
+    const long long n0 = (long long)blockIdx.x * BP;                      // first pixel (over the batch) of the tile
+    const int c0 = blockIdx.y * BC;
+    const int steps = cin >> 4, trips = steps / KS;                        // this group's k steps: grp, grp + KS, ...
+
+    // this thread's pieces of an X tile: piece q = t + v * 256 -> row k = q / (BP / 4), pixels 4 (q % (BP / 4)) ..
+    const float* xsrc[XV];
+    int xdst[XV];
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+        const int q = t + v * 256, k = q / (BP / 4), c4 = q % (BP / 4);
+        const long long n = n0 + 4 * c4;
+        const long long b = n / P;
+        const int p = (int)(n - b * P);
+        xsrc[v] = x + (b * cin + k) * P + p;                              // + step * 16 * P
+        xdst[v] = k * LDX + 4 * c4;
+    }
+    const float* wsrc = wpack + (long long)blockIdx.y * steps * (BC * 16) + t * 4;      // + step * BC * 16 + v * 1024
+    int wdst[WV];
+#pragma unroll
+    for (int v = 0; v < WV; ++v) {
+        const int q = t + v * 256;
+        wdst[v] = (q >> 2) * C1_LDW + 4 * (q & 3);
+    }
+    f32x4 xr[XV], wr[WV];
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int v = 0; v < XV; ++v) xr[v] = *reinterpret_cast<const f32x4*>(xsrc[v] + (long long)s * 16 * P);
+#pragma unroll
+        for (int v = 0; v < WV; ++v) wr[v] = *reinterpret_cast<const f32x4*>(wsrc + (long long)s * (BC * 16) + v * 1024);
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int v = 0; v < XV; ++v) *reinterpret_cast<f32x4*>(xs + buf * XF + xdst[v]) = xr[v];
+#pragma unroll
+        for (int v = 0; v < WV; ++v) *reinterpret_cast<f32x4*>(ws + buf * WF + wdst[v]) = wr[v];
+    };
+    f32x4 acc[PT][CT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    fetch(grp);
+    commit(0);
+    __syncthreads();
+    // rotated: a trip requests the group's next step at its top and writes it into the other LDS half at its end (no loop-carried load registers)
+    for (int s = 0; s < trips; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < trips) fetch((s + 1) * KS + grp);
+        c1_step<PT, CT, LDX>(xs + buf * XF + wp * (BP / 2), ws + buf * WF + wc * (BC / 2) * C1_LDW, acc, i, kg);
+        if (s + 1 < trips) commit(buf ^ 1);
+        __syncthreads();
+    }
+    if (KS > 1) {
+        // accumulator tile q = pt * CT + ct belongs to group q % KS: every group writes the tiles it does not own into its OWN LDS region
+        // (free after the last barrier; slot = the tile's rank among those), then adds the other groups' copies of its own tiles
+        constexpr int NQ = PT * CT, REGION = 2 * XF + 2 * WF;
+        static_assert(NQ % KS == 0 && (NQ - NQ / KS) * 1024 <= REGION, "exchange image must fit the group's LDS region");
+        f32x4* mine = reinterpret_cast<f32x4*>(xs);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (q % KS != grp) mine[(q - q / KS - (q % KS > grp ? 1 : 0)) * 256 + t] = acc[q / CT][q % CT];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (q % KS == grp) {
+#pragma unroll
+                for (int o = 0; o < KS; ++o)
+                    if (o != grp) acc[q / CT][q % CT] += reinterpret_cast<const f32x4*>(lds + o * REGION)[(q - q / KS - (q % KS > o ? 1 : 0)) * 256 + t];
+            }
+    }
+    // epilogue: lane (channel i of the tile, pixel quad kg): + bias (+ residual) (ReLU), 16-byte NCHW accesses
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int co = c0 + wc * (BC / 2) + ct * 16 + i;
+        const float bv = bias[co];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            if (KS > 1 && (pt * CT + ct) % KS != grp) continue;
+            const long long n = n0 + wp * (BP / 2) + pt * 16 + 4 * kg;
+            const long long b = n / P;
+            const int p = (int)(n - b * P);
+            const long long off = (b * cout + co) * P + p;
+            f32x4 v = acc[pt][ct] + bv;
+            if (res) v += *reinterpret_cast<const f32x4*>(res + off);
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<f32x4*>(out + off) = v;
+        }
+    }
+}
+
+template <int BP, int BC, int KS>
+int launch_c1(const float* x, const float* wpack, const float* bias, const float* res, float* out, long long pixels, int cin, int cout, int P,
+              int relu, hipStream_t s) {
+    constexpr int LDS = KS * (2 * C1Geom<BP>::X_FLOATS + 2 * BC * C1_LDW) * 4;
+    auto kern = conv1x1_kernel<BP, BC, KS>;
+    SE_ENSURE_LDS(kern, LDS);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(pixels / BP), cout / BC), dim3(256 * KS), LDS, s, x, wpack, bias, res, out, cin, cout, P, relu);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+// Channel-tile width of the packed weights for a layer (the caller packs [cout / BC][cin / 16][BC][16] from the folded [cout][cin]
+// matrix); 0 = shape not covered (the caller keeps its MIOpen convolution).  Depends on the arguments and the device's CU count only.
+extern "C" int se_conv2d_1x1_tile_f32(int batch, int cin, int cout, int hw) {
+    if (batch <= 0 || cin <= 0 || (cin & 15) || cout <= 0 || (cout & 63) || hw <= 0 || (hw & 15)) return 0;
+    const long long pixels = (long long)batch * hw;
+    if (pixels % 64) return 0;
+    // 128 channels per workgroup where that still gives every CU a workgroup (64-pixel tiles), else 64 (measured, tools/bench_conv1x1.py:
+    // the kernel wins against MIOpen + epilogue pass from ~256 workgroups on and loses below ~128: those shapes would need a split K)
+    return (cout % 128 == 0 && (pixels / 64) * (cout / 128) >= se_num_cus()) ? 128 : 64;
+}
+
+extern "C" int se_conv2d_1x1_f32(const float* x, const float* wpack, const float* bias, const float* residual, float* out, int batch,
+                                 int cin, int cout, int hw, int relu, void* stream) {
+    const int bc = se_conv2d_1x1_tile_f32(batch, cin, cout, hw);
+    if (!bc || !x || !wpack || !bias || !out) return SE_ERR_BAD_ARG;
+    const long long pixels = (long long)batch * hw;
+    hipStream_t s = se_stream(stream);
+    // 64-pixel tiles (128 measured equal or slower on every backbone shape: fewer workgroups in flight; tools/bench_conv1x1.py).
+    // k split over two wave groups from 128 input channels on; se_debug_set_variant(73 / 74 / 75) = 1 / 2 / 4 groups (A/B in development
+    // builds: four groups tie with MIOpen + epilogue on the 1024-channel layers, 23.3 against 23.1 us, and gain < 1 us elsewhere - not routed)
+    const int ks = (g_variant == 73) ? 1 : (g_variant == 74) ? 2 : (g_variant == 75) ? 4 : cin >= C1_SPLIT_MIN_CIN ? 2 : 1;
+    const int kse = (cin % (16 * ks)) ? 1 : ks;
+    if (bc == 128) {
+        if (kse == 4) return launch_c1<64, 128, 4>(x, wpack, bias, residual, out, pixels, cin, cout, hw, relu, s);
+        if (kse == 2) return launch_c1<64, 128, 2>(x, wpack, bias, residual, out, pixels, cin, cout, hw, relu, s);
+        return launch_c1<64, 128, 1>(x, wpack, bias, residual, out, pixels, cin, cout, hw, relu, s);
+    }
+    if (kse == 4) return launch_c1<64, 64, 4>(x, wpack, bias, residual, out, pixels, cin, cout, hw, relu, s);
+    if (kse == 2) return launch_c1<64, 64, 2>(x, wpack, bias, residual, out, pixels, cin, cout, hw, relu, s);
+    return launch_c1<64, 64, 1>(x, wpack, bias, residual, out, pixels, cin, cout, hw, relu, s);
+}

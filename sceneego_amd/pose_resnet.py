@@ -19,6 +19,8 @@ from __future__ import annotations
 
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -150,6 +152,9 @@ class FoldedBackbone:
 
     def __init__(self, net: PoseResNet, dtype=torch.float32, channels_last: bool = False):
         self.dtype = dtype
+        self.conv1x1 = os.environ.get("SCENEEGO_CONV1X1", "1") != "0"
+        self.conv1x1_min_wg = int(os.environ.get("SCENEEGO_CONV1X1_MIN_WG", self.CONV1X1_MIN_WORKGROUPS))    # A/B knobs of the routing rule
+        self.conv1x1_max_cin = int(os.environ.get("SCENEEGO_CONV1X1_MAX_CIN", self.CONV1X1_MAX_CIN))
         self.memory_format = torch.channels_last if channels_last else torch.contiguous_format
         cvt = lambda wb: (wb[0].to(dtype).contiguous(memory_format=self.memory_format), wb[1].to(dtype))
         self.stem = cvt(_fold(net.conv1.weight, net.bn1))
@@ -183,19 +188,45 @@ class FoldedBackbone:
             x = F.relu_(F.conv_transpose2d(x, w, b, stride=2, padding=1))
         return x
 
+    # float32 1x1 convolutions with stride 1 (conv1, conv3 and layer1's downsample of every Bottleneck: 33 of the 53 convolutions) run
+    # on se_conv2d_1x1_f32 - one MFMA GEMM with bias, residual add and ReLU in its epilogue (round 6) - where the shape is covered and
+    # large enough to fill the chip; SCENEEGO_CONV1X1=0 keeps MIOpen + se_bias_act_nchw_f32 for all of them (A/B).
+    CONV1X1_MIN_WORKGROUPS = 256       # below ~one workgroup per CU MIOpen's split kernels win (tools/bench_conv1x1.py)
+    CONV1X1_MAX_CIN = 512              # ... and so they do on the long-K layers (1024 / 2048 input channels: 64 serial k steps per workgroup)
+
+    def _pw(self, x, wb, residual, relu, slot):
+        """1x1 stride-1 convolution + bias (+ residual) (+ ReLU): the fused GEMM when it covers the shape, else MIOpen + epilogue pass."""
+        from . import _lib
+        B, cin, H, W = x.shape
+        cout = wb[0].shape[0]
+        tile = _lib.conv2d_1x1_tile(B, cin, cout, H * W) if (self.dtype == torch.float32 and self.conv1x1) else 0
+        if tile and cin <= self.conv1x1_max_cin and ((B * H * W) // 64) * (cout // tile) >= self.conv1x1_min_wg:
+            cache = self.__dict__.setdefault("_pw_cache", {})
+            key = (slot, tile, x.device)
+            if key not in cache:
+                cache[key] = (_lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile), wb[1].float().contiguous())
+            wp, bias = cache[key]
+            return _lib.conv2d_1x1(x, wp, bias, residual, relu)
+        return _lib.bias_act_nchw(F.conv2d(x, wb[0]), wb[1], residual, relu)
+
     def _call_fused(self, images):
-        """NCHW on a HIP device (float32, or bfloat16 for config 3): MIOpen convolutions WITHOUT bias + one fused HIP
-        epilogue (``se_bias_act_nchw_f32`` / ``_bf16``: bias, residual add, ReLU in a single pass)."""
+        """NCHW on a HIP device (float32, or bfloat16 for config 3): the 1x1 convolutions as fused GEMMs (_pw), the others as MIOpen
+        convolutions WITHOUT bias + one fused HIP epilogue (``se_bias_act_nchw_f32`` / ``_bf16``: bias, residual add, ReLU in a
+        single pass)."""
         from . import _lib
         ba = _lib.bias_act_nchw
         x = ba(F.conv2d(images.contiguous(), self.stem[0], None, stride=2, padding=3), self.stem[1], None, True)
         x = F.max_pool2d(x, 3, stride=2, padding=1)
-        for c1, c2, c3, stride, ds in self.blocks:
-            y = ba(F.conv2d(x, c1[0]), c1[1], None, True)
+        for bi, (c1, c2, c3, stride, ds) in enumerate(self.blocks):
+            y = self._pw(x, c1, None, True, (bi, 1))
             y = ba(F.conv2d(y, c2[0], None, stride=stride, padding=1), c2[1], None, True)
-            y = F.conv2d(y, c3[0])
-            sc = x if ds is None else ba(F.conv2d(x, ds[0], None, stride=ds[2]), ds[1], None, False)
-            x = ba(y, c3[1], sc, True)
+            if ds is None:
+                sc = x
+            elif ds[2] in (1, (1, 1)):
+                sc = self._pw(x, ds, None, False, (bi, 0))
+            else:
+                sc = ba(F.conv2d(x, ds[0], None, stride=ds[2]), ds[1], None, False)
+            x = self._pw(y, c3, sc, True, (bi, 3))
         for li, (w, b) in enumerate(self.ups):
             B, _, H, W = x.shape
             if B * H * W <= self.DECONV_GEMM_MAX_POSITIONS and x.dtype == torch.float32:

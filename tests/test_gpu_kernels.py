@@ -447,6 +447,57 @@ def test_bias_act_and_fused_backbone():
     assert float((fused - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-5
 
 
+@pytest.mark.parametrize("B,cin,cout,H,residual,relu", [
+    (8, 64, 256, 64, True, True), (8, 64, 64, 64, False, True), (8, 256, 128, 64, False, True), (8, 128, 512, 32, True, True),
+    (8, 512, 128, 32, False, True), (8, 256, 1024, 16, True, True), (8, 512, 2048, 8, True, True), (8, 2048, 512, 8, False, True), (8, 1024, 256, 16, False, True), (8, 1024, 512, 16, False, True),
+    (1, 64, 256, 64, True, False), (3, 128, 64, 16, False, False), (4, 48, 192, 12, True, True)])
+def test_conv2d_1x1_fused_gemm_vs_float64(B, cin, cout, H, residual, relu):
+    """se_conv2d_1x1_f32 (the backbone's stride-1 1x1 convolutions, network/pose_resnet.py:72-90 with folded BatchNorm) against a float64
+    product on the host: the backbone's shapes at B = 8, cout = 192 (64-channel tiles), a map whose side is not a multiple of 16 but whose
+    area is (12^2 = 144 = 9 * 16: pixel tiles straddle samples), both epilogue forms.  float32 products summed in float32:
+    1e-5 of the largest |y| (measured 1-3e-6)."""
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(B, cin, H, H, generator=g)
+    w = torch.randn(cout, cin, generator=g) * (2.0 / cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(B, cout, H, H, generator=g) if residual else None
+    want = torch.einsum("oc,bchw->bohw", w.double(), x.double()) + b.double().view(1, -1, 1, 1)
+    if residual:
+        want = want + r.double()
+    if relu:
+        want = want.clamp_min(0)
+    tile = _lib.conv2d_1x1_tile(B, cin, cout, H * H)
+    assert tile in (64, 128)
+    wp = _lib.conv2d_1x1_pack(w, tile).to(DEV)
+    got = _lib.conv2d_1x1(x.to(DEV), wp, b.to(DEV), r.to(DEV) if residual else None, relu)
+    assert got.shape == (B, cout, H, H) and bool(torch.isfinite(got).all())
+    err = float((got.double().cpu() - want).abs().max())
+    assert err < 1e-5 * float(want.abs().max()), err
+    # uncovered shapes are refused, not mis-computed
+    assert _lib.conv2d_1x1_tile(B, cin + 8, cout, H * H) == 0 and _lib.conv2d_1x1_tile(B, cin, cout + 32, H * H) == 0
+    assert _lib.conv2d_1x1_tile(1, cin, cout, 40) == 0
+
+
+def test_backbone_fused_1x1_matches_miopen_route(monkeypatch):
+    """FoldedBackbone with the 1x1 convolutions on se_conv2d_1x1_f32 (default) against the same folded network with every one of them on
+    MIOpen + se_bias_act_nchw_f32 (SCENEEGO_CONV1X1=0), B = 8 and B = 1 (the routing rule keeps the small launches on MIOpen)."""
+    from sceneego_amd import pose_resnet
+    net = pose_resnet.get_pose_net(None).to(DEV).eval()
+    for B in (8, 1):
+        img = torch.randn(B, 3, 256, 256, device=DEV)
+        monkeypatch.setenv("SCENEEGO_CONV1X1", "1")
+        fb = pose_resnet.FoldedBackbone(net)
+        calls = []
+        real = _lib.conv2d_1x1
+        monkeypatch.setattr(_lib, "conv2d_1x1", lambda *a: (calls.append(1), real(*a))[1])
+        a = fb(img)
+        monkeypatch.setattr(_lib, "conv2d_1x1", real)
+        monkeypatch.setenv("SCENEEGO_CONV1X1", "0")
+        bref = pose_resnet.FoldedBackbone(net)(img)
+        assert len(calls) >= (20 if B == 8 else 1)
+        assert float((a - bref).abs().max()) < 2e-5 * float(bref.abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize("B,ci,co,H,W", [(2, 24, 8, 5, 3), (8, 2048, 256, 8, 8), (1, 256, 256, 16, 16)])
 def test_deconv2d_gemm_plus_assemble_vs_torch(B, ci, co, H, W):
     """se_deconv2d_k4s2_assemble_f32: the pose head's ConvTranspose2d(4, 2, 1) + folded BN + ReLU (reference
