@@ -107,10 +107,12 @@ int se_bias_act_nchw_f32(const float* x, const float* bias, const float* residua
  *   x [batch][cin][hw], residual (or NULL) / out [batch][cout][hw] float32 NCHW;  bias [cout]
  *   wpack = the folded [cout][cin] matrix as [cout / BC][cin / 16][BC][16] with BC = se_conv2d_1x1_tile_f32(batch, cin, cout, hw)
  *   (128 when cout % 128 == 0, else 64; 0 = shape not covered: cin % 16, cout % 64, hw % 16, batch * hw % 64 must be 0).
+ *   in_bias (or NULL) [cin]: x is the RAW result of the producing convolution and its bias + ReLU are applied on the way in,
+ *   x' = max(x + in_bias[c], 0) - conv2's `bn2` + `relu` (pose_resnet.py:79-81) folded into conv3's launch.
  * float32 in, float32 accumulate: differs from the MIOpen result by summation order only. */
 int se_conv2d_1x1_tile_f32(int batch, int cin, int cout, int hw);
-int se_conv2d_1x1_f32(const float* x, const float* wpack, const float* bias, const float* residual, float* out, int batch, int cin,
-                      int cout, int hw, int relu, void* stream);
+int se_conv2d_1x1_f32(const float* x, const float* wpack, const float* bias, const float* residual, const float* in_bias, float* out,
+                      int batch, int cin, int cout, int hw, int relu, void* stream);
 
 /* Output side of the 2-D pose head's transposed convolutions - ConvTranspose2d(k=4, s=2, p=1) + BatchNorm2d + ReLU,
  * network/pose_resnet.py:205-224 (built), :238 (run) - when the layer is computed as ONE GEMM over the un-shifted input:

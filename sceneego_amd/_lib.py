@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -45,7 +45,7 @@ SIGNATURES = {
     "se_bias_act_nchw_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_deconv2d_k4s2_assemble_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv2d_1x1_tile_f32": (_i, [_i, _i, _i, _i]),
-    "se_conv2d_1x1_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_conv2d_1x1_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_packed_elems": (_ll, [_i, _i, _i, _i]),
     "se_conv3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
@@ -300,15 +300,17 @@ def conv2d_1x1_pack(w2d, tile):
     return w2d.reshape(cout // tile, tile, cin // 16, 16).permute(0, 2, 1, 3).contiguous()
 
 
-def conv2d_1x1(x, wpack, bias, residual, relu):
-    """``x`` [B, cin, H, W] NCHW float32 -> relu?(W x + bias (+ residual)) [B, cout, H, W] in one launch (se_conv2d_1x1_f32)."""
+def conv2d_1x1(x, wpack, bias, residual, relu, in_bias=None):
+    """``x`` [B, cin, H, W] NCHW float32 -> relu?(W x' + bias (+ residual)) [B, cout, H, W] in one launch (se_conv2d_1x1_f32);
+    ``in_bias`` [cin]: x' = relu(x + in_bias) (the producing convolution's bias + ReLU applied on the way in), else x' = x."""
     require_hip(x, wpack, bias)
-    _chk_f32(x, wpack, bias, residual)
+    _chk_f32(x, wpack, bias, residual, in_bias)
     B, cin, H, W = x.shape
     cout = wpack.shape[0] * wpack.shape[2]
     assert wpack.dim() == 4 and wpack.shape[1] * 16 == cin and wpack.shape[2] == conv2d_1x1_tile(B, cin, cout, H * W)
+    assert in_bias is None or in_bias.numel() == cin
     out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
-    _check(load().se_conv2d_1x1_f32(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(residual), _ptr(out), B, cin, cout, H * W,
+    _check(load().se_conv2d_1x1_f32(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(residual), _ptr(in_bias), _ptr(out), B, cin, cout, H * W,
                                     1 if relu else 0, _stream()), "se_conv2d_1x1_f32")
     return out
 

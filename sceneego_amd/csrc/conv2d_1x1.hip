@@ -50,9 +50,12 @@ __device__ __forceinline__ void c1_step(const float* __restrict__ xs, const floa
 // KS = 2: two groups of four waves share the tile and take alternate k steps (each group has its own double-buffered LDS images and runs
 // the same rotated loop; the barriers are common), so a workgroup has half the serial k steps and a CU twice the waves to hide the
 // step's latencies behind; the groups swap half of their accumulators through LDS at the end and each finishes half of the channels.
-template <int BP, int BC, int KS>
+// INB: the input is the raw result of the producing convolution and its bias + ReLU happen HERE, on the way into LDS: x' = max(x +
+// in_bias[channel], 0) (the 3x3 convolution of a Bottleneck in front of conv3: its own epilogue pass over the tensor disappears).
+template <int BP, int BC, int KS, bool INB>
 __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ wpack, const float* __restrict__ bias,
-                                                      const float* __restrict__ res, float* __restrict__ out, int cin, int cout, int P, int relu) {
+                                                      const float* __restrict__ res, const float* __restrict__ in_bias, float* __restrict__ out,
+                                                      int cin, int cout, int P, int relu) {
     constexpr int PT = BP / 32, CT = BC / 32;                            // 16 x 16 tiles per wave: (BP / 2) pixels x (BC / 2) channels
     constexpr int LDX = C1Geom<BP>::LDX;
     constexpr int XF = C1Geom<BP>::X_FLOATS, WF = BC * C1_LDW;
@@ -89,15 +92,25 @@ __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restri
         wdst[v] = (q >> 2) * C1_LDW + 4 * (q & 3);
     }
     f32x4 xr[XV], wr[WV];
+    float xb[XV];
     auto fetch = [&](int s) {
 #pragma unroll
-        for (int v = 0; v < XV; ++v) xr[v] = *reinterpret_cast<const f32x4*>(xsrc[v] + (long long)s * 16 * P);
+        for (int v = 0; v < XV; ++v) {
+            xr[v] = *reinterpret_cast<const f32x4*>(xsrc[v] + (long long)s * 16 * P);
+            if (INB) xb[v] = in_bias[s * 16 + (t + v * 256) / (BP / 4)];
+        }
 #pragma unroll
         for (int v = 0; v < WV; ++v) wr[v] = *reinterpret_cast<const f32x4*>(wsrc + (long long)s * (BC * 16) + v * 1024);
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int v = 0; v < XV; ++v) *reinterpret_cast<f32x4*>(xs + buf * XF + xdst[v]) = xr[v];
+        for (int v = 0; v < XV; ++v) {
+            if (INB) {
+                xr[v].x = fmaxf(xr[v].x + xb[v], 0.f); xr[v].y = fmaxf(xr[v].y + xb[v], 0.f);
+                xr[v].z = fmaxf(xr[v].z + xb[v], 0.f); xr[v].w = fmaxf(xr[v].w + xb[v], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(xs + buf * XF + xdst[v]) = xr[v];
+        }
 #pragma unroll
         for (int v = 0; v < WV; ++v) *reinterpret_cast<f32x4*>(ws + buf * WF + wdst[v]) = wr[v];
     };
@@ -156,12 +169,19 @@ __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restri
 }
 
 template <int BP, int BC, int KS>
-int launch_c1(const float* x, const float* wpack, const float* bias, const float* res, float* out, long long pixels, int cin, int cout, int P,
-              int relu, hipStream_t s) {
+int launch_c1(const float* x, const float* wpack, const float* bias, const float* res, const float* in_bias, float* out, long long pixels,
+              int cin, int cout, int P, int relu, hipStream_t s) {
     constexpr int LDS = KS * (2 * C1Geom<BP>::X_FLOATS + 2 * BC * C1_LDW) * 4;
-    auto kern = conv1x1_kernel<BP, BC, KS>;
-    SE_ENSURE_LDS(kern, LDS);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(pixels / BP), cout / BC), dim3(256 * KS), LDS, s, x, wpack, bias, res, out, cin, cout, P, relu);
+    const dim3 grid((unsigned)(pixels / BP), cout / BC), block(256 * KS);
+    if (in_bias) {
+        auto kern = conv1x1_kernel<BP, BC, KS, true>;
+        SE_ENSURE_LDS(kern, LDS);
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, x, wpack, bias, res, in_bias, out, cin, cout, P, relu);
+    } else {
+        auto kern = conv1x1_kernel<BP, BC, KS, false>;
+        SE_ENSURE_LDS(kern, LDS);
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, x, wpack, bias, res, in_bias, out, cin, cout, P, relu);
+    }
     SE_CHECK_LAUNCH();
     return 0;
 }
@@ -179,8 +199,8 @@ extern "C" int se_conv2d_1x1_tile_f32(int batch, int cin, int cout, int hw) {
     return (cout % 128 == 0 && (pixels / 64) * (cout / 128) >= se_num_cus()) ? 128 : 64;
 }
 
-extern "C" int se_conv2d_1x1_f32(const float* x, const float* wpack, const float* bias, const float* residual, float* out, int batch,
-                                 int cin, int cout, int hw, int relu, void* stream) {
+extern "C" int se_conv2d_1x1_f32(const float* x, const float* wpack, const float* bias, const float* residual, const float* in_bias, float* out,
+                                 int batch, int cin, int cout, int hw, int relu, void* stream) {
     const int bc = se_conv2d_1x1_tile_f32(batch, cin, cout, hw);
     if (!bc || !x || !wpack || !bias || !out) return SE_ERR_BAD_ARG;
     const long long pixels = (long long)batch * hw;
@@ -191,11 +211,11 @@ extern "C" int se_conv2d_1x1_f32(const float* x, const float* wpack, const float
     const int ks = (g_variant == 73) ? 1 : (g_variant == 74) ? 2 : (g_variant == 75) ? 4 : cin >= C1_SPLIT_MIN_CIN ? 2 : 1;
     const int kse = (cin % (16 * ks)) ? 1 : ks;
     if (bc == 128) {
-        if (kse == 4) return launch_c1<64, 128, 4>(x, wpack, bias, residual, out, pixels, cin, cout, hw, relu, s);
-        if (kse == 2) return launch_c1<64, 128, 2>(x, wpack, bias, residual, out, pixels, cin, cout, hw, relu, s);
-        return launch_c1<64, 128, 1>(x, wpack, bias, residual, out, pixels, cin, cout, hw, relu, s);
+        if (kse == 4) return launch_c1<64, 128, 4>(x, wpack, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s);
+        if (kse == 2) return launch_c1<64, 128, 2>(x, wpack, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s);
+        return launch_c1<64, 128, 1>(x, wpack, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s);
     }
-    if (kse == 4) return launch_c1<64, 64, 4>(x, wpack, bias, residual, out, pixels, cin, cout, hw, relu, s);
-    if (kse == 2) return launch_c1<64, 64, 2>(x, wpack, bias, residual, out, pixels, cin, cout, hw, relu, s);
-    return launch_c1<64, 64, 1>(x, wpack, bias, residual, out, pixels, cin, cout, hw, relu, s);
+    if (kse == 4) return launch_c1<64, 64, 4>(x, wpack, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s);
+    if (kse == 2) return launch_c1<64, 64, 2>(x, wpack, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s);
+    return launch_c1<64, 64, 1>(x, wpack, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s);
 }

@@ -194,19 +194,32 @@ class FoldedBackbone:
     CONV1X1_MIN_WORKGROUPS = 256       # below ~one workgroup per CU MIOpen's split kernels win (tools/bench_conv1x1.py)
     CONV1X1_MAX_CIN = 512              # ... and so they do on the long-K layers (1024 / 2048 input channels: 64 serial k steps per workgroup)
 
-    def _pw(self, x, wb, residual, relu, slot):
-        """1x1 stride-1 convolution + bias (+ residual) (+ ReLU): the fused GEMM when it covers the shape, else MIOpen + epilogue pass."""
+    def _pw_tile(self, x, cout):
+        """Channel tile of the fused GEMM for a 1x1 convolution of ``x`` to ``cout`` channels, 0 = the layer stays on MIOpen."""
+        from . import _lib
+        B, cin, H, W = x.shape
+        tile = _lib.conv2d_1x1_tile(B, cin, cout, H * W) if (self.dtype == torch.float32 and self.conv1x1) else 0
+        if tile and cin <= self.conv1x1_max_cin and ((B * H * W) // 64) * (cout // tile) >= self.conv1x1_min_wg:
+            return tile
+        return 0
+
+    def _pw(self, x, wb, residual, relu, slot, in_bias=None):
+        """1x1 stride-1 convolution + bias (+ residual) (+ ReLU): the fused GEMM when it covers the shape, else MIOpen + epilogue pass.
+        ``in_bias``: ``x`` is the raw result of the convolution in front and relu(x + in_bias) is the real input - applied inside
+        the fused GEMM, or by an epilogue pass of its own on the MIOpen route."""
         from . import _lib
         B, cin, H, W = x.shape
         cout = wb[0].shape[0]
-        tile = _lib.conv2d_1x1_tile(B, cin, cout, H * W) if (self.dtype == torch.float32 and self.conv1x1) else 0
-        if tile and cin <= self.conv1x1_max_cin and ((B * H * W) // 64) * (cout // tile) >= self.conv1x1_min_wg:
+        tile = self._pw_tile(x, cout)
+        if tile:
             cache = self.__dict__.setdefault("_pw_cache", {})
             key = (slot, tile, x.device)
             if key not in cache:
                 cache[key] = (_lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile), wb[1].float().contiguous())
             wp, bias = cache[key]
-            return _lib.conv2d_1x1(x, wp, bias, residual, relu)
+            return _lib.conv2d_1x1(x, wp, bias, residual, relu, in_bias)
+        if in_bias is not None:
+            x = _lib.bias_act_nchw(x, in_bias, None, True)
         return _lib.bias_act_nchw(F.conv2d(x, wb[0]), wb[1], residual, relu)
 
     def _call_fused(self, images):
@@ -219,14 +232,14 @@ class FoldedBackbone:
         x = F.max_pool2d(x, 3, stride=2, padding=1)
         for bi, (c1, c2, c3, stride, ds) in enumerate(self.blocks):
             y = self._pw(x, c1, None, True, (bi, 1))
-            y = ba(F.conv2d(y, c2[0], None, stride=stride, padding=1), c2[1], None, True)
+            y = F.conv2d(y, c2[0], None, stride=stride, padding=1)          # raw: bn2's bias + ReLU ride into conv3's launch (_pw in_bias)
             if ds is None:
                 sc = x
             elif ds[2] in (1, (1, 1)):
                 sc = self._pw(x, ds, None, False, (bi, 0))
             else:
                 sc = ba(F.conv2d(x, ds[0], None, stride=ds[2]), ds[1], None, False)
-            x = self._pw(y, c3, sc, True, (bi, 3))
+            x = self._pw(y, c3, sc, True, (bi, 3), in_bias=c2[1])
         for li, (w, b) in enumerate(self.ups):
             B, _, H, W = x.shape
             if B * H * W <= self.DECONV_GEMM_MAX_POSITIONS and x.dtype == torch.float32:

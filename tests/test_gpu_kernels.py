@@ -473,6 +473,16 @@ def test_conv2d_1x1_fused_gemm_vs_float64(B, cin, cout, H, residual, relu):
     assert got.shape == (B, cout, H, H) and bool(torch.isfinite(got).all())
     err = float((got.double().cpu() - want).abs().max())
     assert err < 1e-5 * float(want.abs().max()), err
+    # the producing convolution's bias + ReLU applied on the way in: x' = relu(x + in_bias)
+    ib = torch.randn(cin, generator=g)
+    want2 = torch.einsum("oc,bchw->bohw", w.double(), (x.double() + ib.double().view(1, -1, 1, 1)).clamp_min(0)) + b.double().view(1, -1, 1, 1)
+    if residual:
+        want2 = want2 + r.double()
+    if relu:
+        want2 = want2.clamp_min(0)
+    got2 = _lib.conv2d_1x1(x.to(DEV), wp, b.to(DEV), r.to(DEV) if residual else None, relu, ib.to(DEV))
+    err2 = float((got2.double().cpu() - want2).abs().max())
+    assert err2 < 1e-5 * float(want2.abs().max()), err2
     # uncovered shapes are refused, not mis-computed
     assert _lib.conv2d_1x1_tile(B, cin + 8, cout, H * H) == 0 and _lib.conv2d_1x1_tile(B, cin, cout + 32, H * H) == 0
     assert _lib.conv2d_1x1_tile(1, cin, cout, 40) == 0

@@ -6,7 +6,7 @@ import csv
 import sys
 
 rows = sorted((r for r in csv.DictReader(open(sys.argv[1])) if r["Kind"] == "KERNEL_DISPATCH"), key=lambda r: int(r["Start_Timestamp"]))
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+N = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 5
 V2V = ("conv3d_", "deconv3d_", "maxpool2", "pointwise_chain3", "softargmax_", "voxelize_", "splitk_reduce", "fft7_")
 steps, cur = [], []
 for r in rows:
@@ -28,4 +28,11 @@ for s in steps:
 print(f"{len(steps)} forwards; per forward:")
 for k, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
     print(f"  {k:28s} {c / len(steps):6.1f} launches {us / len(steps):9.1f} us")
+if "-v" in sys.argv:
+    by = {}
+    for st in steps:
+        for n, us in st:
+            e = by.setdefault(n[:110], [0, 0.0]); e[0] += 1; e[1] += us
+    for n, (c, us) in sorted(by.items(), key=lambda kv: -kv[1][1])[:45]:
+        print(f"      {c / len(steps):5.1f} x {us / c:7.1f} us  {n}")
 print(f"  {'backbone kernels, total':28s} {sum(c for c, _ in tot.values()) / len(steps):6.1f} launches {sum(u for _, u in tot.values()) / len(steps):9.1f} us")
