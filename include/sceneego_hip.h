@@ -114,6 +114,16 @@ int se_conv2d_1x1_tile_f32(int batch, int cin, int cout, int hw);
 int se_conv2d_1x1_f32(const float* x, const float* wpack, const float* bias, const float* residual, const float* in_bias, float* out,
                       int batch, int cin, int cout, int hw, int relu, void* stream);
 
+/* 3x3 convolution (stride 1, padding 1) of the backbone's deep stages as a direct float32 MFMA product: replaces conv2 (`conv3x3`,
+ * network/pose_resnet.py:22-25) of the Bottlenecks of layer3 / layer4 with its folded BatchNorm (round 6; csrc/conv2d_3x3.hip).
+ *   x [batch][cin][h][w], out [batch][cout][h][w] float32 NCHW; bias [cout] or NULL (the raw sums: the consumer adds it, see in_bias above)
+ *   wpack = the folded [cout][cin][3][3] tensor as [cout / BC][cin / 16][9][BC][16] with BC = se_conv2d_3x3_tile_f32(batch, cin, cout, h, w)
+ *   (32 or 16; 0 = shape not covered: cin % 32, cout % 32 must be 0 and the map 8k x 8m or 4k x 16m).
+ * float32 in, float32 accumulate: differs from the MIOpen result by summation order only. */
+int se_conv2d_3x3_tile_f32(int batch, int cin, int cout, int h, int w);
+int se_conv2d_3x3_f32(const float* x, const float* wpack, const float* bias, float* out, int batch, int cin, int cout, int h, int w,
+                      int relu, void* stream);
+
 /* Output side of the 2-D pose head's transposed convolutions - ConvTranspose2d(k=4, s=2, p=1) + BatchNorm2d + ReLU,
  * network/pose_resnet.py:205-224 (built), :238 (run) - when the layer is computed as ONE GEMM over the un-shifted input:
  *   z    [batch][4 ky][4 kx][cout][h][w] = W_tap [cout x cin] @ x[b] [cin x h*w] for each of the 16 taps (any GEMM library;

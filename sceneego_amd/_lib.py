@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -46,6 +46,8 @@ SIGNATURES = {
     "se_deconv2d_k4s2_assemble_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv2d_1x1_tile_f32": (_i, [_i, _i, _i, _i]),
     "se_conv2d_1x1_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_conv2d_3x3_tile_f32": (_i, [_i, _i, _i, _i, _i]),
+    "se_conv2d_3x3_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_packed_elems": (_ll, [_i, _i, _i, _i]),
     "se_conv3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
@@ -312,6 +314,31 @@ def conv2d_1x1(x, wpack, bias, residual, relu, in_bias=None):
     out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
     _check(load().se_conv2d_1x1_f32(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(residual), _ptr(in_bias), _ptr(out), B, cin, cout, H * W,
                                     1 if relu else 0, _stream()), "se_conv2d_1x1_f32")
+    return out
+
+
+def conv2d_3x3_tile(batch, cin, cout, h, w) -> int:
+    """Channel-tile width the packed weights of a 3x3 stride-1 convolution need (32 / 16), 0 when se_conv2d_3x3_f32 does not cover the shape."""
+    return int(load().se_conv2d_3x3_tile_f32(batch, cin, cout, h, w))
+
+
+def conv2d_3x3_pack(w4d, tile):
+    """Folded [cout, cin, 3, 3] tensor -> [cout / tile, cin / 16, 9, tile, 16] (what se_conv2d_3x3_f32 streams per (channel tile, k step))."""
+    cout, cin = w4d.shape[:2]
+    return w4d.reshape(cout // tile, tile, cin // 16, 16, 9).permute(0, 2, 4, 1, 3).contiguous()
+
+
+def conv2d_3x3(x, wpack, bias, relu):
+    """``x`` [B, cin, H, W] NCHW float32 -> relu?(conv3x3(x) (+ bias)) [B, cout, H, W], stride 1, padding 1 (se_conv2d_3x3_f32);
+    ``bias`` None: the raw sums (the consumer applies the bias - conv2d_1x1's ``in_bias``)."""
+    require_hip(x, wpack)
+    _chk_f32(x, wpack, bias)
+    B, cin, H, W = x.shape
+    cout = wpack.shape[0] * wpack.shape[3]
+    assert wpack.dim() == 5 and wpack.shape[1] * 16 == cin and wpack.shape[2] == 9 and wpack.shape[3] == conv2d_3x3_tile(B, cin, cout, H, W)
+    out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+    _check(load().se_conv2d_3x3_f32(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(out), B, cin, cout, H, W, 1 if relu else 0, _stream()),
+           "se_conv2d_3x3_f32")
     return out
 
 

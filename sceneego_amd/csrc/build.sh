@@ -21,7 +21,7 @@ newer() {  # source $1, a shared header or (development builds) a devtools/ incl
   return 1
 }
 OBJS=()
-for f in voxelize gather softargmax conv2d_1x1 conv3d conv3d_tiled conv3d_wino conv3d_wino2d conv3d_wino44pp conv3d_wino67 conv3d_fft7 conv3d_bf16 conv3d_bf16_tiled conv3d_split; do
+for f in voxelize gather softargmax conv2d_1x1 conv2d_3x3 conv3d conv3d_tiled conv3d_wino conv3d_wino2d conv3d_wino44pp conv3d_wino67 conv3d_fft7 conv3d_bf16 conv3d_bf16_tiled conv3d_split; do
   [ -f $f.hip ] || { echo "build.sh: source $f.hip is missing" >&2; exit 1; }
   OBJS+=($OBJ/$f.o)
   extra=""

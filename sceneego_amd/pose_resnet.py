@@ -153,6 +153,8 @@ class FoldedBackbone:
     def __init__(self, net: PoseResNet, dtype=torch.float32, channels_last: bool = False):
         self.dtype = dtype
         self.conv1x1 = os.environ.get("SCENEEGO_CONV1X1", "1") != "0"
+        self.conv3x3 = os.environ.get("SCENEEGO_CONV3X3", "1") != "0"
+        self.conv3x3_min_wg = int(os.environ.get("SCENEEGO_CONV3X3_MIN_WG", self.CONV3X3_MIN_WORKGROUPS))
         self.conv1x1_min_wg = int(os.environ.get("SCENEEGO_CONV1X1_MIN_WG", self.CONV1X1_MIN_WORKGROUPS))    # A/B knobs of the routing rule
         self.conv1x1_max_cin = int(os.environ.get("SCENEEGO_CONV1X1_MAX_CIN", self.CONV1X1_MAX_CIN))
         self.memory_format = torch.channels_last if channels_last else torch.contiguous_format
@@ -222,6 +224,29 @@ class FoldedBackbone:
             x = _lib.bias_act_nchw(x, in_bias, None, True)
         return _lib.bias_act_nchw(F.conv2d(x, wb[0]), wb[1], residual, relu)
 
+    # float32 3x3 stride-1 convolutions of the deep stages (layer3: 256 -> 256 at 16 x 16, layer4: 512 -> 512 at 8 x 8 for 256 x 256 images)
+    # run on se_conv2d_3x3_f32, a direct MFMA product: 29 / 34 us at B = 8 where MIOpen's Winograd assembly kernel takes 53 and its NHWC
+    # implicit GEMM with the transposes around it 62; on the wide maps of layer1 / layer2 MIOpen is level or ahead (32 vs 35, 29 vs 30) and stays.
+    # SCENEEGO_CONV3X3=0: MIOpen for all (A/B).
+    CONV3X3_MAX_PIXELS = 256
+    CONV3X3_MIN_WORKGROUPS = 0          # also at batch 1 (64 workgroups): 398.3 -> 401 frames/s as a graph, batch 2: 560 -> 570 (tools/ab_conv3x3_b1.sh)
+
+    def _c3(self, x, wb, stride, slot):
+        """conv2 of a Bottleneck WITHOUT its bias (raw sums)."""
+        from . import _lib
+        B, cin, H, W = x.shape
+        cout = wb[0].shape[0]
+        if (stride in (1, (1, 1)) and self.dtype == torch.float32 and self.conv3x3 and H * W <= self.CONV3X3_MAX_PIXELS
+                and ((B * H * W) // 64) * (cout // 16) >= self.conv3x3_min_wg):
+            tile = _lib.conv2d_3x3_tile(B, cin, cout, H, W)
+            if tile:
+                cache = self.__dict__.setdefault("_c3_cache", {})
+                key = (slot, tile, x.device)
+                if key not in cache:
+                    cache[key] = _lib.conv2d_3x3_pack(wb[0].float(), tile)
+                return _lib.conv2d_3x3(x, cache[key], None, False)
+        return F.conv2d(x, wb[0], None, stride=stride, padding=1)
+
     def _call_fused(self, images):
         """NCHW on a HIP device (float32, or bfloat16 for config 3): the 1x1 convolutions as fused GEMMs (_pw), the others as MIOpen
         convolutions WITHOUT bias + one fused HIP epilogue (``se_bias_act_nchw_f32`` / ``_bf16``: bias, residual add, ReLU in a
@@ -232,7 +257,7 @@ class FoldedBackbone:
         x = F.max_pool2d(x, 3, stride=2, padding=1)
         for bi, (c1, c2, c3, stride, ds) in enumerate(self.blocks):
             y = self._pw(x, c1, None, True, (bi, 1))
-            y = F.conv2d(y, c2[0], None, stride=stride, padding=1)          # raw: bn2's bias + ReLU ride into conv3's launch (_pw in_bias)
+            y = self._c3(y, c2, stride, (bi, 2))                            # raw: bn2's bias + ReLU ride into conv3's launch (_pw in_bias)
             if ds is None:
                 sc = x
             elif ds[2] in (1, (1, 1)):

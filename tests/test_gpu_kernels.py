@@ -488,6 +488,31 @@ def test_conv2d_1x1_fused_gemm_vs_float64(B, cin, cout, H, residual, relu):
     assert _lib.conv2d_1x1_tile(1, cin, cout, 40) == 0
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W,bias,relu", [
+    (8, 256, 256, 16, 16, False, False), (8, 512, 512, 8, 8, False, False), (8, 128, 128, 32, 32, True, True), (1, 64, 64, 64, 64, True, False),
+    (2, 32, 96, 8, 24, True, True), (3, 64, 32, 12, 16, False, True), (1, 512, 512, 8, 8, True, True)])
+def test_conv2d_3x3_direct_mfma_vs_float64(B, cin, cout, H, W, bias, relu):
+    """se_conv2d_3x3_f32 (`conv3x3` of the Bottlenecks, network/pose_resnet.py:22-25,78 with folded BatchNorm) against a float64 convolution
+    on the host: the layer3 / layer4 shapes at B = 8 (raw sums, as the backbone uses them), 16- and 8-pixel-wide tiles, non-square maps,
+    both channel tiles, bias + ReLU in the epilogue.  Zero padding at every map border.  1e-5 of the largest |y|."""
+    g = torch.Generator().manual_seed(cin * 3 + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    want = F.conv2d(x.double(), w.double(), b.double() if bias else None, padding=1)
+    if relu:
+        want = want.clamp_min(0)
+    tile = _lib.conv2d_3x3_tile(B, cin, cout, H, W)
+    assert tile in (16, 32)
+    wp = _lib.conv2d_3x3_pack(w, tile).to(DEV)
+    got = _lib.conv2d_3x3(x.to(DEV), wp, b.to(DEV) if bias else None, relu)
+    assert got.shape == (B, cout, H, W) and bool(torch.isfinite(got).all())
+    err = float((got.double().cpu() - want).abs().max())
+    assert err < 1e-5 * float(want.abs().max()), err
+    assert _lib.conv2d_3x3_tile(B, cin + 16, cout, H, W) == 0 and _lib.conv2d_3x3_tile(B, cin, cout + 16, H, W) == 0
+    assert _lib.conv2d_3x3_tile(B, cin, cout, 6, 16) == 0 and _lib.conv2d_3x3_tile(B, cin, cout, 8, 12) == 0
+
+
 def test_backbone_fused_1x1_matches_miopen_route(monkeypatch):
     """FoldedBackbone with the 1x1 convolutions on se_conv2d_1x1_f32 (default) against the same folded network with every one of them on
     MIOpen + se_bias_act_nchw_f32 (SCENEEGO_CONV1X1=0), B = 8 and B = 1 (the routing rule keeps the small launches on MIOpen)."""
