@@ -10,7 +10,9 @@
 //   (pre-packed: one contiguous run) go through registers into the other half of a double-buffered LDS image; a wave owns one
 //   16-pixel row tile and all BC channels: per tap one ds_read_b128 per 16 channels (W[co][4 kg .. 4 kg + 3]) and four
 //   ds_read_b32 (X[4 kg + j][pixel + tap offset]) feed 4 * BC / 16 MFMAs.
-// The bound is the weight stream: every workgroup reads its 9 * cin * BC * 4 bytes once (295 KB), 256 workgroups at once.
+// Where the 28 us of a 256 -> 256 launch at 16 x 16, B = 8 go (knock-out builds, profiles/r06_conv3x3.txt): the MFMA phases with their LDS
+// operand reads alone 22 us (the float32 MFMA peak prices the 2.4 GFLOP at 15.4), the loads + LDS writes + barriers alone 11.6; every
+// workgroup streams its 9 * cin * BC * 4 bytes of weights once (295 KB), 256 workgroups at once.
 // float32 in, float32 accumulate (v_mfma_f32_16x16x4_f32); the result differs from MIOpen's by summation order only.
 #include "common.h"
 
@@ -111,20 +113,29 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_kernel(const float* __restri
         const int buf = s & 1;
         if (s + 1 < trips) fetch((s + 1) * KS + grp);
         {
+            // operands one tap ahead of the MFMAs that use them (two register sets; the scheduling barriers keep hipcc from sinking the
+            // reads back down to their first use, where the LDS latency is exposed with two waves per SIMD)
             const float* xa = xs + buf * XF + 4 * kg * XS + apix;
             const float* wa = ws + buf * WF + i * C3_LDW + 4 * kg;
+            f32x4 wv[2][CT];
+            float av[2][4];
+            auto load_tap = [&](int tap, int slot) {
+                const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) wv[slot][ct] = *reinterpret_cast<const f32x4*>(wa + (tap * BC + ct * 16) * C3_LDW);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[slot][j] = xa[j * XS + dy * PW + dx];
+            };
+            load_tap(0, 0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const int dy = tap / 3, dx = tap % 3;
-                f32x4 wv[CT];
+                if (tap + 1 < 9) load_tap(tap + 1, (tap + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) wv[ct] = *reinterpret_cast<const f32x4*>(wa + (tap * BC + ct * 16) * C3_LDW);
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = xa[j * XS + dy * PW + dx];
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wv[ct][j], acc[ct], 0, 0, 0);
-                }
+                    for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap & 1][j], wv[tap & 1][ct][j], acc[ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (s + 1 < trips) commit(buf ^ 1);
