@@ -114,6 +114,12 @@ int se_conv2d_1x1_tile_f32(int batch, int cin, int cout, int hw);
 int se_conv2d_1x1_f32(const float* x, const float* wpack, const float* bias, const float* residual, const float* in_bias, float* out,
                       int batch, int cin, int cout, int hw, int relu, void* stream);
 
+/* ... and its stride-2 form, the `downsample` convolution of a stage's first Bottleneck (network/pose_resnet.py:140-146):
+ * x [batch][cin][2 ho][2 wo] -> out [batch][cout][ho][wo] = W x[:, :, ::2, ::2] + bias (+ ReLU); wpack / covered shapes as
+ * se_conv2d_1x1_tile_f32(batch, cin, cout, ho * wo) says, wo % 4 == 0. */
+int se_conv2d_1x1_s2_f32(const float* x, const float* wpack, const float* bias, float* out, int batch, int cin, int cout, int ho, int wo,
+                         int relu, void* stream);
+
 /* 3x3 convolution (stride 1, padding 1) of the backbone's deep stages as a direct float32 MFMA product: replaces conv2 (`conv3x3`,
  * network/pose_resnet.py:22-25) of the Bottlenecks of layer3 / layer4 with its folded BatchNorm (round 6; csrc/conv2d_3x3.hip).
  *   x [batch][cin][h][w], out [batch][cout][h][w] float32 NCHW; bias [cout] or NULL (the raw sums: the consumer adds it, see in_bias above)

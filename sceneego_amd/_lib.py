@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -46,6 +46,7 @@ SIGNATURES = {
     "se_deconv2d_k4s2_assemble_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv2d_1x1_tile_f32": (_i, [_i, _i, _i, _i]),
     "se_conv2d_1x1_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_conv2d_1x1_s2_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "se_conv2d_3x3_tile_f32": (_i, [_i, _i, _i, _i, _i]),
     "se_conv2d_3x3_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -314,6 +315,22 @@ def conv2d_1x1(x, wpack, bias, residual, relu, in_bias=None):
     out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
     _check(load().se_conv2d_1x1_f32(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(residual), _ptr(in_bias), _ptr(out), B, cin, cout, H * W,
                                     1 if relu else 0, _stream()), "se_conv2d_1x1_f32")
+    return out
+
+
+def conv2d_1x1_s2(x, wpack, bias, relu=False):
+    """``x`` [B, cin, 2 ho, 2 wo] -> relu?(W x[:, :, ::2, ::2] + bias) [B, cout, ho, wo]: the stride-2 1x1 convolution (se_conv2d_1x1_s2_f32);
+    ``wpack`` packed for ``conv2d_1x1_tile(B, cin, cout, ho * wo)``."""
+    require_hip(x, wpack, bias)
+    _chk_f32(x, wpack, bias)
+    B, cin, H, W = x.shape
+    assert H % 2 == 0 and W % 2 == 0
+    ho, wo = H // 2, W // 2
+    cout = wpack.shape[0] * wpack.shape[2]
+    assert wpack.dim() == 4 and wpack.shape[1] * 16 == cin and wpack.shape[2] == conv2d_1x1_tile(B, cin, cout, ho * wo)
+    out = torch.empty((B, cout, ho, wo), device=x.device, dtype=torch.float32)
+    _check(load().se_conv2d_1x1_s2_f32(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(out), B, cin, cout, ho, wo, 1 if relu else 0, _stream()),
+           "se_conv2d_1x1_s2_f32")
     return out
 
 

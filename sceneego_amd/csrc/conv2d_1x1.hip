@@ -52,10 +52,14 @@ __device__ __forceinline__ void c1_step(const float* __restrict__ xs, const floa
 // step's latencies behind; the groups swap half of their accumulators through LDS at the end and each finishes half of the channels.
 // INB: the input is the raw result of the producing convolution and its bias + ReLU happen HERE, on the way into LDS: x' = max(x +
 // in_bias[channel], 0) (the 3x3 convolution of a Bottleneck in front of conv3: its own epilogue pass over the tensor disappears).
-template <int BP, int BC, int KS, bool INB>
+// MODE 2 (stride 2, the downsample convolution of a stage's first Bottleneck): P counts OUTPUT pixels per sample, `wo` is the output
+// width; output pixel (y, x) reads input pixel (2 y, 2 x) of a [2 ho][2 wo] map - a thread's four pixels are the even elements of
+// eight consecutive input floats (two 16-byte loads).
+template <int BP, int BC, int KS, int MODE>
 __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ wpack, const float* __restrict__ bias,
                                                       const float* __restrict__ res, const float* __restrict__ in_bias, float* __restrict__ out,
-                                                      int cin, int cout, int P, int relu) {
+                                                      int cin, int cout, int P, int relu, int wo) {
+    constexpr bool INB = MODE == 1, S2 = MODE == 2;
     constexpr int PT = BP / 32, CT = BC / 32;                            // 16 x 16 tiles per wave: (BP / 2) pixels x (BC / 2) channels
     constexpr int LDX = C1Geom<BP>::LDX;
     constexpr int XF = C1Geom<BP>::X_FLOATS, WF = BC * C1_LDW;
@@ -81,7 +85,12 @@ __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restri
         const long long n = n0 + 4 * c4;
         const long long b = n / P;
         const int p = (int)(n - b * P);
-        xsrc[v] = x + (b * cin + k) * P + p;                              // + step * 16 * P
+        if (S2) {
+            const int y = p / wo, xo = p - y * wo;
+            xsrc[v] = x + (b * cin + k) * (4LL * P) + (2LL * y) * (2 * wo) + 2 * xo;
+        } else {
+            xsrc[v] = x + (b * cin + k) * P + p;                          // + step * 16 * P
+        }
         xdst[v] = k * LDX + 4 * c4;
     }
     const float* wsrc = wpack + (long long)blockIdx.y * steps * (BC * 16) + t * 4;      // + step * BC * 16 + v * 1024
@@ -96,7 +105,13 @@ __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restri
     auto fetch = [&](int s) {
 #pragma unroll
         for (int v = 0; v < XV; ++v) {
-            xr[v] = *reinterpret_cast<const f32x4*>(xsrc[v] + (long long)s * 16 * P);
+            if (S2) {
+                const float* q = xsrc[v] + (long long)s * 64 * P;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(q), hi = *reinterpret_cast<const f32x4*>(q + 4);
+                xr[v] = (f32x4){lo.x, lo.z, hi.x, hi.z};
+            } else {
+                xr[v] = *reinterpret_cast<const f32x4*>(xsrc[v] + (long long)s * 16 * P);
+            }
             if (INB) xb[v] = in_bias[s * 16 + (t + v * 256) / (BP / 4)];
         }
 #pragma unroll
@@ -170,17 +185,21 @@ __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restri
 
 template <int BP, int BC, int KS>
 int launch_c1(const float* x, const float* wpack, const float* bias, const float* res, const float* in_bias, float* out, long long pixels,
-              int cin, int cout, int P, int relu, hipStream_t s) {
+              int cin, int cout, int P, int relu, hipStream_t s, int wo = 0) {
     constexpr int LDS = KS * (2 * C1Geom<BP>::X_FLOATS + 2 * BC * C1_LDW) * 4;
     const dim3 grid((unsigned)(pixels / BP), cout / BC), block(256 * KS);
-    if (in_bias) {
-        auto kern = conv1x1_kernel<BP, BC, KS, true>;
+    if (wo) {
+        auto kern = conv1x1_kernel<BP, BC, KS, 2>;
         SE_ENSURE_LDS(kern, LDS);
-        hipLaunchKernelGGL(kern, grid, block, LDS, s, x, wpack, bias, res, in_bias, out, cin, cout, P, relu);
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, x, wpack, bias, res, in_bias, out, cin, cout, P, relu, wo);
+    } else if (in_bias) {
+        auto kern = conv1x1_kernel<BP, BC, KS, 1>;
+        SE_ENSURE_LDS(kern, LDS);
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, x, wpack, bias, res, in_bias, out, cin, cout, P, relu, 0);
     } else {
-        auto kern = conv1x1_kernel<BP, BC, KS, false>;
+        auto kern = conv1x1_kernel<BP, BC, KS, 0>;
         SE_ENSURE_LDS(kern, LDS);
-        hipLaunchKernelGGL(kern, grid, block, LDS, s, x, wpack, bias, res, in_bias, out, cin, cout, P, relu);
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, x, wpack, bias, res, in_bias, out, cin, cout, P, relu, 0);
     }
     SE_CHECK_LAUNCH();
     return 0;
@@ -218,4 +237,22 @@ extern "C" int se_conv2d_1x1_f32(const float* x, const float* wpack, const float
     if (kse == 4) return launch_c1<64, 64, 4>(x, wpack, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s);
     if (kse == 2) return launch_c1<64, 64, 2>(x, wpack, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s);
     return launch_c1<64, 64, 1>(x, wpack, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s);
+}
+
+// The stride-2 form (the `downsample` convolution of the first Bottleneck of layer2 / layer3 / layer4, network/pose_resnet.py:140-146):
+// x [batch][cin][2 ho][2 wo] -> out [batch][cout][ho][wo] = W x[:, :, ::2, ::2] + bias (ReLU optional).  wpack and the covered shapes as
+// se_conv2d_1x1_tile_f32(batch, cin, cout, ho * wo) says, and wo % 4 == 0.
+extern "C" int se_conv2d_1x1_s2_f32(const float* x, const float* wpack, const float* bias, float* out, int batch, int cin, int cout, int ho,
+                                    int wo, int relu, void* stream) {
+    if (ho <= 0 || wo <= 0 || (wo & 3)) return SE_ERR_BAD_ARG;
+    const int hw = ho * wo;
+    const int bc = se_conv2d_1x1_tile_f32(batch, cin, cout, hw);
+    if (!bc || !x || !wpack || !bias || !out) return SE_ERR_BAD_ARG;
+    const long long pixels = (long long)batch * hw;
+    hipStream_t s = se_stream(stream);
+    const bool split = cin >= C1_SPLIT_MIN_CIN && cin % 32 == 0;
+    if (bc == 128) return split ? launch_c1<64, 128, 2>(x, wpack, bias, nullptr, nullptr, out, pixels, cin, cout, hw, relu, s, wo)
+                                : launch_c1<64, 128, 1>(x, wpack, bias, nullptr, nullptr, out, pixels, cin, cout, hw, relu, s, wo);
+    return split ? launch_c1<64, 64, 2>(x, wpack, bias, nullptr, nullptr, out, pixels, cin, cout, hw, relu, s, wo)
+                 : launch_c1<64, 64, 1>(x, wpack, bias, nullptr, nullptr, out, pixels, cin, cout, hw, relu, s, wo);
 }

@@ -205,6 +205,24 @@ class FoldedBackbone:
             return tile
         return 0
 
+    def _pw_s2(self, x, wb, slot):
+        """The stride-2 1x1 downsample convolution + bias: se_conv2d_1x1_s2_f32 when covered (MIOpen's route: a transpose in, a GEMM, a
+        transpose out, then the bias pass)."""
+        from . import _lib
+        B, cin, H, W = x.shape
+        cout = wb[0].shape[0]
+        stride = wb[2]
+        ok = (stride in (2, (2, 2)) and self.dtype == torch.float32 and self.conv1x1 and H % 2 == 0 and W % 8 == 0 and cin <= 2 * self.conv1x1_max_cin)
+        tile = _lib.conv2d_1x1_tile(B, cin, cout, (H // 2) * (W // 2)) if ok else 0
+        if tile and ((B * H * W // 4) // 64) * (cout // tile) >= self.conv1x1_min_wg:
+            cache = self.__dict__.setdefault("_pw_cache", {})
+            key = (slot, tile, x.device)
+            if key not in cache:
+                cache[key] = (_lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile), wb[1].float().contiguous())
+            wp, bias = cache[key]
+            return _lib.conv2d_1x1_s2(x, wp, bias, False)
+        return _lib.bias_act_nchw(F.conv2d(x, wb[0], None, stride=stride), wb[1], None, False)
+
     def _pw(self, x, wb, residual, relu, slot, in_bias=None):
         """1x1 stride-1 convolution + bias (+ residual) (+ ReLU): the fused GEMM when it covers the shape, else MIOpen + epilogue pass.
         ``in_bias``: ``x`` is the raw result of the convolution in front and relu(x + in_bias) is the real input - applied inside
@@ -263,7 +281,7 @@ class FoldedBackbone:
             elif ds[2] in (1, (1, 1)):
                 sc = self._pw(x, ds, None, False, (bi, 0))
             else:
-                sc = ba(F.conv2d(x, ds[0], None, stride=ds[2]), ds[1], None, False)
+                sc = self._pw_s2(x, ds, (bi, 0))
             x = self._pw(y, c3, sc, True, (bi, 3), in_bias=c2[1])
         for li, (w, b) in enumerate(self.ups):
             B, _, H, W = x.shape

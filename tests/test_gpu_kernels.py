@@ -488,6 +488,22 @@ def test_conv2d_1x1_fused_gemm_vs_float64(B, cin, cout, H, residual, relu):
     assert _lib.conv2d_1x1_tile(1, cin, cout, 40) == 0
 
 
+@pytest.mark.parametrize("B,cin,cout,ho,wo", [(8, 256, 512, 32, 32), (8, 512, 1024, 16, 16), (8, 1024, 2048, 8, 8), (1, 256, 512, 32, 32), (2, 64, 128, 4, 24)])
+def test_conv2d_1x1_stride2_vs_float64(B, cin, cout, ho, wo):
+    """se_conv2d_1x1_s2_f32 (the `downsample` convolution of a stage's first Bottleneck, network/pose_resnet.py:140-146, BatchNorm folded)
+    against a float64 product of x[:, :, ::2, ::2] on the host; the odd rows / columns of x hold NaN (never read)."""
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.full((B, cin, 2 * ho, 2 * wo), float("nan"))
+    x[:, :, ::2, ::2] = torch.randn(B, cin, ho, wo, generator=g)
+    w = torch.randn(cout, cin, generator=g) * (2.0 / cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    want = torch.einsum("oc,bchw->bohw", w.double(), x[:, :, ::2, ::2].double()) + b.double().view(1, -1, 1, 1)
+    tile = _lib.conv2d_1x1_tile(B, cin, cout, ho * wo)
+    got = _lib.conv2d_1x1_s2(x.to(DEV), _lib.conv2d_1x1_pack(w, tile).to(DEV), b.to(DEV), False)
+    assert got.shape == (B, cout, ho, wo) and bool(torch.isfinite(got).all())
+    assert float((got.double().cpu() - want).abs().max()) < 1e-5 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("B,cin,cout,H,W,bias,relu", [
     (8, 256, 256, 16, 16, False, False), (8, 512, 512, 8, 8, False, False), (8, 128, 128, 32, 32, True, True), (1, 64, 64, 64, 64, True, False),
     (2, 32, 96, 8, 24, True, True), (3, 64, 32, 12, 16, False, True), (1, 512, 512, 8, 8, True, True)])
