@@ -130,6 +130,11 @@ int se_conv2d_3x3_tile_f32(int batch, int cin, int cout, int h, int w);
 int se_conv2d_3x3_f32(const float* x, const float* wpack, const float* bias, float* out, int batch, int cin, int cout, int h, int w,
                       int relu, void* stream);
 
+/* ... and its stride-2 form (conv2 of a stage's first Bottleneck): x [batch][cin][2 ho][2 wo] -> out [batch][cout][ho][wo], padding 1;
+ * wpack = [cout / 16][cin / 16][9][16][16] (channel tile 16); cin % 32 == 0, cout % 16 == 0, output map 8k x 8m or 4k x 16m. */
+int se_conv2d_3x3_s2_f32(const float* x, const float* wpack, const float* bias, float* out, int batch, int cin, int cout, int ho, int wo,
+                         int relu, void* stream);
+
 /* Output side of the 2-D pose head's transposed convolutions - ConvTranspose2d(k=4, s=2, p=1) + BatchNorm2d + ReLU,
  * network/pose_resnet.py:205-224 (built), :238 (run) - when the layer is computed as ONE GEMM over the un-shifted input:
  *   z    [batch][4 ky][4 kx][cout][h][w] = W_tap [cout x cin] @ x[b] [cin x h*w] for each of the 16 taps (any GEMM library;

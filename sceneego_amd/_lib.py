@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -49,6 +49,7 @@ SIGNATURES = {
     "se_conv2d_1x1_s2_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "se_conv2d_3x3_tile_f32": (_i, [_i, _i, _i, _i, _i]),
     "se_conv2d_3x3_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "se_conv2d_3x3_s2_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_pack_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv3d_packed_elems": (_ll, [_i, _i, _i, _i]),
     "se_conv3d_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
@@ -356,6 +357,27 @@ def conv2d_3x3(x, wpack, bias, relu):
     out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
     _check(load().se_conv2d_3x3_f32(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(out), B, cin, cout, H, W, 1 if relu else 0, _stream()),
            "se_conv2d_3x3_f32")
+    return out
+
+
+def conv2d_3x3_s2_ok(cin, cout, ho, wo) -> bool:
+    """Shapes se_conv2d_3x3_s2_f32 covers (output map ho x wo)."""
+    tile_ok = (ho % 4 == 0) if wo % 16 == 0 else (wo % 8 == 0 and ho % 8 == 0)
+    return cin % 32 == 0 and cout % 16 == 0 and ho > 0 and wo > 0 and tile_ok and cin * ho * wo * 4 < (1 << 31) // 4
+
+
+def conv2d_3x3_s2(x, wpack, bias, relu):
+    """``x`` [B, cin, 2 ho, 2 wo] -> relu?(conv3x3 stride 2 padding 1 (x) (+ bias)) [B, cout, ho, wo] (se_conv2d_3x3_s2_f32); ``wpack`` =
+    ``conv2d_3x3_pack(w, 16)``."""
+    require_hip(x, wpack)
+    _chk_f32(x, wpack, bias)
+    B, cin, H, W = x.shape
+    assert H % 2 == 0 and W % 2 == 0
+    cout = wpack.shape[0] * wpack.shape[3]
+    assert wpack.dim() == 5 and wpack.shape[1] * 16 == cin and wpack.shape[2] == 9 and wpack.shape[3] == 16
+    out = torch.empty((B, cout, H // 2, W // 2), device=x.device, dtype=torch.float32)
+    _check(load().se_conv2d_3x3_s2_f32(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(out), B, cin, cout, H // 2, W // 2, 1 if relu else 0, _stream()),
+           "se_conv2d_3x3_s2_f32")
     return out
 
 

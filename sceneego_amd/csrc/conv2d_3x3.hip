@@ -20,20 +20,22 @@ namespace {
 
 constexpr int C3_LDW = 24;          // floats per (tap, cout) row of the W image (16 k + 8: conflict-free ds_read_b128)
 
-template <int TW>
+template <int TW, int S>
 struct C3Geom {
-    static constexpr int TH = 64 / TW, PH = TH + 2, PW = TW + 2;
-    static constexpr int XS = (TW == 16) ? 116 : 100;                   // floats per channel of the X image: = 4 (mod 16), so the four k groups of a wave read four disjoint 16-bank windows
+    static constexpr int TH = 64 / TW, PH = S * TH + 3 - S, PW = S * TW + 3 - S;     // stride 1: (TH + 2) x (TW + 2); stride 2: (2 TH + 1) x (2 TW + 1)
+    // floats per channel of the X image: = 4 (mod 16), so the four k groups of a wave read four disjoint 16-bank windows
+    static constexpr int XS = (S == 1) ? ((TW == 16) ? 116 : 100) : ((TW == 16) ? 308 : 292);
     static constexpr int X_FLOATS = 16 * XS;
     static_assert(XS >= PH * PW && XS % 16 == 4, "X image stride");
 };
 
-// x [B][cin][H][W], wpack [cout / BC][cin / 16][9][BC][16], bias (or null) [cout], out [B][cout][H][W];
-// H % TH == 0, W % TW == 0, cin % (16 KS) == 0, cout % BC == 0.  Grid: (pixel tiles, cout / BC), walked XCD by XCD (see below).
-template <int TW, int BC, int KS>
+// x [B][cin][S H][S W], wpack [cout / BC][cin / 16][9][BC][16], bias (or null) [cout], out [B][cout][H][W] (H, W: the OUTPUT map; S = stride,
+// padding 1: output (y, x) reads input rows S y - 1 .. S y + 1); H % TH == 0, W % TW == 0, cin % (16 KS) == 0, cout % BC == 0.
+// Grid: (pixel tiles, cout / BC), walked XCD by XCD (see below).
+template <int TW, int BC, int KS, int S>
 __global__ __launch_bounds__(256 * KS) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ wpack, const float* __restrict__ bias,
                                                            float* __restrict__ out, int cin, int cout, int H, int W, int relu) {
-    using G = C3Geom<TW>;
+    using G = C3Geom<TW, S>;
     constexpr int TH = G::TH, PH = G::PH, PW = G::PW, XS = G::XS, XF = G::X_FLOATS;
     constexpr int CT = BC / 16;
     constexpr int WF = 9 * BC * C3_LDW;
@@ -58,8 +60,9 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_kernel(const float* __restri
     const int y0 = ty * TH, x0 = tx * TW;
     const int c0 = ctile * BC;
     const int steps = cin >> 4, trips = steps / KS;
-    const long long HW = (long long)H * W;
-    const float* xb = x + (long long)b * cin * HW;
+    const long long HW = (long long)H * W, HWI = HW * (S * S);
+    const int HI = S * H, WI = S * W;
+    const float* xb = x + (long long)b * cin * HWI;
 
     // this thread's elements of an X patch: e = t + 256 v -> (channel, patch row, patch column); the same every step but for the channel base
     int xoff[NX], xdst[NX];
@@ -69,10 +72,10 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_kernel(const float* __restri
         int e = t + 256 * v;
         if (e >= NXE) e = NXE - 1;                                       // the tail repeats the last element (same value, same slot)
         const int ch = e / (PH * PW), rem = e - ch * (PH * PW), r = rem / PW, c = rem - r * PW;
-        const int y = y0 - 1 + r, xx = x0 - 1 + c;
-        const bool ok = y >= 0 && y < H && xx >= 0 && xx < W;
+        const int y = S * y0 - 1 + r, xx = S * x0 - 1 + c;
+        const bool ok = y >= 0 && y < HI && xx >= 0 && xx < WI;
         xok |= (ok ? 1u : 0u) << v;
-        xoff[v] = ch * (int)HW + (ok ? y * W + xx : 0);
+        xoff[v] = ch * (int)HWI + (ok ? y * WI + xx : 0);
         xdst[v] = ch * XS + r * PW + c;
     }
     const float* wsrc = wpack + (long long)ctile * steps * (9 * BC * 16);
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_kernel(const float* __restri
     float xr[NX];
     f32x4 wr[NW];
     auto fetch = [&](int s) {
-        const float* xc = xb + (long long)s * 16 * HW;
+        const float* xc = xb + (long long)s * 16 * HWI;
 #pragma unroll
         for (int v = 0; v < NX; ++v) xr[v] = xc[xoff[v]];
         const float* wc = wsrc + (long long)s * (9 * BC * 16);
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_kernel(const float* __restri
     };
     // this lane's pixel of the wave's row tile, as an offset into a channel of the patch (tap (0, 0) = the pixel's upper left neighbour)
     const int ry = (TW == 16) ? wave : 2 * wave + (i >> 3), rx = (TW == 16) ? i : (i & 7);
-    const int apix = ry * PW + rx;
+    const int apix = S * (ry * PW + rx);
     f32x4 acc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -167,11 +170,12 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_kernel(const float* __restri
     }
 }
 
-template <int TW, int BC, int KS>
+template <int TW, int BC, int KS, int S = 1>
 int launch_c3(const float* x, const float* wpack, const float* bias, float* out, int batch, int cin, int cout, int H, int W, int relu, hipStream_t s) {
-    using G = C3Geom<TW>;
+    using G = C3Geom<TW, S>;
     constexpr int LDS = KS * (2 * G::X_FLOATS + 2 * 9 * BC * C3_LDW) * 4;
-    auto kern = conv3x3_kernel<TW, BC, KS>;
+    static_assert(LDS <= 160 * 1024, "LDS image");
+    auto kern = conv3x3_kernel<TW, BC, KS, S>;
     SE_ENSURE_LDS(kern, LDS);
     const dim3 grid((unsigned)(batch * (H / G::TH) * (W / TW)), cout / BC);
     hipLaunchKernelGGL(kern, grid, dim3(256 * KS), LDS, s, x, wpack, bias, out, cin, cout, H, W, relu);
@@ -212,4 +216,19 @@ extern "C" int se_conv2d_3x3_f32(const float* x, const float* wpack, const float
         return launch_c3<8, 16, 4>(x, wpack, bias, out, batch, cin, cout, h, w, relu, s);
     if (t8) return bc == 32 ? launch_c3<8, 32, 2>(x, wpack, bias, out, batch, cin, cout, h, w, relu, s) : launch_c3<8, 16, 2>(x, wpack, bias, out, batch, cin, cout, h, w, relu, s);
     return bc == 32 ? launch_c3<16, 32, 2>(x, wpack, bias, out, batch, cin, cout, h, w, relu, s) : launch_c3<16, 16, 2>(x, wpack, bias, out, batch, cin, cout, h, w, relu, s);
+}
+
+// The stride-2 form (conv2 of the first Bottleneck of layer2 / layer3 / layer4, network/pose_resnet.py:78 with stride 2):
+// x [batch][cin][2 ho][2 wo] -> out [batch][cout][ho][wo], padding 1.  wpack = [cout / 16][cin / 16][9][16][16] (channel tile 16: the input
+// patch of a 64-pixel output tile is 2.7 times the stride-1 one and leaves the LDS room for 16 channels of weights per wave group).
+// Covered: cin % 32 == 0, cout % 16 == 0 and an output map of 8k x 8m or 4k x 16m; SE_ERR_BAD_ARG otherwise.
+extern "C" int se_conv2d_3x3_s2_f32(const float* x, const float* wpack, const float* bias, float* out, int batch, int cin, int cout, int ho, int wo,
+                                    int relu, void* stream) {
+    if (batch <= 0 || cin <= 0 || (cin & 31) || cout <= 0 || (cout & 15) || ho <= 0 || wo <= 0 || !x || !wpack || !out) return SE_ERR_BAD_ARG;
+    const bool t8 = (wo % 16 != 0);
+    if (t8 ? (wo % 8 != 0 || ho % 8 != 0) : (ho % 4 != 0)) return SE_ERR_BAD_ARG;
+    if ((long long)cin * ho * wo * 4 >= (1LL << 31) / 4) return SE_ERR_BAD_ARG;
+    hipStream_t s = se_stream(stream);
+    if (t8) return launch_c3<8, 16, 2, 2>(x, wpack, bias, out, batch, cin, cout, ho, wo, relu, s);
+    return launch_c3<16, 16, 2, 2>(x, wpack, bias, out, batch, cin, cout, ho, wo, relu, s);
 }

@@ -247,6 +247,7 @@ class FoldedBackbone:
     # implicit GEMM with the transposes around it 62; on the wide maps of layer1 / layer2 MIOpen is level or ahead (32 vs 35, 29 vs 30) and stays.
     # SCENEEGO_CONV3X3=0: MIOpen for all (A/B).
     CONV3X3_MAX_PIXELS = 256
+    CONV3X3_S2_MAX_PIXELS = int(os.environ.get("SCENEEGO_CONV3X3_S2_MAX_PIXELS", 1024))   # output pixels of the stride-2 form
     CONV3X3_MIN_WORKGROUPS = 0          # also at batch 1 (64 workgroups): 398.3 -> 401 frames/s as a graph, batch 2: 560 -> 570 (tools/ab_conv3x3_b1.sh)
 
     def _c3(self, x, wb, stride, slot):
@@ -263,6 +264,13 @@ class FoldedBackbone:
                 if key not in cache:
                     cache[key] = _lib.conv2d_3x3_pack(wb[0].float(), tile)
                 return _lib.conv2d_3x3(x, cache[key], None, False)
+        if (stride in (2, (2, 2)) and self.dtype == torch.float32 and self.conv3x3 and H % 2 == 0 and W % 2 == 0
+                and (H * W) // 4 <= self.CONV3X3_S2_MAX_PIXELS and _lib.conv2d_3x3_s2_ok(cin, cout, H // 2, W // 2)):
+            cache = self.__dict__.setdefault("_c3_cache", {})
+            key = (slot, 16, x.device)
+            if key not in cache:
+                cache[key] = _lib.conv2d_3x3_pack(wb[0].float(), 16)
+            return _lib.conv2d_3x3_s2(x, cache[key], None, False)
         return F.conv2d(x, wb[0], None, stride=stride, padding=1)
 
     def _call_fused(self, images):

@@ -529,6 +529,23 @@ def test_conv2d_3x3_direct_mfma_vs_float64(B, cin, cout, H, W, bias, relu):
     assert _lib.conv2d_3x3_tile(B, cin, cout, 6, 16) == 0 and _lib.conv2d_3x3_tile(B, cin, cout, 8, 12) == 0
 
 
+@pytest.mark.parametrize("B,cin,cout,ho,wo,bias", [(8, 128, 128, 32, 32, False), (8, 256, 256, 16, 16, False), (8, 512, 512, 8, 8, False),
+                                                    (1, 256, 256, 16, 16, True), (2, 32, 48, 8, 24, True), (3, 64, 16, 4, 16, False)])
+def test_conv2d_3x3_stride2_vs_float64(B, cin, cout, ho, wo, bias):
+    """se_conv2d_3x3_s2_f32 (conv2 of a stage's first Bottleneck: stride 2, padding 1; network/pose_resnet.py:22-25,78) against a float64
+    convolution on the host: the three backbone shapes at B = 8, 16- and 8-pixel-wide tiles, non-square maps.  1e-5 of the largest |y|."""
+    g = torch.Generator().manual_seed(cin + 3 * cout + ho)
+    x = torch.randn(B, cin, 2 * ho, 2 * wo, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    want = F.conv2d(x.double(), w.double(), b.double() if bias else None, stride=2, padding=1)
+    assert _lib.conv2d_3x3_s2_ok(cin, cout, ho, wo) and not _lib.conv2d_3x3_s2_ok(cin + 16, cout, ho, wo) and not _lib.conv2d_3x3_s2_ok(cin, cout, 6, 16)
+    got = _lib.conv2d_3x3_s2(x.to(DEV), _lib.conv2d_3x3_pack(w, 16).to(DEV), b.to(DEV) if bias else None, False)
+    assert got.shape == (B, cout, ho, wo) and bool(torch.isfinite(got).all())
+    err = float((got.double().cpu() - want).abs().max())
+    assert err < 1e-5 * float(want.abs().max()), err
+
+
 def test_backbone_fused_1x1_matches_miopen_route(monkeypatch):
     """FoldedBackbone with the 1x1 convolutions on se_conv2d_1x1_f32 (default) against the same folded network with every one of them on
     MIOpen + se_bias_act_nchw_f32 (SCENEEGO_CONV1X1=0), B = 8 and B = 1 (the routing rule keeps the small launches on MIOpen)."""
