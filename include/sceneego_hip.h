@@ -101,6 +101,11 @@ int se_intersection_f32(float* buf, const float* occ, int batch, int voxels, int
 int se_bias_act_nchw_f32(const float* x, const float* bias, const float* residual, float* out,
                          int batch, int channels, int hw, int relu, void* stream);
 
+/* Stem tail of the backbone in one pass: `bn1` (folded into conv1's weights: + bias), `relu` and `maxpool` (3x3, stride 2, padding 1),
+ * network/pose_resnet.py:229-232, on the raw result of conv1: out = relu(max over the window (x) + bias[c]).
+ * x [batch][channels][2 ho][2 wo], out [batch][channels][ho][wo] float32; wo % 4 == 0. */
+int se_bias_relu_maxpool3x3s2_f32(const float* x, const float* bias, float* out, int batch, int channels, int ho, int wo, void* stream);
+
 /* 1x1 convolution (stride 1) of the backbone as ONE float32 MFMA GEMM with its whole epilogue: replaces conv1 / conv3 / the stride-1
  * downsample of Bottleneck.forward with their BatchNorm (folded into w and bias), `out += residual` and the ReLU
  * (network/pose_resnet.py:72-90) - MIOpen's convolution plus the se_bias_act_nchw_f32 pass behind it (round 6; csrc/conv2d_1x1.hip).

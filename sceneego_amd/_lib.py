@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -44,6 +44,7 @@ SIGNATURES = {
     "se_intersection_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "se_bias_act_nchw_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_deconv2d_k4s2_assemble_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_bias_relu_maxpool3x3s2_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_conv2d_1x1_tile_f32": (_i, [_i, _i, _i, _i]),
     "se_conv2d_1x1_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "se_conv2d_1x1_s2_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -291,6 +292,18 @@ def bias_act_nchw(x, bias, residual, relu):
     _check(load().se_bias_act_nchw_f32(_ptr(x), _ptr(bias), _ptr(residual), _ptr(x), n, c, hh * ww, 1 if relu else 0,
                                        _stream()), "se_bias_act_nchw_f32")
     return x
+
+
+def bias_relu_maxpool(x, bias):
+    """``x`` [B, C, 2 ho, 2 wo] float32 (raw stem convolution) -> max_pool2d(relu(x + bias), 3, stride 2, padding 1) [B, C, ho, wo] in one
+    pass (se_bias_relu_maxpool3x3s2_f32); wo % 4 == 0."""
+    require_hip(x, bias)
+    _chk_f32(x, bias)
+    B, C, H, W = x.shape
+    assert H % 2 == 0 and W % 8 == 0 and bias.numel() == C
+    out = torch.empty((B, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
+    _check(load().se_bias_relu_maxpool3x3s2_f32(_ptr(x), _ptr(bias), _ptr(out), B, C, H // 2, W // 2, _stream()), "se_bias_relu_maxpool3x3s2_f32")
+    return out
 
 
 def conv2d_1x1_tile(batch, cin, cout, hw) -> int:

@@ -232,6 +232,51 @@ extern "C" int se_bias_act_nchw_f32(const float* x, const float* bias, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stem tail of the backbone in one pass: `bn1` (folded: + bias) + `relu` + `maxpool` (3 x 3, stride 2, padding 1) of
+// network/pose_resnet.py:229-232 on the raw result of conv1.  relu(. + b) is monotone, so max first: out = relu(max_window(x) + bias[c]).
+// x [N][C][2 ho][2 wo], out [N][C][ho][wo]; wo % 4 == 0 (a thread makes 4 consecutive outputs from 3 rows x 9 columns).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(const float* __restrict__ x, const float* __restrict__ bias, f32x4* __restrict__ out,
+                                                                long long total4, int channels, int ho, int wo) {
+    const int wo4 = wo >> 2, wi = 2 * wo;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int xo4 = (int)(i % wo4), yo = (int)((i / wo4) % ho);
+        const long long nc = i / ((long long)wo4 * ho);
+        const float* base = x + nc * (4LL * ho * wo) + 8 * xo4;
+        const float ninf = -__builtin_inff();
+        f32x4 m = {ninf, ninf, ninf, ninf};
+#pragma unroll
+        for (int r = -1; r <= 1; ++r) {
+            const int y = 2 * yo + r;
+            if (y < 0) continue;
+            const float* row = base + (long long)y * wi;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(row), b = *reinterpret_cast<const f32x4*>(row + 4);
+            const float l = xo4 > 0 ? row[-1] : ninf;
+            m.x = fmaxf(m.x, fmaxf(l, fmaxf(a.x, a.y)));
+            m.y = fmaxf(m.y, fmaxf(a.y, fmaxf(a.z, a.w)));
+            m.z = fmaxf(m.z, fmaxf(a.w, fmaxf(b.x, b.y)));
+            m.w = fmaxf(m.w, fmaxf(b.y, fmaxf(b.z, b.w)));
+        }
+        const float bv = bias[(int)(nc % channels)];
+        m += bv;
+        m.x = fmaxf(m.x, 0.f); m.y = fmaxf(m.y, 0.f); m.z = fmaxf(m.z, 0.f); m.w = fmaxf(m.w, 0.f);
+        out[i] = m;
+    }
+}
+}  // namespace
+
+extern "C" int se_bias_relu_maxpool3x3s2_f32(const float* x, const float* bias, float* out, int batch, int channels, int ho, int wo, void* stream) {
+    if (batch <= 0 || channels <= 0 || ho <= 0 || wo <= 0 || (wo & 3) || !x || !bias || !out) return SE_ERR_BAD_ARG;
+    const long long total4 = (long long)batch * channels * ho * (wo / 4);
+    const unsigned grid = (unsigned)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(bias_relu_maxpool_kernel, dim3(grid), dim3(256), 0, se_stream(stream), x, bias, reinterpret_cast<f32x4*>(out), total4, channels,
+                       ho, wo);
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // ConvTranspose2d(k = 4, stride 2, padding 1) + folded BatchNorm + ReLU of the 2-D pose head (network/pose_resnet.py:205-224,238)
 // as ONE GEMM over the un-shifted input plus this assembly pass.  With Z[b][ky][kx][co][j][i] = sum_ci w[ci][co][ky][kx] x[b][ci][j][i]
 // (a plain [16 co x ci] x [ci x HW] GEMM per sample: no gathered / shifted copies of x, which for the 2048-channel layer were

@@ -279,8 +279,11 @@ class FoldedBackbone:
         single pass)."""
         from . import _lib
         ba = _lib.bias_act_nchw
-        x = ba(F.conv2d(images.contiguous(), self.stem[0], None, stride=2, padding=3), self.stem[1], None, True)
-        x = F.max_pool2d(x, 3, stride=2, padding=1)
+        x = F.conv2d(images.contiguous(), self.stem[0], None, stride=2, padding=3)
+        if self.dtype == torch.float32 and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0:
+            x = _lib.bias_relu_maxpool(x, self.stem[1])                    # bn1 + relu + maxpool in one pass over the stem's largest tensor
+        else:
+            x = F.max_pool2d(ba(x, self.stem[1], None, True), 3, stride=2, padding=1)
         for bi, (c1, c2, c3, stride, ds) in enumerate(self.blocks):
             y = self._pw(x, c1, None, True, (bi, 1))
             y = self._c3(y, c2, stride, (bi, 2))                            # raw: bn2's bias + ReLU ride into conv3's launch (_pw in_bias)

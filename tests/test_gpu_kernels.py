@@ -488,6 +488,18 @@ def test_conv2d_1x1_fused_gemm_vs_float64(B, cin, cout, H, residual, relu):
     assert _lib.conv2d_1x1_tile(1, cin, cout, 40) == 0
 
 
+def test_bias_relu_maxpool_stem_tail_exact():
+    """se_bias_relu_maxpool3x3s2_f32 against max_pool2d(relu(x + bias), 3, 2, 1): the same float32 operations in another order (max is
+    exact, relu(. + b) monotone) - bit-identical, borders included."""
+    g = torch.Generator().manual_seed(11)
+    for B, C, H, W in ((2, 64, 128, 128), (1, 3, 6, 8), (3, 5, 10, 24)):
+        x = torch.randn(B, C, H, W, generator=g).to(DEV)
+        b = torch.randn(C, generator=g).to(DEV)
+        want = F.max_pool2d(F.relu(x + b.view(1, -1, 1, 1)), 3, stride=2, padding=1)
+        got = _lib.bias_relu_maxpool(x, b)
+        assert got.shape == want.shape and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("B,cin,cout,ho,wo", [(8, 256, 512, 32, 32), (8, 512, 1024, 16, 16), (8, 1024, 2048, 8, 8), (1, 256, 512, 32, 32), (2, 64, 128, 4, 24)])
 def test_conv2d_1x1_stride2_vs_float64(B, cin, cout, ho, wo):
     """se_conv2d_1x1_s2_f32 (the `downsample` convolution of a stage's first Bottleneck, network/pose_resnet.py:140-146, BatchNorm folded)
