@@ -306,9 +306,21 @@ def bias_relu_maxpool(x, bias):
     return out
 
 
+_TILE_MEMO = {}
+
+
+def _tile_memo(fn_name, *args) -> int:
+    """The library's tile answers depend on the arguments and the current device's CU count only: one ctypes call per distinct question."""
+    key = (fn_name, torch.cuda.current_device() if torch.cuda.is_available() else -1) + args
+    t = _TILE_MEMO.get(key)
+    if t is None:
+        t = _TILE_MEMO[key] = int(getattr(load(), fn_name)(*args))
+    return t
+
+
 def conv2d_1x1_tile(batch, cin, cout, hw) -> int:
     """Channel-tile width the packed weights of a 1x1 convolution need (128 / 64), 0 when se_conv2d_1x1_f32 does not cover the shape."""
-    return int(load().se_conv2d_1x1_tile_f32(batch, cin, cout, hw))
+    return _tile_memo("se_conv2d_1x1_tile_f32", int(batch), int(cin), int(cout), int(hw))
 
 
 def conv2d_1x1_pack(w2d, tile):
@@ -350,7 +362,7 @@ def conv2d_1x1_s2(x, wpack, bias, relu=False):
 
 def conv2d_3x3_tile(batch, cin, cout, h, w) -> int:
     """Channel-tile width the packed weights of a 3x3 stride-1 convolution need (32 / 16), 0 when se_conv2d_3x3_f32 does not cover the shape."""
-    return int(load().se_conv2d_3x3_tile_f32(batch, cin, cout, h, w))
+    return _tile_memo("se_conv2d_3x3_tile_f32", int(batch), int(cin), int(cout), int(h), int(w))
 
 
 def conv2d_3x3_pack(w4d, tile):

@@ -196,31 +196,36 @@ class FoldedBackbone:
     CONV1X1_MIN_WORKGROUPS = 256       # below ~one workgroup per CU MIOpen's split kernels win (tools/bench_conv1x1.py)
     CONV1X1_MAX_CIN = 512              # ... and so they do on the long-K layers (1024 / 2048 input channels: 64 serial k steps per workgroup)
 
-    def _pw_tile(self, x, cout):
-        """Channel tile of the fused GEMM for a 1x1 convolution of ``x`` to ``cout`` channels, 0 = the layer stays on MIOpen."""
-        from . import _lib
-        B, cin, H, W = x.shape
-        tile = _lib.conv2d_1x1_tile(B, cin, cout, H * W) if (self.dtype == torch.float32 and self.conv1x1) else 0
-        if tile and cin <= self.conv1x1_max_cin and ((B * H * W) // 64) * (cout // tile) >= self.conv1x1_min_wg:
-            return tile
-        return 0
+    def _plan(self, kind, slot, x, make):
+        """Routing decisions are taken once per (layer, input shape, device): ``make()`` -> the packed operands of the HIP kernel, or
+        False for MIOpen.  (The decision asks the library for its tile width - a ctypes call per layer and forward would cost batch 1,
+        which is bound by the host when launched eagerly, ~3 % .)"""
+        plans = self.__dict__.setdefault("_plans", {})
+        key = (kind, slot, tuple(x.shape), x.device)
+        p = plans.get(key)
+        if p is None:
+            p = plans[key] = make()
+        return p
 
     def _pw_s2(self, x, wb, slot):
         """The stride-2 1x1 downsample convolution + bias: se_conv2d_1x1_s2_f32 when covered (MIOpen's route: a transpose in, a GEMM, a
         transpose out, then the bias pass)."""
         from . import _lib
-        B, cin, H, W = x.shape
-        cout = wb[0].shape[0]
         stride = wb[2]
-        ok = (stride in (2, (2, 2)) and self.dtype == torch.float32 and self.conv1x1 and H % 2 == 0 and W % 8 == 0 and cin <= 2 * self.conv1x1_max_cin)
-        tile = _lib.conv2d_1x1_tile(B, cin, cout, (H // 2) * (W // 2)) if ok else 0
-        if tile and ((B * H * W // 4) // 64) * (cout // tile) >= self.conv1x1_min_wg:
-            cache = self.__dict__.setdefault("_pw_cache", {})
-            key = (slot, tile, x.device)
-            if key not in cache:
-                cache[key] = (_lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile), wb[1].float().contiguous())
-            wp, bias = cache[key]
-            return _lib.conv2d_1x1_s2(x, wp, bias, False)
+
+        def make():
+            B, cin, H, W = x.shape
+            cout = wb[0].shape[0]
+            ok = (stride in (2, (2, 2)) and self.dtype == torch.float32 and self.conv1x1 and H % 2 == 0 and W % 8 == 0
+                  and cin <= 2 * self.conv1x1_max_cin)
+            tile = _lib.conv2d_1x1_tile(B, cin, cout, (H // 2) * (W // 2)) if ok else 0
+            if tile and ((B * H * W // 4) // 64) * (cout // tile) >= self.conv1x1_min_wg:
+                return (_lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile), wb[1].float().contiguous())
+            return False
+
+        p = self._plan("pw_s2", slot, x, make)
+        if p:
+            return _lib.conv2d_1x1_s2(x, p[0], p[1], False)
         return _lib.bias_act_nchw(F.conv2d(x, wb[0], None, stride=stride), wb[1], None, False)
 
     def _pw(self, x, wb, residual, relu, slot, in_bias=None):
@@ -228,16 +233,18 @@ class FoldedBackbone:
         ``in_bias``: ``x`` is the raw result of the convolution in front and relu(x + in_bias) is the real input - applied inside
         the fused GEMM, or by an epilogue pass of its own on the MIOpen route."""
         from . import _lib
-        B, cin, H, W = x.shape
-        cout = wb[0].shape[0]
-        tile = self._pw_tile(x, cout)
-        if tile:
-            cache = self.__dict__.setdefault("_pw_cache", {})
-            key = (slot, tile, x.device)
-            if key not in cache:
-                cache[key] = (_lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile), wb[1].float().contiguous())
-            wp, bias = cache[key]
-            return _lib.conv2d_1x1(x, wp, bias, residual, relu, in_bias)
+
+        def make():
+            B, cin, H, W = x.shape
+            cout = wb[0].shape[0]
+            tile = _lib.conv2d_1x1_tile(B, cin, cout, H * W) if (self.dtype == torch.float32 and self.conv1x1) else 0
+            if tile and cin <= self.conv1x1_max_cin and ((B * H * W) // 64) * (cout // tile) >= self.conv1x1_min_wg:
+                return (_lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile), wb[1].float().contiguous())
+            return False
+
+        p = self._plan("pw", slot, x, make)
+        if p:
+            return _lib.conv2d_1x1(x, p[0], p[1], residual, relu, in_bias)
         if in_bias is not None:
             x = _lib.bias_act_nchw(x, in_bias, None, True)
         return _lib.bias_act_nchw(F.conv2d(x, wb[0]), wb[1], residual, relu)
@@ -253,24 +260,24 @@ class FoldedBackbone:
     def _c3(self, x, wb, stride, slot):
         """conv2 of a Bottleneck WITHOUT its bias (raw sums)."""
         from . import _lib
-        B, cin, H, W = x.shape
-        cout = wb[0].shape[0]
-        if (stride in (1, (1, 1)) and self.dtype == torch.float32 and self.conv3x3 and H * W <= self.CONV3X3_MAX_PIXELS
-                and ((B * H * W) // 64) * (cout // 16) >= self.conv3x3_min_wg):
-            tile = _lib.conv2d_3x3_tile(B, cin, cout, H, W)
-            if tile:
-                cache = self.__dict__.setdefault("_c3_cache", {})
-                key = (slot, tile, x.device)
-                if key not in cache:
-                    cache[key] = _lib.conv2d_3x3_pack(wb[0].float(), tile)
-                return _lib.conv2d_3x3(x, cache[key], None, False)
-        if (stride in (2, (2, 2)) and self.dtype == torch.float32 and self.conv3x3 and H % 2 == 0 and W % 2 == 0
-                and (H * W) // 4 <= self.CONV3X3_S2_MAX_PIXELS and _lib.conv2d_3x3_s2_ok(cin, cout, H // 2, W // 2)):
-            cache = self.__dict__.setdefault("_c3_cache", {})
-            key = (slot, 16, x.device)
-            if key not in cache:
-                cache[key] = _lib.conv2d_3x3_pack(wb[0].float(), 16)
-            return _lib.conv2d_3x3_s2(x, cache[key], None, False)
+
+        def make():
+            B, cin, H, W = x.shape
+            cout = wb[0].shape[0]
+            if self.dtype != torch.float32 or not self.conv3x3:
+                return False
+            if (stride in (1, (1, 1)) and H * W <= self.CONV3X3_MAX_PIXELS and ((B * H * W) // 64) * (cout // 16) >= self.conv3x3_min_wg):
+                tile = _lib.conv2d_3x3_tile(B, cin, cout, H, W)
+                if tile:
+                    return (1, _lib.conv2d_3x3_pack(wb[0].float(), tile))
+            if (stride in (2, (2, 2)) and H % 2 == 0 and W % 2 == 0 and (H * W) // 4 <= self.CONV3X3_S2_MAX_PIXELS
+                    and _lib.conv2d_3x3_s2_ok(cin, cout, H // 2, W // 2)):
+                return (2, _lib.conv2d_3x3_pack(wb[0].float(), 16))
+            return False
+
+        p = self._plan("c3", slot, x, make)
+        if p:
+            return _lib.conv2d_3x3(x, p[1], None, False) if p[0] == 1 else _lib.conv2d_3x3_s2(x, p[1], None, False)
         return F.conv2d(x, wb[0], None, stride=stride, padding=1)
 
     def _call_fused(self, images):
