@@ -52,10 +52,14 @@ __device__ __forceinline__ void c1_step(const float* __restrict__ xs, const floa
 // step's latencies behind; the groups swap half of their accumulators through LDS at the end and each finishes half of the channels.
 // INB: the input is the raw result of the producing convolution and its bias + ReLU happen HERE, on the way into LDS: x' = max(x +
 // in_bias[channel], 0) (the 3x3 convolution of a Bottleneck in front of conv3: its own epilogue pass over the tensor disappears).
+// TRIPS > 0: the group's k loop has exactly TRIPS steps and is unrolled completely, with the loads TWO steps ahead of their use (two
+// register sets; in straight-line code hipcc counts its vmcnt waits exactly - loads carried around a loop's back edge get vmcnt(0)): a
+// workgroup's steps are a chain of load latencies (16-32 MFMAs per wave and step against ~2 us to L2 / HBM), and most launches have one
+// or two workgroups per CU.  TRIPS = 0: the run-time loop, loads one step ahead.
 // MODE 2 (stride 2, the downsample convolution of a stage's first Bottleneck): P counts OUTPUT pixels per sample, `wo` is the output
 // width; output pixel (y, x) reads input pixel (2 y, 2 x) of a [2 ho][2 wo] map - a thread's four pixels are the even elements of
 // eight consecutive input floats (two 16-byte loads).
-template <int BP, int BC, int KS, int MODE>
+template <int BP, int BC, int KS, int MODE, int TRIPS>
 __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ wpack, const float* __restrict__ bias,
                                                       const float* __restrict__ res, const float* __restrict__ in_bias, float* __restrict__ out,
                                                       int cin, int cout, int P, int relu, int wo) {
@@ -100,9 +104,12 @@ __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restri
         const int q = t + v * 256;
         wdst[v] = (q >> 2) * C1_LDW + 4 * (q & 3);
     }
-    f32x4 xr[XV], wr[WV];
-    float xb[XV];
-    auto fetch = [&](int s) {
+    f32x4 xr2[2][XV], wr2[2][WV];
+    float xb2[2][XV];
+    auto fetch = [&](int s, int set = 0) {
+        f32x4 (&xr)[XV] = xr2[set];
+        f32x4 (&wr)[WV] = wr2[set];
+        float (&xb)[XV] = xb2[set];
 #pragma unroll
         for (int v = 0; v < XV; ++v) {
             if (S2) {
@@ -117,7 +124,10 @@ __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restri
 #pragma unroll
         for (int v = 0; v < WV; ++v) wr[v] = *reinterpret_cast<const f32x4*>(wsrc + (long long)s * (BC * 16) + v * 1024);
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, int set = 0) {
+        f32x4 (&xr)[XV] = xr2[set];
+        f32x4 (&wr)[WV] = wr2[set];
+        float (&xb)[XV] = xb2[set];
 #pragma unroll
         for (int v = 0; v < XV; ++v) {
             if (INB) {
@@ -134,16 +144,31 @@ __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restri
     for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    fetch(grp);
-    commit(0);
-    __syncthreads();
-    // rotated: a trip requests the group's next step at its top and writes it into the other LDS half at its end (no loop-carried load registers)
-    for (int s = 0; s < trips; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < trips) fetch((s + 1) * KS + grp);
-        c1_step<PT, CT, LDX>(xs + buf * XF + wp * (BP / 2), ws + buf * WF + wc * (BC / 2) * C1_LDW, acc, i, kg);
-        if (s + 1 < trips) commit(buf ^ 1);
+    if (TRIPS > 0) {
+        // step n travels in register set n & 1: requested at the top of trip n - 2, written to LDS half n & 1 at the end of trip n - 1
+        fetch(grp, 0);
+        if (TRIPS > 1) fetch(KS + grp, 1);
+        commit(0, 0);
         __syncthreads();
+#pragma unroll
+        for (int s = 0; s < TRIPS; ++s) {
+            if (s + 2 < TRIPS) fetch((s + 2) * KS + grp, s & 1);
+            c1_step<PT, CT, LDX>(xs + (s & 1) * XF + wp * (BP / 2), ws + (s & 1) * WF + wc * (BC / 2) * C1_LDW, acc, i, kg);
+            if (s + 1 < TRIPS) commit((s + 1) & 1, (s + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        fetch(grp);
+        commit(0);
+        __syncthreads();
+        // rotated: a trip requests the group's next step at its top and writes it into the other LDS half at its end (no loop-carried load registers)
+        for (int s = 0; s < trips; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < trips) fetch((s + 1) * KS + grp);
+            c1_step<PT, CT, LDX>(xs + buf * XF + wp * (BP / 2), ws + buf * WF + wc * (BC / 2) * C1_LDW, acc, i, kg);
+            if (s + 1 < trips) commit(buf ^ 1);
+            __syncthreads();
+        }
     }
     if (KS > 1) {
         // accumulator tile q = pt * CT + ct belongs to group q % KS: every group writes the tiles it does not own into its OWN LDS region
@@ -183,26 +208,40 @@ __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restri
     }
 }
 
-template <int BP, int BC, int KS>
-int launch_c1(const float* x, const float* wpack, const float* bias, const float* res, const float* in_bias, float* out, long long pixels,
-              int cin, int cout, int P, int relu, hipStream_t s, int wo = 0) {
+template <int BP, int BC, int KS, int TRIPS>
+int launch_c1t(const float* x, const float* wpack, const float* bias, const float* res, const float* in_bias, float* out, long long pixels,
+               int cin, int cout, int P, int relu, hipStream_t s, int wo) {
     constexpr int LDS = KS * (2 * C1Geom<BP>::X_FLOATS + 2 * BC * C1_LDW) * 4;
     const dim3 grid((unsigned)(pixels / BP), cout / BC), block(256 * KS);
     if (wo) {
-        auto kern = conv1x1_kernel<BP, BC, KS, 2>;
+        auto kern = conv1x1_kernel<BP, BC, KS, 2, TRIPS>;
         SE_ENSURE_LDS(kern, LDS);
         hipLaunchKernelGGL(kern, grid, block, LDS, s, x, wpack, bias, res, in_bias, out, cin, cout, P, relu, wo);
     } else if (in_bias) {
-        auto kern = conv1x1_kernel<BP, BC, KS, 1>;
+        auto kern = conv1x1_kernel<BP, BC, KS, 1, TRIPS>;
         SE_ENSURE_LDS(kern, LDS);
         hipLaunchKernelGGL(kern, grid, block, LDS, s, x, wpack, bias, res, in_bias, out, cin, cout, P, relu, 0);
     } else {
-        auto kern = conv1x1_kernel<BP, BC, KS, 0>;
+        auto kern = conv1x1_kernel<BP, BC, KS, 0, TRIPS>;
         SE_ENSURE_LDS(kern, LDS);
         hipLaunchKernelGGL(kern, grid, block, LDS, s, x, wpack, bias, res, in_bias, out, cin, cout, P, relu, 0);
     }
     SE_CHECK_LAUNCH();
     return 0;
+}
+
+// the unrolled forms for the trip counts of the backbone (4: 64 channels, or 128 over two groups; 8: 256; 16: 512 - all over two groups),
+// the run-time loop for everything else; se_debug_set_variant(78): the run-time loop always (A/B in development builds)
+template <int BP, int BC, int KS>
+int launch_c1(const float* x, const float* wpack, const float* bias, const float* res, const float* in_bias, float* out, long long pixels,
+              int cin, int cout, int P, int relu, hipStream_t s, int wo = 0) {
+    const int trips = (cin >> 4) / KS;
+    if (g_variant != 78 && KS <= 2) {
+        if (trips == 4) return launch_c1t<BP, BC, KS, 4>(x, wpack, bias, res, in_bias, out, pixels, cin, cout, P, relu, s, wo);
+        if (trips == 8) return launch_c1t<BP, BC, KS, 8>(x, wpack, bias, res, in_bias, out, pixels, cin, cout, P, relu, s, wo);
+        if (trips == 16) return launch_c1t<BP, BC, KS, 16>(x, wpack, bias, res, in_bias, out, pixels, cin, cout, P, relu, s, wo);
+    }
+    return launch_c1t<BP, BC, KS, 0>(x, wpack, bias, res, in_bias, out, pixels, cin, cout, P, relu, s, wo);
 }
 
 }  // namespace

@@ -18,7 +18,7 @@ SHAPES = [(64, 64, 64, False, 1), (64, 256, 64, True, 3), (64, 256, 64, False, 1
           (1024, 512, 16, False, 1), (512, 2048, 8, True, 3), (2048, 512, 8, False, 2)]
 
 
-def timeit(fn, n=30, warm=5):
+def timeit(fn, n=400, warm=100):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -56,12 +56,12 @@ def main():
         if hasattr(lib, "se_debug_set_variant"):          # development library: force the 64- / 128-pixel tile
             ts = []
             ds = []
-            for v in (73, 74, 75):
+            for v in (73, 74, 78):
                 lib.se_debug_set_variant(v)
                 ts.append(timeit(new))
                 ds.append(float((new() - old()).abs().max()))
             lib.se_debug_set_variant(0)
-            extra = f"   [k split over 1 / 2 / 4 wave groups: {ts[0]:6.1f} {ts[1]:6.1f} {ts[2]:6.1f} (maxdiff {max(ds):.1e})]  workgroups {(B * H * H // 64) * (cout // tile)}"
+            extra = f"   [k split over 1 / 2 wave groups, run-time loop: {ts[0]:6.1f} {ts[1]:6.1f} {ts[2]:6.1f} (maxdiff {max(ds):.1e})]  workgroups {(B * H * H // 64) * (cout // tile)}"
         diff = float((new() - old()).abs().max())
         flop = 2.0 * B * H * H * cin * cout
         byts = 4.0 * B * H * H * (cin + cout * (2 if has_res else 1))

@@ -16,7 +16,7 @@ from sceneego_amd import _lib      # noqa: E402
 SHAPES = [(64, 64, 3), (128, 32, 3), (256, 16, 5), (512, 8, 2)]
 
 
-def timeit(fn, n=30, warm=5):
+def timeit(fn, n=400, warm=100):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
