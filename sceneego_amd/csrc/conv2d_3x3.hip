@@ -32,7 +32,9 @@ struct C3Geom {
 // x [B][cin][S H][S W], wpack [cout / BC][cin / 16][9][BC][16], bias (or null) [cout], out [B][cout][H][W] (H, W: the OUTPUT map; S = stride,
 // padding 1: output (y, x) reads input rows S y - 1 .. S y + 1); H % TH == 0, W % TW == 0, cin % (16 KS) == 0, cout % BC == 0.
 // Grid: (pixel tiles, cout / BC), walked XCD by XCD (see below).
-template <int TW, int BC, int KS, int S>
+// TRIPS > 0: the group's k loop has exactly TRIPS steps and is unrolled completely with the loads TWO steps ahead (two register sets; see
+// conv2d_1x1.hip); TRIPS = 0: the run-time loop, loads one step ahead.
+template <int TW, int BC, int KS, int S, int TRIPS>
 __global__ __launch_bounds__(256 * KS) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ wpack, const float* __restrict__ bias,
                                                            float* __restrict__ out, int cin, int cout, int H, int W, int relu) {
     using G = C3Geom<TW, S>;
@@ -87,9 +89,11 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_kernel(const float* __restri
         woff[v] = 4 * q;
         wdst[v] = (q >> 2) * C3_LDW + 4 * (q & 3);
     }
-    float xr[NX];
-    f32x4 wr[NW];
-    auto fetch = [&](int s) {
+    float xr2[TRIPS > 0 ? 2 : 1][NX];
+    f32x4 wr2[TRIPS > 0 ? 2 : 1][NW];
+    auto fetch = [&](int s, int set = 0) {
+        float (&xr)[NX] = xr2[set];
+        f32x4 (&wr)[NW] = wr2[set];
         const float* xc = xb + (long long)s * 16 * HWI;
 #pragma unroll
         for (int v = 0; v < NX; ++v) xr[v] = xc[xoff[v]];
@@ -97,7 +101,9 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_kernel(const float* __restri
 #pragma unroll
         for (int v = 0; v < NW; ++v) wr[v] = *reinterpret_cast<const f32x4*>(wc + woff[v]);
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, int set = 0) {
+        float (&xr)[NX] = xr2[set];
+        f32x4 (&wr)[NW] = wr2[set];
 #pragma unroll
         for (int v = 0; v < NX; ++v) xs[buf * XF + xdst[v]] = ((xok >> v) & 1u) ? xr[v] : 0.f;
 #pragma unroll
@@ -109,13 +115,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_kernel(const float* __restri
     f32x4 acc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    fetch(grp);
-    commit(0);
-    __syncthreads();
-    for (int s = 0; s < trips; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < trips) fetch((s + 1) * KS + grp);
-        {
+    auto compute = [&](int buf) {
             // operands one tap ahead of the MFMAs that use them (two register sets; the scheduling barriers keep hipcc from sinking the
             // reads back down to their first use, where the LDS latency is exposed with two waves per SIMD)
             const float* xa = xs + buf * XF + 4 * kg * XS + apix;
@@ -140,9 +140,31 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_kernel(const float* __restri
                     for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap & 1][j], wv[tap & 1][ct][j], acc[ct], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        if (s + 1 < trips) commit(buf ^ 1);
+    };
+    if (TRIPS > 0) {
+        // step n travels in register set n & 1: requested at the top of trip n - 2, written to LDS half n & 1 at the end of trip n - 1
+        fetch(grp, 0);
+        if (TRIPS > 1) fetch(KS + grp, 1);
+        commit(0, 0);
         __syncthreads();
+#pragma unroll
+        for (int s = 0; s < TRIPS; ++s) {
+            if (s + 2 < TRIPS) fetch((s + 2) * KS + grp, s & 1);
+            compute(s & 1);
+            if (s + 1 < TRIPS) commit((s + 1) & 1, (s + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        fetch(grp);
+        commit(0);
+        __syncthreads();
+        for (int s = 0; s < trips; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < trips) fetch((s + 1) * KS + grp);
+            compute(buf);
+            if (s + 1 < trips) commit(buf ^ 1);
+            __syncthreads();
+        }
     }
     if (KS > 1) {
         // the other groups' sums travel through their own LDS regions (free after the last barrier); group 0 finishes
@@ -170,17 +192,28 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_kernel(const float* __restri
     }
 }
 
-template <int TW, int BC, int KS, int S = 1>
-int launch_c3(const float* x, const float* wpack, const float* bias, float* out, int batch, int cin, int cout, int H, int W, int relu, hipStream_t s) {
+template <int TW, int BC, int KS, int S, int TRIPS>
+int launch_c3t(const float* x, const float* wpack, const float* bias, float* out, int batch, int cin, int cout, int H, int W, int relu, hipStream_t s) {
     using G = C3Geom<TW, S>;
     constexpr int LDS = KS * (2 * G::X_FLOATS + 2 * 9 * BC * C3_LDW) * 4;
     static_assert(LDS <= 160 * 1024, "LDS image");
-    auto kern = conv3x3_kernel<TW, BC, KS, S>;
+    auto kern = conv3x3_kernel<TW, BC, KS, S, TRIPS>;
     SE_ENSURE_LDS(kern, LDS);
     const dim3 grid((unsigned)(batch * (H / G::TH) * (W / TW)), cout / BC);
     hipLaunchKernelGGL(kern, grid, dim3(256 * KS), LDS, s, x, wpack, bias, out, cin, cout, H, W, relu);
     SE_CHECK_LAUNCH();
     return 0;
+}
+
+// unrolled forms for the stride-1 trip counts of the backbone (8: 256 channels over two groups, 16: 512); se_debug_set_variant(78): never
+template <int TW, int BC, int KS, int S = 1>
+int launch_c3(const float* x, const float* wpack, const float* bias, float* out, int batch, int cin, int cout, int H, int W, int relu, hipStream_t s) {
+    const int trips = (cin >> 4) / KS;
+    if (S == 1 && KS == 2 && g_variant != 78) {
+        if (trips == 8) return launch_c3t<TW, BC, KS, S, (S == 1 && KS == 2) ? 8 : 0>(x, wpack, bias, out, batch, cin, cout, H, W, relu, s);
+        if (trips == 16) return launch_c3t<TW, BC, KS, S, (S == 1 && KS == 2) ? 16 : 0>(x, wpack, bias, out, batch, cin, cout, H, W, relu, s);
+    }
+    return launch_c3t<TW, BC, KS, S, 0>(x, wpack, bias, out, batch, cin, cout, H, W, relu, s);
 }
 
 }  // namespace
