@@ -458,3 +458,45 @@ def test_fft7_numpy_model_equals_direct_convolution():
     ref, got = m.conv7_direct(x, w, b), m.conv7_fft(x, w, b)
     assert float(np.abs(ref - got).max()) < 1e-12 and float(ref.max()) > 0.5
     assert m.NF == 7488 and m.weight_spectrum(w).shape == (7488, 3, 2)
+
+
+def test_backbone_weight_packers_and_stride2_shape_rule():
+    """Host side of the backbone kernels (csrc/conv2d_1x1.hip, conv2d_3x3.hip): the packed layouts the kernels stream -
+    [cout / BC][cin / 16][BC][16] and [cout / BC][cin / 16][9][BC][16], tap = 3 dy + dx - element by element, and the shape rule of the
+    stride-2 3x3 form."""
+    from sceneego_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(128, 48, generator=g)
+    for tile in (64, 128):
+        p = _lib.conv2d_1x1_pack(w, tile)
+        assert p.shape == (128 // tile, 3, tile, 16) and p.is_contiguous()
+        for ct, s, co, k in ((0, 0, 0, 0), (128 // tile - 1, 2, tile - 1, 15), (0, 1, 17, 3)):
+            assert p[ct, s, co, k] == w[ct * tile + co, 16 * s + k]
+    w3 = torch.randn(64, 32, 3, 3, generator=g)
+    for tile in (16, 32):
+        p = _lib.conv2d_3x3_pack(w3, tile)
+        assert p.shape == (64 // tile, 2, 9, tile, 16) and p.is_contiguous()
+        for ct, s, tap, co, k in ((0, 0, 0, 0, 0), (64 // tile - 1, 1, 8, tile - 1, 15), (1, 0, 5, 3, 7)):
+            assert p[ct, s, tap, co, k] == w3[ct * tile + co, 16 * s + k, tap // 3, tap % 3]
+    ok = _lib.conv2d_3x3_s2_ok
+    assert ok(128, 128, 32, 32) and ok(256, 256, 16, 16) and ok(512, 512, 8, 8) and ok(32, 16, 4, 16) and ok(32, 48, 8, 24)
+    assert not ok(48, 128, 32, 32) and not ok(128, 24, 32, 32) and not ok(128, 128, 6, 16) and not ok(128, 128, 8, 12) and not ok(128, 128, 4, 4)
+
+
+def test_folded_backbone_routes_on_cpu_without_the_library():
+    """FoldedBackbone on a CPU tensor takes the plain PyTorch route (folded weights, no HIP call): the host-side folding of every BatchNorm
+    into its convolution is checked against the unfolded network; the HIP routes are the `-m gpu` tests' business."""
+    from sceneego_amd import pose_resnet
+    torch.manual_seed(3)
+    net = pose_resnet.get_pose_net(None).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.1, 0.1)
+            m.running_var.uniform_(0.8, 1.2)
+            m.weight.data.uniform_(0.8, 1.2)
+            m.bias.data.uniform_(-0.1, 0.1)
+    img = torch.randn(1, 3, 64, 64)
+    with torch.no_grad():
+        ref = net(img, compute_heatmaps=False)[1]
+        got = pose_resnet.FoldedBackbone(net)(img)
+    assert float((got - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-5
