@@ -205,13 +205,16 @@ int launch_c3t(const float* x, const float* wpack, const float* bias, float* out
     return 0;
 }
 
-// unrolled forms for the stride-1 trip counts of the backbone (8: 256 channels over two groups, 16: 512); se_debug_set_variant(78): never
+// unrolled forms for the stride-1 trip counts of the backbone (4 / 8: 64 / 128 channels in one group, 8 / 16: 256 / 512 over two);
+// se_debug_set_variant(78): never
 template <int TW, int BC, int KS, int S = 1>
 int launch_c3(const float* x, const float* wpack, const float* bias, float* out, int batch, int cin, int cout, int H, int W, int relu, hipStream_t s) {
     const int trips = (cin >> 4) / KS;
-    if (S == 1 && KS == 2 && g_variant != 78) {
-        if (trips == 8) return launch_c3t<TW, BC, KS, S, (S == 1 && KS == 2) ? 8 : 0>(x, wpack, bias, out, batch, cin, cout, H, W, relu, s);
-        if (trips == 16) return launch_c3t<TW, BC, KS, S, (S == 1 && KS == 2) ? 16 : 0>(x, wpack, bias, out, batch, cin, cout, H, W, relu, s);
+    if (S == 1 && KS <= 2 && g_variant != 78) {
+        constexpr bool U = (S == 1 && KS <= 2);
+        if (trips == 4) return launch_c3t<TW, BC, KS, S, U ? 4 : 0>(x, wpack, bias, out, batch, cin, cout, H, W, relu, s);
+        if (trips == 8) return launch_c3t<TW, BC, KS, S, U ? 8 : 0>(x, wpack, bias, out, batch, cin, cout, H, W, relu, s);
+        if (trips == 16) return launch_c3t<TW, BC, KS, S, U ? 16 : 0>(x, wpack, bias, out, batch, cin, cout, H, W, relu, s);
     }
     return launch_c3t<TW, BC, KS, S, 0>(x, wpack, bias, out, batch, cin, cout, H, W, relu, s);
 }
@@ -238,8 +241,10 @@ extern "C" int se_conv2d_3x3_f32(const float* x, const float* wpack, const float
     if (!bc || !x || !wpack || !out) return SE_ERR_BAD_ARG;
     hipStream_t s = se_stream(stream);
     const bool t8 = (w % 16 != 0);
-    // se_debug_set_variant(76): one wave group instead of two (A/B in development builds)
-    if (g_variant == 76) {
+    // one wave group where the grid alone fills the device (two or more workgroups per CU: the wide maps of layer1 / layer2 - 27.9 / 25.8 us
+    // against 32.0 / 27.8 with two groups); se_debug_set_variant(76): always one group, (79): never (A/B in development builds)
+    const long long wgs0 = ((long long)batch * h * w / 64) * (cout / bc);
+    if (g_variant == 76 || (wgs0 >= 2LL * se_num_cus() && g_variant != 79)) {
         if (t8) return bc == 32 ? launch_c3<8, 32, 1>(x, wpack, bias, out, batch, cin, cout, h, w, relu, s) : launch_c3<8, 16, 1>(x, wpack, bias, out, batch, cin, cout, h, w, relu, s);
         return bc == 32 ? launch_c3<16, 32, 1>(x, wpack, bias, out, batch, cin, cout, h, w, relu, s) : launch_c3<16, 16, 1>(x, wpack, bias, out, batch, cin, cout, h, w, relu, s);
     }

@@ -193,7 +193,7 @@ class FoldedBackbone:
     # float32 1x1 convolutions with stride 1 (conv1, conv3 and layer1's downsample of every Bottleneck: 33 of the 53 convolutions) run
     # on se_conv2d_1x1_f32 - one MFMA GEMM with bias, residual add and ReLU in its epilogue (round 6) - where the shape is covered and
     # large enough to fill the chip; SCENEEGO_CONV1X1=0 keeps MIOpen + se_bias_act_nchw_f32 for all of them (A/B).
-    CONV1X1_MIN_WORKGROUPS = 256       # below ~one workgroup per CU MIOpen's split kernels win (tools/bench_conv1x1.py)
+    CONV1X1_MIN_WORKGROUPS = 64        # from a quarter of a workgroup per CU on (batch 1 as a graph: 414.4 frames/s with 256, 417.3 / 420.8 / 418.3 with 128 / 64 / 0; tools/ab_conv1x1_b1g.sh)
     CONV1X1_MAX_CIN = 512              # ... and so they do on the long-K layers (1024 / 2048 input channels: 64 serial k steps per workgroup)
 
     def _plan(self, kind, slot, x, make):
@@ -249,11 +249,11 @@ class FoldedBackbone:
             x = _lib.bias_act_nchw(x, in_bias, None, True)
         return _lib.bias_act_nchw(F.conv2d(x, wb[0]), wb[1], residual, relu)
 
-    # float32 3x3 stride-1 convolutions of the deep stages (layer3: 256 -> 256 at 16 x 16, layer4: 512 -> 512 at 8 x 8 for 256 x 256 images)
-    # run on se_conv2d_3x3_f32, a direct MFMA product: 29 / 34 us at B = 8 where MIOpen's Winograd assembly kernel takes 53 and its NHWC
-    # implicit GEMM with the transposes around it 62; on the wide maps of layer1 / layer2 MIOpen is level or ahead (32 vs 35, 29 vs 30) and stays.
-    # SCENEEGO_CONV3X3=0: MIOpen for all (A/B).
-    CONV3X3_MAX_PIXELS = 256
+    # float32 3x3 convolutions of the Bottlenecks run on se_conv2d_3x3_f32 / _s2_f32, a direct MFMA product: 26 / 28 us at B = 8 for layer3 /
+    # layer4 where MIOpen's Winograd assembly kernel takes 53 and its NHWC implicit GEMM with the transposes around it 62; on the wide maps of
+    # layer1 / layer2 (one wave group) 28 / 26 us against MIOpen's 30 - level at B = 8 (one stream 1003 -> 1009 frames/s), ahead at batch 1
+    # (404.6 -> 414.5 as a graph; tools/ab_conv3x3_wide.sh).  SCENEEGO_CONV3X3=0: MIOpen for all (A/B).
+    CONV3X3_MAX_PIXELS = int(os.environ.get("SCENEEGO_CONV3X3_MAX_PIXELS", 4096))   # layer1 .. layer4 for 256 x 256 images
     CONV3X3_S2_MAX_PIXELS = int(os.environ.get("SCENEEGO_CONV3X3_S2_MAX_PIXELS", 1024))   # output pixels of the stride-2 form
     CONV3X3_MIN_WORKGROUPS = 0          # also at batch 1 (64 workgroups): 398.3 -> 401 frames/s as a graph, batch 2: 560 -> 570 (tools/ab_conv3x3_b1.sh)
 
