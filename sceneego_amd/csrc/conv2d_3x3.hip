@@ -205,13 +205,15 @@ int launch_c3t(const float* x, const float* wpack, const float* bias, float* out
     return 0;
 }
 
-// unrolled forms for the stride-1 trip counts of the backbone (4 / 8: 64 / 128 channels in one group, 8 / 16: 256 / 512 over two);
+// unrolled forms for the stride-1 trip counts of the backbone (4 / 8: 64 / 128 channels in one group, 8 / 16: 256 / 512 over two,
+// 2 / 4 / 8: 128 / 256 / 512 over four at batch 1-2);
 // se_debug_set_variant(78): never
 template <int TW, int BC, int KS, int S = 1>
 int launch_c3(const float* x, const float* wpack, const float* bias, float* out, int batch, int cin, int cout, int H, int W, int relu, hipStream_t s) {
     const int trips = (cin >> 4) / KS;
-    if (S == 1 && KS <= 2 && g_variant != 78) {
-        constexpr bool U = (S == 1 && KS <= 2);
+    if (S == 1 && g_variant != 78) {
+        constexpr bool U = (S == 1);
+        if (trips == 2) return launch_c3t<TW, BC, KS, S, U ? 2 : 0>(x, wpack, bias, out, batch, cin, cout, H, W, relu, s);
         if (trips == 4) return launch_c3t<TW, BC, KS, S, U ? 4 : 0>(x, wpack, bias, out, batch, cin, cout, H, W, relu, s);
         if (trips == 8) return launch_c3t<TW, BC, KS, S, U ? 8 : 0>(x, wpack, bias, out, batch, cin, cout, H, W, relu, s);
         if (trips == 16) return launch_c3t<TW, BC, KS, S, U ? 16 : 0>(x, wpack, bias, out, batch, cin, cout, H, W, relu, s);
