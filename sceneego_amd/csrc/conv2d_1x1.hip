@@ -19,6 +19,9 @@
 namespace {
 
 constexpr int C1_SPLIT_MIN_CIN = 128;   // k split over two wave groups from here on (8+ k steps): 17.4 -> 14.8 us at 512 -> 128 @32^2, 18.5 -> 16.1 at 256 -> 1024 @16^2; layer1's 64-channel inputs lose 1 us
+#ifndef C1_PREFETCH
+#define C1_PREFETCH 2
+#endif
 constexpr int C1_LDW = 24;          // floats per cout row of the W image (16 k + 8: conflict-free ds_read_b128 over the 4 x 16 lane groups)
 
 template <int BP>
@@ -104,8 +107,9 @@ __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restri
         const int q = t + v * 256;
         wdst[v] = (q >> 2) * C1_LDW + 4 * (q & 3);
     }
-    f32x4 xr2[2][XV], wr2[2][WV];
-    float xb2[2][XV];
+    constexpr int PD = C1_PREFETCH;                                        // steps the loads run ahead in the unrolled forms
+    f32x4 xr2[PD][XV], wr2[PD][WV];
+    float xb2[PD][XV];
     auto fetch = [&](int s, int set = 0) {
         f32x4 (&xr)[XV] = xr2[set];
         f32x4 (&wr)[WV] = wr2[set];
@@ -145,16 +149,18 @@ __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restri
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (TRIPS > 0) {
-        // step n travels in register set n & 1: requested at the top of trip n - 2, written to LDS half n & 1 at the end of trip n - 1
+        // step n travels in register set n % PD: requested at the top of trip n - PD, written to LDS half n & 1 at the end of trip n - 1
         fetch(grp, 0);
-        if (TRIPS > 1) fetch(KS + grp, 1);
+#pragma unroll
+        for (int n = 1; n < PD; ++n)
+            if (n < TRIPS) fetch(n * KS + grp, n);
         commit(0, 0);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < TRIPS; ++s) {
-            if (s + 2 < TRIPS) fetch((s + 2) * KS + grp, s & 1);
+            if (s + PD < TRIPS) fetch((s + PD) * KS + grp, s % PD);
             c1_step<PT, CT, LDX>(xs + (s & 1) * XF + wp * (BP / 2), ws + (s & 1) * WF + wc * (BC / 2) * C1_LDW, acc, i, kg);
-            if (s + 1 < TRIPS) commit((s + 1) & 1, (s + 1) & 1);
+            if (s + 1 < TRIPS) commit((s + 1) & 1, (s + 1) % PD);
             __syncthreads();
         }
     } else {
