@@ -119,6 +119,15 @@ int se_conv2d_1x1_tile_f32(int batch, int cin, int cout, int hw);
 int se_conv2d_1x1_f32(const float* x, const float* wpack, const float* bias, const float* residual, const float* in_bias, float* out,
                       int batch, int cin, int cout, int hw, int relu, void* stream);
 
+/* The same operator for the launches of batch 1-2 that would leave most CUs without a workgroup (64 - 1024 pixels against megabytes of
+ * weights): 64 pixels x 16 channels per workgroup, the k steps over four / two wave groups.  wpack16 = [cout / 16][cin / 16][16][16];
+ * cin % 64 == 0, cout % 16 == 0, hw % 16 == 0, batch * hw % 64 == 0 (SE_ERR_BAD_ARG otherwise).  Arguments as se_conv2d_1x1_f32. */
+int se_conv2d_1x1_small_f32(const float* x, const float* wpack16, const float* bias, const float* residual, const float* in_bias, float* out,
+                            int batch, int cin, int cout, int hw, int relu, void* stream);
+/* ... stride 2: x [batch][cin][2 ho][2 wo] -> out [batch][cout][ho][wo]; the conditions above on (cin, cout, ho * wo), wo % 4 == 0. */
+int se_conv2d_1x1_small_s2_f32(const float* x, const float* wpack16, const float* bias, float* out, int batch, int cin, int cout, int ho,
+                               int wo, int relu, void* stream);
+
 /* ... and its stride-2 form, the `downsample` convolution of a stage's first Bottleneck (network/pose_resnet.py:140-146):
  * x [batch][cin][2 ho][2 wo] -> out [batch][cout][ho][wo] = W x[:, :, ::2, ::2] + bias (+ ReLU); wpack / covered shapes as
  * se_conv2d_1x1_tile_f32(batch, cin, cout, ho * wo) says, wo % 4 == 0. */

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # tools/ may point at the development build (csrc/build.sh --devtools -> libsceneego_hip_dev.so)
 LIB_PATH = os.environ.get("SCENEEGO_HIP_LIB") or os.path.join(_HERE, "libsceneego_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 EPI_RELU = 1
 EPI_RES_PRE_RELU = 2
@@ -47,6 +47,8 @@ SIGNATURES = {
     "se_bias_relu_maxpool3x3s2_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "se_conv2d_1x1_tile_f32": (_i, [_i, _i, _i, _i]),
     "se_conv2d_1x1_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_conv2d_1x1_small_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "se_conv2d_1x1_small_s2_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "se_conv2d_1x1_s2_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "se_conv2d_3x3_tile_f32": (_i, [_i, _i, _i, _i, _i]),
     "se_conv2d_3x3_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -344,17 +346,44 @@ def conv2d_1x1(x, wpack, bias, residual, relu, in_bias=None):
     return out
 
 
+def conv2d_1x1_small_ok(batch, cin, cout, hw) -> bool:
+    """Shapes se_conv2d_1x1_small_f32 covers."""
+    return cin % 64 == 0 and cout % 16 == 0 and hw % 16 == 0 and (batch * hw) % 64 == 0 and batch > 0
+
+
+def conv2d_1x1_small(x, wpack16, bias, residual, relu, in_bias=None):
+    """conv2d_1x1's result from the small-M kernel (se_conv2d_1x1_small_f32: 64 pixels x 16 channels per workgroup, k split over four / two
+    wave groups); ``wpack16`` = ``conv2d_1x1_pack(w2d, 16)``."""
+    require_hip(x, wpack16, bias)
+    _chk_f32(x, wpack16, bias, residual, in_bias)
+    B, cin, H, W = x.shape
+    cout = wpack16.shape[0] * 16
+    assert wpack16.dim() == 4 and wpack16.shape[1] * 16 == cin and wpack16.shape[2] == 16 and conv2d_1x1_small_ok(B, cin, cout, H * W)
+    assert in_bias is None or in_bias.numel() == cin
+    out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+    _check(load().se_conv2d_1x1_small_f32(_ptr(x), _ptr(wpack16), _ptr(bias), _ptr(residual), _ptr(in_bias), _ptr(out), B, cin, cout, H * W,
+                                          1 if relu else 0, _stream()), "se_conv2d_1x1_small_f32")
+    return out
+
+
 def conv2d_1x1_s2(x, wpack, bias, relu=False):
-    """``x`` [B, cin, 2 ho, 2 wo] -> relu?(W x[:, :, ::2, ::2] + bias) [B, cout, ho, wo]: the stride-2 1x1 convolution (se_conv2d_1x1_s2_f32);
-    ``wpack`` packed for ``conv2d_1x1_tile(B, cin, cout, ho * wo)``."""
+    """``x`` [B, cin, 2 ho, 2 wo] -> relu?(W x[:, :, ::2, ::2] + bias) [B, cout, ho, wo]: the stride-2 1x1 convolution (se_conv2d_1x1_s2_f32;
+    ``wpack`` packed for ``conv2d_1x1_tile(B, cin, cout, ho * wo)``) - or, with a 16-channel packing, its small-M form
+    (se_conv2d_1x1_small_s2_f32)."""
     require_hip(x, wpack, bias)
     _chk_f32(x, wpack, bias)
     B, cin, H, W = x.shape
     assert H % 2 == 0 and W % 2 == 0
     ho, wo = H // 2, W // 2
     cout = wpack.shape[0] * wpack.shape[2]
-    assert wpack.dim() == 4 and wpack.shape[1] * 16 == cin and wpack.shape[2] == conv2d_1x1_tile(B, cin, cout, ho * wo)
     out = torch.empty((B, cout, ho, wo), device=x.device, dtype=torch.float32)
+    assert wpack.dim() == 4 and wpack.shape[1] * 16 == cin
+    if wpack.shape[2] == 16:
+        assert conv2d_1x1_small_ok(B, cin, cout, ho * wo)
+        _check(load().se_conv2d_1x1_small_s2_f32(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(out), B, cin, cout, ho, wo, 1 if relu else 0, _stream()),
+               "se_conv2d_1x1_small_s2_f32")
+        return out
+    assert wpack.shape[2] == conv2d_1x1_tile(B, cin, cout, ho * wo)
     _check(load().se_conv2d_1x1_s2_f32(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(out), B, cin, cout, ho, wo, 1 if relu else 0, _stream()),
            "se_conv2d_1x1_s2_f32")
     return out

@@ -214,6 +214,152 @@ __global__ __launch_bounds__(256 * KS) void conv1x1_kernel(const float* __restri
     }
 }
 
+// Small-M form (batch 1-2: the long-K layers of layer2 .. layer4, 64 - 1024 pixels against 0.3 - 4 MB of weights): a workgroup owns 64
+// pixels x 16 output channels, so that even a 64-pixel map gives cout / 16 workgroups, and its KS wave groups take alternate 32-channel k
+// steps (wave = one 16-pixel row tile, all 16 channels); the groups' sums are added through LDS at the end and group 0 finishes.
+//   wpack16 = [cout / 16][cin / 16][16][16] (conv2d_1x1's packing with a 16-channel tile: a 32-channel step is one contiguous 2 KB run).
+// The X tile is re-read by every channel tile (cout / 16 times): right where the weights dominate the bytes, wrong for large maps - the caller
+// routes by shape.  MODE 1: in_bias as above.  TRIPS as above.
+template <int KS, int MODE, int TRIPS>
+__global__ __launch_bounds__(256 * KS) void conv1x1_small_kernel(const float* __restrict__ x, const float* __restrict__ wpack16, const float* __restrict__ bias,
+                                                                 const float* __restrict__ res, const float* __restrict__ in_bias, float* __restrict__ out,
+                                                                 int cin, int cout, int P, int relu, int wo) {
+    constexpr bool INB = MODE == 1, S2 = MODE == 2;
+    constexpr int KC = 32, LDX = 68, XF = KC * LDX, WF = (KC / 16) * 16 * C1_LDW, REGION = 2 * XF + 2 * WF;
+    constexpr int PD = C1_PREFETCH;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int grp = KS > 1 ? (int)(threadIdx.x >> 8) : 0;
+    float* xs = lds + grp * REGION;
+    float* ws = xs + 2 * XF;
+    const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
+    const int i = lane & 15, kg = lane >> 4;
+    const long long n0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 16;
+    const int trips = cin / (KC * KS);
+    // X pieces: q = t + 256 v -> channel q / 16 of the step, pixels 4 (q % 16) ..; W piece: q = t % 128 -> 16 bytes of the step's 2 KB run
+    const float* xsrc[2];
+    int xdst[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int q = t + 256 * v, k = q >> 4, c4 = q & 15;
+        const long long n = n0 + 4 * c4;
+        const long long b = n / P;
+        const int p = (int)(n - b * P);
+        if (S2) {
+            const int y = p / wo, xo = p - y * wo;
+            xsrc[v] = x + (b * cin + k) * (4LL * P) + (2LL * y) * (2 * wo) + 2 * xo;
+        } else {
+            xsrc[v] = x + (b * cin + k) * P + p;
+        }
+        xdst[v] = k * LDX + 4 * c4;
+    }
+    const int wq = t & 127;
+    const float* wsrc = wpack16 + (long long)blockIdx.y * (cin >> 4) * 256 + wq * 4;
+    const int wdst = (wq >> 2) * C1_LDW + 4 * (wq & 3);
+    f32x4 xr2[PD][2], wr2[PD];
+    float xb2[PD][2];
+    auto fetch = [&](int s, int set = 0) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            if (S2) {
+                const float* q = xsrc[v] + (long long)s * KC * 4 * P;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(q), hi = *reinterpret_cast<const f32x4*>(q + 4);
+                xr2[set][v] = (f32x4){lo.x, lo.z, hi.x, hi.z};
+            } else {
+                xr2[set][v] = *reinterpret_cast<const f32x4*>(xsrc[v] + (long long)s * KC * P);
+            }
+            if (INB) xb2[set][v] = in_bias[s * KC + ((t + 256 * v) >> 4)];
+        }
+        wr2[set] = *reinterpret_cast<const f32x4*>(wsrc + (long long)s * (KC * 16));
+    };
+    auto commit = [&](int buf, int set = 0) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            f32x4 r = xr2[set][v];
+            if (INB) {
+                const float bb = xb2[set][v];
+                r.x = fmaxf(r.x + bb, 0.f); r.y = fmaxf(r.y + bb, 0.f); r.z = fmaxf(r.z + bb, 0.f); r.w = fmaxf(r.w + bb, 0.f);
+            }
+            *reinterpret_cast<f32x4*>(xs + buf * XF + xdst[v]) = r;
+        }
+        *reinterpret_cast<f32x4*>(ws + buf * WF + wdst) = wr2[set];
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+        const float* xa = xs + buf * XF + 4 * kg * LDX + wave * 16 + i;
+        const float* wa = ws + buf * WF + i * C1_LDW + 4 * kg;
+#pragma unroll
+        for (int sub = 0; sub < KC / 16; ++sub) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wa + sub * 16 * C1_LDW);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(sub * 16 + j) * LDX], wv[j], acc, 0, 0, 0);
+        }
+    };
+    if (TRIPS > 0) {
+        fetch(grp, 0);
+#pragma unroll
+        for (int n = 1; n < PD; ++n)
+            if (n < TRIPS) fetch(n * KS + grp, n);
+        commit(0, 0);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < TRIPS; ++s) {
+            if (s + PD < TRIPS) fetch((s + PD) * KS + grp, s % PD);
+            compute(s & 1);
+            if (s + 1 < TRIPS) commit((s + 1) & 1, (s + 1) % PD);
+            __syncthreads();
+        }
+    } else {
+        fetch(grp);
+        commit(0);
+        __syncthreads();
+        for (int s = 0; s < trips; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < trips) fetch((s + 1) * KS + grp);
+            compute(buf);
+            if (s + 1 < trips) commit(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    if (KS > 1) {
+        if (grp != 0) reinterpret_cast<f32x4*>(xs)[t] = acc;
+        __syncthreads();
+        if (grp != 0) return;
+#pragma unroll
+        for (int o = 1; o < KS; ++o) acc += reinterpret_cast<const f32x4*>(lds + o * REGION)[t];
+    }
+    const int co = c0 + i;
+    const long long n = n0 + wave * 16 + 4 * kg;
+    const long long b = n / P;
+    const long long off = (b * cout + co) * P + (n - b * P);
+    f32x4 v = acc + bias[co];
+    if (res) v += *reinterpret_cast<const f32x4*>(res + off);
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<f32x4*>(out + off) = v;
+}
+
+template <int KS, int TRIPS>
+int launch_c1s(const float* x, const float* wpack16, const float* bias, const float* res, const float* in_bias, float* out, long long pixels,
+               int cin, int cout, int P, int relu, hipStream_t s, int wo = 0) {
+    constexpr int LDS = KS * (2 * 32 * 68 + 2 * 2 * 16 * C1_LDW) * 4;
+    const dim3 grid((unsigned)(pixels / 64), cout / 16), block(256 * KS);
+    if (wo) {
+        auto kern = conv1x1_small_kernel<KS, 2, TRIPS>;
+        SE_ENSURE_LDS(kern, LDS);
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, x, wpack16, bias, res, in_bias, out, cin, cout, P, relu, wo);
+    } else if (in_bias) {
+        auto kern = conv1x1_small_kernel<KS, 1, TRIPS>;
+        SE_ENSURE_LDS(kern, LDS);
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, x, wpack16, bias, res, in_bias, out, cin, cout, P, relu, 0);
+    } else {
+        auto kern = conv1x1_small_kernel<KS, 0, TRIPS>;
+        SE_ENSURE_LDS(kern, LDS);
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, x, wpack16, bias, res, in_bias, out, cin, cout, P, relu, 0);
+    }
+    SE_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int BP, int BC, int KS, int TRIPS>
 int launch_c1t(const float* x, const float* wpack, const float* bias, const float* res, const float* in_bias, float* out, long long pixels,
                int cin, int cout, int P, int relu, hipStream_t s, int wo) {
@@ -300,4 +446,39 @@ extern "C" int se_conv2d_1x1_s2_f32(const float* x, const float* wpack, const fl
                                 : launch_c1<64, 128, 1>(x, wpack, bias, nullptr, nullptr, out, pixels, cin, cout, hw, relu, s, wo);
     return split ? launch_c1<64, 64, 2>(x, wpack, bias, nullptr, nullptr, out, pixels, cin, cout, hw, relu, s, wo)
                  : launch_c1<64, 64, 1>(x, wpack, bias, nullptr, nullptr, out, pixels, cin, cout, hw, relu, s, wo);
+}
+
+// The small-M form: 64 pixels x 16 channels per workgroup, k steps over four (cin % 128 == 0) or two (cin % 64 == 0) wave groups; for the
+// launches of batch 1-2 that se_conv2d_1x1_f32 would run with a handful of workgroups (a 64-pixel map gives it cout / 64, this one cout / 16
+// with four times the waves each).  wpack16 = the folded [cout][cin] matrix as [cout / 16][cin / 16][16][16].  cin % 64 == 0, cout % 16 == 0,
+// hw % 16 == 0, batch * hw % 64 == 0; SE_ERR_BAD_ARG otherwise.  Same arithmetic, another summation order (k steps interleaved over the groups).
+static int c1_small(const float* x, const float* wpack16, const float* bias, const float* residual, const float* in_bias, float* out, int batch,
+                    int cin, int cout, int hw, int relu, void* stream, int wo) {
+    if (batch <= 0 || cin <= 0 || (cin & 63) || cout <= 0 || (cout & 15) || hw <= 0 || (hw & 15) || !x || !wpack16 || !bias || !out) return SE_ERR_BAD_ARG;
+    const long long pixels = (long long)batch * hw;
+    if (pixels % 64) return SE_ERR_BAD_ARG;
+    hipStream_t s = se_stream(stream);
+    if (cin % 128 == 0) {
+        const int trips = cin / 128;
+        if (g_variant != 78) {
+            if (trips == 2) return launch_c1s<4, 2>(x, wpack16, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s, wo);
+            if (trips == 4) return launch_c1s<4, 4>(x, wpack16, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s, wo);
+            if (trips == 8) return launch_c1s<4, 8>(x, wpack16, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s, wo);
+            if (trips == 16) return launch_c1s<4, 16>(x, wpack16, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s, wo);
+        }
+        return launch_c1s<4, 0>(x, wpack16, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s, wo);
+    }
+    return launch_c1s<2, 0>(x, wpack16, bias, residual, in_bias, out, pixels, cin, cout, hw, relu, s, wo);
+}
+
+extern "C" int se_conv2d_1x1_small_f32(const float* x, const float* wpack16, const float* bias, const float* residual, const float* in_bias,
+                                       float* out, int batch, int cin, int cout, int hw, int relu, void* stream) {
+    return c1_small(x, wpack16, bias, residual, in_bias, out, batch, cin, cout, hw, relu, stream, 0);
+}
+
+// ... and its stride-2 form: x [batch][cin][2 ho][2 wo] -> out [batch][cout][ho][wo] = W x[:, :, ::2, ::2] + bias (+ ReLU); wo % 4 == 0.
+extern "C" int se_conv2d_1x1_small_s2_f32(const float* x, const float* wpack16, const float* bias, float* out, int batch, int cin, int cout, int ho,
+                                          int wo, int relu, void* stream) {
+    if (ho <= 0 || wo <= 0 || (wo & 3)) return SE_ERR_BAD_ARG;
+    return c1_small(x, wpack16, bias, nullptr, nullptr, out, batch, cin, cout, ho * wo, relu, stream, wo);
 }

@@ -157,6 +157,7 @@ class FoldedBackbone:
         self.conv3x3_min_wg = int(os.environ.get("SCENEEGO_CONV3X3_MIN_WG", self.CONV3X3_MIN_WORKGROUPS))
         self.conv1x1_min_wg = int(os.environ.get("SCENEEGO_CONV1X1_MIN_WG", self.CONV1X1_MIN_WORKGROUPS))    # A/B knobs of the routing rule
         self.conv1x1_max_cin = int(os.environ.get("SCENEEGO_CONV1X1_MAX_CIN", self.CONV1X1_MAX_CIN))
+        self.conv1x1_small_max_wg = int(os.environ.get("SCENEEGO_CONV1X1_SMALL_MAX_WG", self.CONV1X1_SMALL_MAX_WORKGROUPS))
         self.memory_format = torch.channels_last if channels_last else torch.contiguous_format
         cvt = lambda wb: (wb[0].to(dtype).contiguous(memory_format=self.memory_format), wb[1].to(dtype))
         self.stem = cvt(_fold(net.conv1.weight, net.bn1))
@@ -194,6 +195,7 @@ class FoldedBackbone:
     # on se_conv2d_1x1_f32 - one MFMA GEMM with bias, residual add and ReLU in its epilogue (round 6) - where the shape is covered and
     # large enough to fill the chip; SCENEEGO_CONV1X1=0 keeps MIOpen + se_bias_act_nchw_f32 for all of them (A/B).
     CONV1X1_MIN_WORKGROUPS = 64        # from a quarter of a workgroup per CU on (batch 1 as a graph: 414.4 frames/s with 256, 417.3 / 420.8 / 418.3 with 128 / 64 / 0; tools/ab_conv1x1_b1g.sh)
+    CONV1X1_SMALL_MAX_WORKGROUPS = 512  # the small-M form (se_conv2d_1x1_small_f32) for what is left, up to this many of ITS workgroups (batch 1-2)
     CONV1X1_MAX_CIN = 512              # ... and so they do on the long-K layers (1024 / 2048 input channels: 64 serial k steps per workgroup)
 
     def _plan(self, kind, slot, x, make):
@@ -221,6 +223,9 @@ class FoldedBackbone:
             tile = _lib.conv2d_1x1_tile(B, cin, cout, (H // 2) * (W // 2)) if ok else 0
             if tile and ((B * H * W // 4) // 64) * (cout // tile) >= self.conv1x1_min_wg:
                 return (_lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile), wb[1].float().contiguous())
+            if (ok and _lib.conv2d_1x1_small_ok(B, cin, cout, (H // 2) * (W // 2))
+                    and ((B * H * W // 4) // 64) * (cout // 16) <= self.conv1x1_small_max_wg):
+                return (_lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), 16), wb[1].float().contiguous())      # the small-M form
             return False
 
         p = self._plan("pw_s2", slot, x, make)
@@ -237,14 +242,20 @@ class FoldedBackbone:
         def make():
             B, cin, H, W = x.shape
             cout = wb[0].shape[0]
-            tile = _lib.conv2d_1x1_tile(B, cin, cout, H * W) if (self.dtype == torch.float32 and self.conv1x1) else 0
+            if self.dtype != torch.float32 or not self.conv1x1:
+                return False
+            tile = _lib.conv2d_1x1_tile(B, cin, cout, H * W)
             if tile and cin <= self.conv1x1_max_cin and ((B * H * W) // 64) * (cout // tile) >= self.conv1x1_min_wg:
-                return (_lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile), wb[1].float().contiguous())
+                return (1, _lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile), wb[1].float().contiguous())
+            # batch 1-2: few pixels against megabytes of weights - 64 x 16 tiles, k over four wave groups
+            if _lib.conv2d_1x1_small_ok(B, cin, cout, H * W) and ((B * H * W) // 64) * (cout // 16) <= self.conv1x1_small_max_wg:
+                return (2, _lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), 16), wb[1].float().contiguous())
             return False
 
         p = self._plan("pw", slot, x, make)
         if p:
-            return _lib.conv2d_1x1(x, p[0], p[1], residual, relu, in_bias)
+            fn = _lib.conv2d_1x1 if p[0] == 1 else _lib.conv2d_1x1_small
+            return fn(x, p[1], p[2], residual, relu, in_bias)
         if in_bias is not None:
             x = _lib.bias_act_nchw(x, in_bias, None, True)
         return _lib.bias_act_nchw(F.conv2d(x, wb[0]), wb[1], residual, relu)

@@ -488,6 +488,33 @@ def test_conv2d_1x1_fused_gemm_vs_float64(B, cin, cout, H, residual, relu):
     assert _lib.conv2d_1x1_tile(1, cin, cout, 40) == 0
 
 
+@pytest.mark.parametrize("B,cin,cout,H,residual,relu", [
+    (1, 512, 128, 32, False, True), (1, 1024, 256, 16, False, True), (1, 2048, 512, 8, False, True), (1, 512, 2048, 8, True, True),
+    (2, 1024, 512, 16, False, True), (1, 256, 128, 16, True, False), (4, 64, 48, 4, False, False), (1, 192, 16, 8, True, True)])
+def test_conv2d_1x1_small_m_form_vs_float64(B, cin, cout, H, residual, relu):
+    """se_conv2d_1x1_small_f32 (the long-K 1x1 layers at batch 1-2: 64 x 16 tiles, k over four / two wave groups) against a float64 product,
+    with and without the input-side bias + ReLU; 4 x 4 maps (a 64-pixel tile spans four samples), cin = 192 (two groups, run-time loop)."""
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(B, cin, H, H, generator=g)
+    w = torch.randn(cout, cin, generator=g) * (2.0 / cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(B, cout, H, H, generator=g) if residual else None
+    ib = torch.randn(cin, generator=g)
+    assert _lib.conv2d_1x1_small_ok(B, cin, cout, H * H) and not _lib.conv2d_1x1_small_ok(B, cin + 32, cout, H * H)
+    wp = _lib.conv2d_1x1_pack(w, 16).to(DEV)
+    for inb in (None, ib):
+        xin = x.double() if inb is None else (x.double() + inb.double().view(1, -1, 1, 1)).clamp_min(0)
+        want = torch.einsum("oc,bchw->bohw", w.double(), xin) + b.double().view(1, -1, 1, 1)
+        if residual:
+            want = want + r.double()
+        if relu:
+            want = want.clamp_min(0)
+        got = _lib.conv2d_1x1_small(x.to(DEV), wp, b.to(DEV), r.to(DEV) if residual else None, relu, None if inb is None else inb.to(DEV))
+        assert got.shape == (B, cout, H, H) and bool(torch.isfinite(got).all())
+        err = float((got.double().cpu() - want).abs().max())
+        assert err < 1e-5 * float(want.abs().max()), err
+
+
 def test_bias_relu_maxpool_stem_tail_exact():
     """se_bias_relu_maxpool3x3s2_f32 against max_pool2d(relu(x + bias), 3, 2, 1): the same float32 operations in another order (max is
     exact, relu(. + b) monotone) - bit-identical, borders included."""
@@ -512,6 +539,10 @@ def test_conv2d_1x1_stride2_vs_float64(B, cin, cout, ho, wo):
     want = torch.einsum("oc,bchw->bohw", w.double(), x[:, :, ::2, ::2].double()) + b.double().view(1, -1, 1, 1)
     tile = _lib.conv2d_1x1_tile(B, cin, cout, ho * wo)
     got = _lib.conv2d_1x1_s2(x.to(DEV), _lib.conv2d_1x1_pack(w, tile).to(DEV), b.to(DEV), False)
+    assert got.shape == (B, cout, ho, wo) and bool(torch.isfinite(got).all())
+    assert float((got.double().cpu() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    # the small-M form of the same operator (16-channel packing)
+    got = _lib.conv2d_1x1_s2(x.to(DEV), _lib.conv2d_1x1_pack(w, 16).to(DEV), b.to(DEV), False)
     assert got.shape == (B, cout, ho, wo) and bool(torch.isfinite(got).all())
     assert float((got.double().cpu() - want).abs().max()) < 1e-5 * float(want.abs().max())
 
