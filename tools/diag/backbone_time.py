@@ -20,7 +20,7 @@ steps = steps[-N:]
 tot = {}
 for s in steps:
     for n, us in s:
-        k = ("conv1x1 (fused GEMM)" if "conv1x1_kernel" in n else "conv3x3 (direct MFMA)" if "conv3x3_kernel" in n else "stem tail" if "bias_relu_maxpool" in n else "bias_act" if "bias_act" in n else "deconv assemble" if "assemble" in n
+        k = ("conv1x1 (fused GEMM)" if ("conv1x1_kernel" in n or "conv1x1_small_kernel" in n) else "conv3x3 (direct MFMA)" if "conv3x3_kernel" in n else "stem tail" if "bias_relu_maxpool" in n else "bias_act" if "bias_act" in n else "deconv assemble" if "assemble" in n
              else "Tensile GEMM" if n.startswith("Cijk") else "MIOpen asm / igemm / CK" if ("miopen" in n.lower() or "igemm" in n or "ck" in n[:8]) else "torch / other")
         e = tot.setdefault(k, [0, 0.0])
         e[0] += 1
