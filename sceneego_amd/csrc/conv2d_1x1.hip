@@ -1,11 +1,14 @@
 // 1x1 convolutions of the 2-D backbone as a float32 MFMA GEMM with the whole epilogue fused (round 6).
 //
-// Stands in for the three 1x1 convolutions of every ResNet-50 Bottleneck - conv1, conv3 and the stride-1 downsample - with their folded
-// BatchNorm, the residual add and the ReLU (reference network/pose_resnet.py:52-90, Bottleneck.forward :72-90): 32 of the backbone's 53
-// convolutions.  MIOpen runs them as strided-batched Tensile GEMMs at 32-68 TFLOP/s (profiles/r04_backbone_solvers.txt) and the bias /
-// residual / ReLU cost one more pass each (se_bias_act_nchw_f32): 1.04 + 0.22 ms of the 2.03 ms backbone at B = 8.  Most of these layers
-// are short-K products (K = 64 ... 512 channels) over tens of thousands of pixels: the expanding convolutions of layer1 move 75 MB for
-// 2 MFLOP per 64 KB - they are bound by bytes, and a fused epilogue removes two of their four tensor passes.
+// Stands in for the 1x1 convolutions of every ResNet-50 Bottleneck - conv1, conv3 and the downsample convolution (stride 1 and 2) - with
+// their folded BatchNorm, the residual add and the ReLU (reference network/pose_resnet.py:52-90, Bottleneck.forward :72-90, downsample
+// :140-146): 36 of the backbone's 53 convolutions.  MIOpen runs them as strided-batched Tensile GEMMs at 32-68 TFLOP/s
+// (profiles/r04_backbone_solvers.txt) and the bias / residual / ReLU cost one more pass each (se_bias_act_nchw_f32): 1.04 + 0.22 ms of the
+// 2.03 ms backbone at B = 8.  Most of these layers are short-K products (K = 64 ... 512 channels) over tens of thousands of pixels: the
+// expanding convolutions of layer1 move 75 MB for 2 GFLOP - they are bound by bytes, and a fused epilogue removes two of their four tensor
+// passes (three with in_bias: the producing 3x3 convolution's bias + ReLU applied on the way into LDS).
+// Three forms: conv1x1_kernel (64 pixels x 64 / 128 channels per workgroup: batch 8), its stride-2 mode, and conv1x1_small_kernel (64 x 16,
+// the k steps over four wave groups: the long-K layers at batch 1-4).
 //
 // NCHW in, NCHW out (what the 3x3 convolutions of MIOpen around them read and write).  GEMM roles: MFMA rows = PIXELS, MFMA columns =
 // output channels, so a lane's D fragment is 4 consecutive pixels of one channel: one 16-byte store (and one 16-byte residual load) in NCHW.

@@ -1,7 +1,9 @@
-// 3x3 convolutions (stride 1, padding 1) of the 2-D backbone's deep stages as a direct float32 MFMA product (round 6).
+// 3x3 convolutions (padding 1, stride 1 or 2) of the 2-D backbone's Bottlenecks as a direct float32 MFMA product (round 6).
 //
-// Stands in for conv2 of the Bottlenecks of layer3 / layer4 (reference network/pose_resnet.py:52-90, `conv3x3` :22-25 - 256 -> 256 at
-// 16 x 16 and 512 -> 512 at 8 x 8 for a 256 x 256 image): few pixels, many channels - 2.4 GFLOP against 2.4 - 9.4 MB of weights per launch.
+// Stands in for conv2 (`conv3x3`, reference network/pose_resnet.py:22-25, run at :78) of all sixteen Bottlenecks (:52-90).  Built for the
+// deep stages - 256 -> 256 at 16 x 16 and 512 -> 512 at 8 x 8 for a 256 x 256 image: few pixels, many channels, 2.4 GFLOP against 2.4 - 9.4 MB
+// of weights per launch - and for the three stride-2 layers; on the wide maps of layer1 / layer2 it is level with MIOpen at batch 8 and ahead
+// at batch 1.
 // MIOpen's picks there: its float32 Winograd assembly kernel (vector ALUs, 38 us) and, for the 8 x 8 maps, an NHWC implicit GEMM between
 // three layout transposes and a workspace fill (46 + 20 us).  Here: K = 9 * cin walked as (16-channel step, tap), MFMA rows = the 64
 // pixels of a TH x TW tile, MFMA columns = BC output channels; a workgroup is KS groups of four waves which take alternate k steps
