@@ -1467,3 +1467,27 @@ def test_conv3d_fused_skip_convolution_quad_planar_skip_input(B, dim):
         ref = F.relu(bn.cpu()(conv.cpu()(_ncdhw(_unquad(a).cpu()))) + bns.cpu()(skip.cpu()(_ncdhw(xs.cpu()))))
     err = float((_ncdhw(_unquad(got).cpu()) - ref).abs().max())
     assert err < 2e-5 * float(ref.abs().max()), err
+
+
+def test_integration_md_bottleneck_stub_runs_as_written():
+    """The reference-side binding INTEGRATION.md shows for Bottleneck.forward (raw ctypes on the shared library, no sceneego_amd import in
+    the stub itself) is executed as written and compared with the reference module's own forward."""
+    import re
+    from sceneego_amd import pose_resnet
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    block = next(b for b in re.findall(r"```python\n(.*?)```", text, re.S) if "def bottleneck_forward(" in b)
+    head = block[:block.index("def ")]
+    stub = block[block.index("def bottleneck_forward("):]
+    stub = stub[:stub.index("# (sceneego_amd/pose_resnet.py:FoldedBackbone")]
+    ns = {}
+    exec(head.replace('ctypes.CDLL("libsceneego_hip.so")', f'ctypes.CDLL({_lib.LIB_PATH!r})'), ns)
+    exec(stub, ns)
+    torch.manual_seed(2)
+    blk = pose_resnet.Bottleneck(256, 64).to(DEV).eval()
+    for bn in (blk.bn1, blk.bn2, blk.bn3):
+        bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.7, 1.3); bn.weight.data.uniform_(0.7, 1.3); bn.bias.data.uniform_(-0.2, 0.2)
+    x = torch.randn(8, 256, 16, 16, device=DEV)
+    with torch.no_grad():
+        want = blk(x)
+        got = ns["bottleneck_forward"](blk, x)
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
