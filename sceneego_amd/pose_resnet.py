@@ -209,6 +209,16 @@ class FoldedBackbone:
             p = plans[key] = make()
         return p
 
+    def _packed(self, kind, slot, tile, device, make):
+        """Packed weights are shared by every plan of a layer that asks for the same tile (plans are per input shape: a caller that walks
+        through many batch sizes must not get a copy of the weights for each)."""
+        packs = self.__dict__.setdefault("_packs", {})
+        key = (kind, slot, tile, device)
+        w = packs.get(key)
+        if w is None:
+            w = packs[key] = make()
+        return w
+
     def _pw_s2(self, x, wb, slot):
         """The stride-2 1x1 downsample convolution + bias: se_conv2d_1x1_s2_f32 when covered (MIOpen's route: a transpose in, a GEMM, a
         transpose out, then the bias pass)."""
@@ -222,10 +232,12 @@ class FoldedBackbone:
                   and cin <= 2 * self.conv1x1_max_cin)
             tile = _lib.conv2d_1x1_tile(B, cin, cout, (H // 2) * (W // 2)) if ok else 0
             if tile and ((B * H * W // 4) // 64) * (cout // tile) >= self.conv1x1_min_wg:
-                return (_lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile), wb[1].float().contiguous())
+                return (self._packed("1x1", slot, tile, x.device, lambda: _lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile)),
+                        self._packed("bias", slot, 0, x.device, lambda: wb[1].float().contiguous()))
             if (ok and _lib.conv2d_1x1_small_ok(B, cin, cout, (H // 2) * (W // 2))
                     and ((B * H * W // 4) // 64) * (cout // 16) <= self.conv1x1_small_max_wg):
-                return (_lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), 16), wb[1].float().contiguous())      # the small-M form
+                return (self._packed("1x1", slot, 16, x.device, lambda: _lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), 16)),
+                        self._packed("bias", slot, 0, x.device, lambda: wb[1].float().contiguous()))      # the small-M form
             return False
 
         p = self._plan("pw_s2", slot, x, make)
@@ -246,10 +258,12 @@ class FoldedBackbone:
                 return False
             tile = _lib.conv2d_1x1_tile(B, cin, cout, H * W)
             if tile and cin <= self.conv1x1_max_cin and ((B * H * W) // 64) * (cout // tile) >= self.conv1x1_min_wg:
-                return (1, _lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile), wb[1].float().contiguous())
+                return (1, self._packed("1x1", slot, tile, x.device, lambda: _lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), tile)),
+                        self._packed("bias", slot, 0, x.device, lambda: wb[1].float().contiguous()))
             # batch 1-2: few pixels against megabytes of weights - 64 x 16 tiles, k over four wave groups
             if _lib.conv2d_1x1_small_ok(B, cin, cout, H * W) and ((B * H * W) // 64) * (cout // 16) <= self.conv1x1_small_max_wg:
-                return (2, _lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), 16), wb[1].float().contiguous())
+                return (2, self._packed("1x1", slot, 16, x.device, lambda: _lib.conv2d_1x1_pack(wb[0].reshape(cout, cin).float(), 16)),
+                        self._packed("bias", slot, 0, x.device, lambda: wb[1].float().contiguous()))
             return False
 
         p = self._plan("pw", slot, x, make)
@@ -280,10 +294,10 @@ class FoldedBackbone:
             if (stride in (1, (1, 1)) and H * W <= self.CONV3X3_MAX_PIXELS and ((B * H * W) // 64) * (cout // 16) >= self.conv3x3_min_wg):
                 tile = _lib.conv2d_3x3_tile(B, cin, cout, H, W)
                 if tile:
-                    return (1, _lib.conv2d_3x3_pack(wb[0].float(), tile))
+                    return (1, self._packed("3x3", slot, tile, x.device, lambda: _lib.conv2d_3x3_pack(wb[0].float(), tile)))
             if (stride in (2, (2, 2)) and H % 2 == 0 and W % 2 == 0 and (H * W) // 4 <= self.CONV3X3_S2_MAX_PIXELS
                     and _lib.conv2d_3x3_s2_ok(cin, cout, H // 2, W // 2)):
-                return (2, _lib.conv2d_3x3_pack(wb[0].float(), 16))
+                return (2, self._packed("3x3", slot, 16, x.device, lambda: _lib.conv2d_3x3_pack(wb[0].float(), 16)))
             return False
 
         p = self._plan("c3", slot, x, make)
